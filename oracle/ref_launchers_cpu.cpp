@@ -1,0 +1,706 @@
+// oracle/ref_launchers_cpu.cpp
+// =====================================================================================
+// TEST INFRASTRUCTURE ONLY.  CPU restatement ("oracle") of the reference's CUDA operator
+// surface for the resident decode path.  Nothing under ntransformer_amd/ (the product) may
+// include, link or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg use it, and only as the checker / the reported CPU baseline.
+//
+// What it restates (file:line into /root/reference, snapshot 2026-02-27):
+//   src/cuda/gemm.cu:32-86     gemv_q4_0_kernel          -> gemv_q4_0_row
+//   src/cuda/gemm.cu:92-152    gemv_q8_0_kernel          -> gemv_q8_0_row
+//   src/cuda/gemm.cu:158-255   gemv_q4_k_kernel          -> gemv_q4_k_row
+//   src/cuda/gemm.cu:265-365   gemv_q5_k_kernel          -> gemv_q5_k_row
+//   src/cuda/gemm.cu:387-470   gemv_q6_k_kernel          -> gemv_q6_k_row
+//   src/cuda/gemm.cu:476-540   gemv_f16_add_kernel       -> launch_gemv_add
+//   src/cuda/gemm.cu:546-612   gemv_f16_kernel           -> gemv_f16_row
+//   src/cuda/gemm.cu:617-671   gemv_f32_kernel           -> gemv_f32_row
+//   src/cuda/gemm.cu:713-725   silu_elementwise_mul      -> launch_silu_mul
+//   src/cuda/gemm.cu:748-805   launch_gemv (dtype switch, unsupported dtype -> stderr only)
+//   src/cuda/rmsnorm.cu:16-70,129-148   rmsnorm_kernel<BS> + block-size rule
+//   src/cuda/rotary.cu:16-62,65-107     rope_kernel / rope_interleaved_kernel
+//   src/cuda/attention.cu:108-202       attention_decode_generic_kernel
+//   src/cuda/attention.cu:216-311       attention_prefill_kernel
+//   src/cuda/attention.cu:316-342       copy_to_kv_cache_kernel (F32 -> F16, RNE)
+//   src/cuda/elementwise.cu:11-84       add / add_inplace / copy / cosine_similarity
+//   src/model/transformer.cpp:394-599   embed_tokens row dequant (oracle_embed_row)
+//
+// Fidelity rules.  The CUDA kernels accumulate per *lane* of a 32-wide warp (lane t owns blocks
+// t, t+32, ...), then combine lanes with a 5-step xor butterfly; block reductions go through a
+// 32-slot shared array and a second butterfly.  This file keeps exactly that association order
+// (so the F32 rounding sequence is the reference's), uses fmaf() where nvcc's default
+// -fmad=true contracts `a*b+c`, and IEEE libm (expf/sinf/cosf/powf, 1/sqrtf) where the CUDA
+// build used --use_fast_math approximations (CMakeLists.txt:20) -- those approximations cannot
+// be reproduced without an NVIDIA GPU, which is why parity is stated as |dlogit| <= 1e-3.
+//
+// PARITY PIN.  Pinned against: the known-answer vectors in the reference's tests/test_gemm.cpp
+// (tests/test_oracle_kat.py), the independent numpy dequantisers in the reference's
+// tools/decompose_gguf.py (tests/golden/dequant_*.npz, made by tools/make_golden_dequant.py), and
+// end-to-end through the reference's own unmodified host code linked against this file
+// (oracle/_ref/ref_logits, tests/golden/tiny_*_logits.npy).  The device arithmetic itself
+// (src/cuda/*.cu) cannot be executed here (no nvcc, no NVIDIA GPU): for Q8_0/Q4_K/Q5_K GEMV,
+// RoPE, KV store and attention the reference has no tests of its own, so those rows are
+// "pinned by restatement + independent dequant only" (see DESIGN.md, section Oracle).
+// =====================================================================================
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#ifdef ORACLE_WITH_REFERENCE_HEADERS
+#include "core/types.h"      // nt::DType from the reference (only when linking with its host TUs)
+#else
+namespace nt {
+// Mirror of the numeric values in reference src/core/types.h:24-35 (the ABI contract).
+enum class DType : uint8_t { F32 = 0, F16 = 1, Q8_0 = 2, Q4_0 = 3, Q4_K_M = 4, Q6_K = 5, Q5_K = 6, Q2_K = 7, I32 = 8, COUNT };
+}
+#endif
+
+namespace {
+
+// ---------------------------------------------------------------- fp16 <-> fp32 (bit exact)
+inline float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t exp = (h >> 10) & 0x1Fu;
+    uint32_t man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {  // subnormal: renormalise
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3FFu) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7F800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 112u) << 23) | (man << 13);
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// round-to-nearest-even, as __float2half (attention.cu:338-339)
+inline uint16_t f2h(float f) {
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) {  // inf / nan
+        return (uint16_t)(sign | 0x7C00u | ((x > 0x7F800000u) ? 0x200u | ((x >> 13) & 0x3FFu) : 0u));
+    }
+    if (x >= 0x477FF000u) {  // >= 65520 rounds to inf
+        return (uint16_t)(sign | 0x7C00u);
+    }
+    if (x < 0x38800000u) {  // result is subnormal (or zero) in fp16
+        if (x < 0x33000000u) return (uint16_t)sign;  // < 2^-25 -> 0
+        const int e = (int)(x >> 23);                 // biased fp32 exponent, 102..112
+        uint32_t man = (x & 0x7FFFFFu) | 0x800000u;   // 24-bit significand
+        const int shift = 126 - e;                    // 14..24
+        uint32_t half = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1u);
+        const uint32_t halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (half & 1u))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    // normal
+    uint32_t half = ((x >> 13) & 0x3FFu) | ((((x >> 23) - 112u) & 0x1Fu) << 10);
+    const uint32_t rem = x & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) ++half;  // may carry into exponent: correct
+    return (uint16_t)(sign | half);
+}
+
+inline uint16_t rd16(const uint8_t* p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+
+// 5-step xor butterfly over a 32-lane warp; returns what lane 0 holds afterwards
+// (gemm.cu:76-80 and every other `__shfl_xor_sync` loop).
+inline float butterfly32_sum(float* v) {
+    for (int off = 16; off > 0; off >>= 1) {
+        float t[32];
+        for (int i = 0; i < 32; ++i) t[i] = v[i] + v[i ^ off];
+        std::memcpy(v, t, sizeof(t));
+    }
+    return v[0];
+}
+
+// Block-wide sum the way rmsnorm.cu:37-56 / attention.cu:172-182 do it: per-warp butterfly, lane 0
+// of each warp -> shared[wid], warp 0 reloads (tid < nwarps ? shared[lane] : 0) and butterflies.
+float block_sum(const std::vector<float>& per_thread) {
+    const int n = (int)per_thread.size();
+    const int nw = n / 32;
+    float shared[32];
+    for (int w = 0; w < nw; ++w) {
+        float lane[32];
+        std::memcpy(lane, per_thread.data() + 32 * w, sizeof(lane));
+        shared[w] = butterfly32_sum(lane);
+    }
+    float lane[32];
+    for (int i = 0; i < 32; ++i) lane[i] = (i < nw) ? shared[i] : 0.0f;
+    return butterfly32_sum(lane);
+}
+
+// ---------------------------------------------------------------- GEMV rows (one warp per row)
+// K-quant 6-bit scale/min unpack, gemm.cu:206-222 (== 308-324).
+inline void kq_scale_min(const uint8_t* sc, int j, uint8_t& s, uint8_t& m) {
+    if (j < 4) {
+        s = sc[j] & 0x3F;
+        m = sc[j + 4] & 0x3F;
+    } else {
+        s = (uint8_t)((sc[j + 4] & 0x0F) | ((sc[j - 4] >> 6) << 4));
+        m = (uint8_t)((sc[j + 4] >> 4) | ((sc[j] >> 6) << 4));
+    }
+}
+
+float gemv_q4_0_row(const uint8_t* row, const float* x, int in) {  // gemm.cu:52-85
+    const int nb = in / 32;
+    float lane[32];
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int b = t; b < nb; b += 32) {
+            const uint8_t* blk = row + (size_t)b * 18;
+            const float d = h2f(rd16(blk));
+            const uint8_t* qs = blk + 2;
+            const float* xb = x + b * 32;
+            float bs = 0.0f;
+            for (int j = 0; j < 16; ++j) {
+                const float lo = (float)(int8_t)((qs[j] & 0x0F) - 8);
+                const float hi = (float)(int8_t)((qs[j] >> 4) - 8);
+                bs += fmaf(lo, xb[j], hi * xb[j + 16]);
+            }
+            sum = fmaf(d, bs, sum);
+        }
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+float gemv_q8_0_row(const uint8_t* row, const float* x, int in) {  // gemm.cu:121-151
+    const int nb = in / 32;
+    float lane[32];
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int b = t; b < nb; b += 32) {
+            const uint8_t* blk = row + (size_t)b * 34;
+            const float d = h2f(rd16(blk));
+            const int8_t* qs = (const int8_t*)(blk + 2);
+            const float* xb = x + b * 32;
+            float bs = 0.0f;
+            for (int j = 0; j < 32; ++j) bs = fmaf((float)qs[j], xb[j], bs);
+            sum = fmaf(d, bs, sum);
+        }
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+float gemv_q4_k_row(const uint8_t* row, const float* x, int in) {  // gemm.cu:185-254
+    const int nb = in / 256;
+    float lane[32];
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int b = t; b < nb; b += 32) {
+            const uint8_t* blk = row + (size_t)b * 144;
+            const float d = h2f(rd16(blk)), dmin = h2f(rd16(blk + 2));
+            const uint8_t* scales = blk + 4;
+            const uint8_t* qs = blk + 16;
+            float bsum = 0.0f;
+            for (int c = 0; c < 4; ++c) {
+                uint8_t sl, ml, sh, mh;
+                kq_scale_min(scales, 2 * c, sl, ml);
+                kq_scale_min(scales, 2 * c + 1, sh, mh);
+                const float d1 = d * sl, m1 = dmin * ml, d2 = d * sh, m2 = dmin * mh;
+                const float* xc = x + b * 256 + c * 64;
+                const uint8_t* q = qs + c * 32;
+                float s_lo = 0, s_hi = 0, sx_lo = 0, sx_hi = 0;
+                for (int l = 0; l < 32; ++l) {
+                    s_lo = fmaf((float)(q[l] & 0x0F), xc[l], s_lo);
+                    s_hi = fmaf((float)(q[l] >> 4), xc[l + 32], s_hi);
+                    sx_lo += xc[l];
+                    sx_hi += xc[l + 32];
+                }
+                float tacc = d1 * s_lo;
+                tacc = fmaf(-m1, sx_lo, tacc);
+                tacc = fmaf(d2, s_hi, tacc);
+                tacc = fmaf(-m2, sx_hi, tacc);
+                bsum += tacc;
+            }
+            sum += bsum;
+        }
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+float gemv_q5_k_row(const uint8_t* row, const float* x, int in) {  // gemm.cu:292-364
+    const int nb = in / 256;
+    float lane[32];
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int b = t; b < nb; b += 32) {
+            const uint8_t* blk = row + (size_t)b * 176;
+            const float d = h2f(rd16(blk)), dmin = h2f(rd16(blk + 2));
+            const uint8_t* scales = blk + 4;
+            const uint8_t* qh = blk + 16;
+            const uint8_t* qlb = blk + 48;
+            float bsum = 0.0f;
+            uint8_t u1 = 1, u2 = 2;
+            for (int c = 0; c < 4; ++c) {
+                uint8_t sl, ml, sh, mh;
+                kq_scale_min(scales, 2 * c, sl, ml);
+                kq_scale_min(scales, 2 * c + 1, sh, mh);
+                const float d1 = d * sl, m1 = dmin * ml, d2 = d * sh, m2 = dmin * mh;
+                const float* xc = x + b * 256 + c * 64;
+                const uint8_t* ql = qlb + c * 32;
+                float s_lo = 0, s_hi = 0, sx_lo = 0, sx_hi = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const int lo = (ql[l] & 0x0F) + ((qh[l] & u1) ? 16 : 0);
+                    const int hi = (ql[l] >> 4) + ((qh[l] & u2) ? 16 : 0);
+                    s_lo = fmaf((float)lo, xc[l], s_lo);
+                    s_hi = fmaf((float)hi, xc[l + 32], s_hi);
+                    sx_lo += xc[l];
+                    sx_hi += xc[l + 32];
+                }
+                float tacc = d1 * s_lo;
+                tacc = fmaf(-m1, sx_lo, tacc);
+                tacc = fmaf(d2, s_hi, tacc);
+                tacc = fmaf(-m2, sx_hi, tacc);
+                bsum += tacc;
+                u1 = (uint8_t)(u1 << 2);
+                u2 = (uint8_t)(u2 << 2);
+            }
+            sum += bsum;
+        }
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+float gemv_q6_k_row(const uint8_t* row, const float* x, int in) {  // gemm.cu:415-469
+    const int nb = in / 256;
+    float lane[32];
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int b = t; b < nb; b += 32) {
+            const uint8_t* blk = row + (size_t)b * 210;
+            const float d = h2f(rd16(blk + 208));
+            const uint8_t* ql = blk;
+            const uint8_t* qh = blk + 128;
+            const int8_t* sc = (const int8_t*)(blk + 192);
+            float bs = 0.0f;
+            for (int hf = 0; hf < 2; ++hf) {
+                const float* xh = x + b * 256 + hf * 128;
+                for (int l = 0; l < 32; ++l) {
+                    const int is = l / 16;
+                    const int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                    const int q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                    const int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                    const int q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                    bs = fmaf((float)sc[is + 0] * (float)q1, xh[l], bs);
+                    bs = fmaf((float)sc[is + 2] * (float)q2, xh[l + 32], bs);
+                    bs = fmaf((float)sc[is + 4] * (float)q3, xh[l + 64], bs);
+                    bs = fmaf((float)sc[is + 6] * (float)q4, xh[l + 96], bs);
+                }
+                ql += 64; qh += 32; sc += 8;
+            }
+            sum = fmaf(d, bs, sum);
+        }
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+float gemv_f16_row(const uint16_t* w, const float* x, int in) {  // gemm.cu:575-611
+    float lane[32];
+    const int in8 = (in / 8) * 8;
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int i = t * 8; i < in8; i += 256) {
+            float acc = h2f(w[i]) * x[i];
+            for (int k = 1; k < 8; ++k) acc = fmaf(h2f(w[i + k]), x[i + k], acc);
+            sum += acc;
+        }
+        for (int i = in8 + t; i < in; i += 32) sum = fmaf(h2f(w[i]), x[i], sum);
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+float gemv_f32_row(const float* w, const float* x, int in) {  // gemm.cu:647-670
+    float lane[32];
+    const int in4 = (in / 4) * 4;
+    for (int t = 0; t < 32; ++t) {
+        float sum = 0.0f;
+        for (int i = t * 4; i < in4; i += 128) {
+            float acc = w[i] * x[i];
+            acc = fmaf(w[i + 1], x[i + 1], acc);
+            acc = fmaf(w[i + 2], x[i + 2], acc);
+            acc = fmaf(w[i + 3], x[i + 3], acc);
+            sum += acc;
+        }
+        for (int i = in4 + t; i < in; i += 32) sum = fmaf(w[i], x[i], sum);
+        lane[t] = sum;
+    }
+    return butterfly32_sum(lane);
+}
+
+size_t row_bytes(nt::DType dt, int in) {
+    switch (dt) {
+        case nt::DType::F32: return (size_t)in * 4;
+        case nt::DType::F16: return (size_t)in * 2;
+        case nt::DType::Q8_0: return (size_t)(in / 32) * 34;
+        case nt::DType::Q4_0: return (size_t)(in / 32) * 18;
+        case nt::DType::Q4_K_M: return (size_t)(in / 256) * 144;
+        case nt::DType::Q5_K: return (size_t)(in / 256) * 176;
+        case nt::DType::Q6_K: return (size_t)(in / 256) * 210;
+        default: return 0;
+    }
+}
+
+const char* dt_name(nt::DType dt) {
+    switch (dt) {
+        case nt::DType::F32: return "F32"; case nt::DType::F16: return "F16";
+        case nt::DType::Q8_0: return "Q8_0"; case nt::DType::Q4_0: return "Q4_0";
+        case nt::DType::Q4_K_M: return "Q4_K_M"; case nt::DType::Q6_K: return "Q6_K";
+        case nt::DType::Q5_K: return "Q5_K"; case nt::DType::Q2_K: return "Q2_K";
+        case nt::DType::I32: return "I32"; default: return "UNKNOWN";
+    }
+}
+
+// scores -> softmax -> PV for one (head, query) pair; shared by decode and prefill
+// (attention.cu:126-201 and :239-310).  bs = blockDim.x.
+void attend_one(float* out, const float* q, const uint16_t* kc, const uint16_t* vc, int n_keys,
+                int kv_head, int n_kv_heads, int head_dim, float scale, int bs, bool guard_zero_sum) {
+    std::vector<float> sm((size_t)n_keys);
+    const size_t stride = (size_t)n_kv_heads * head_dim;
+    for (int pos = 0; pos < n_keys; ++pos) {
+        const uint16_t* k = kc + pos * stride + (size_t)kv_head * head_dim;
+        float s = 0.0f;
+        for (int d = 0; d < head_dim; ++d) s = fmaf(q[d], h2f(k[d]), s);
+        sm[pos] = s * scale;
+    }
+    float mx = -FLT_MAX;  // max is order independent
+    for (int pos = 0; pos < n_keys; ++pos) mx = fmaxf(mx, sm[pos]);
+    std::vector<float> part((size_t)bs, 0.0f);
+    for (int tid = 0; tid < bs; ++tid) {
+        float ls = 0.0f;
+        for (int pos = tid; pos < n_keys; pos += bs) {
+            const float v = expf(sm[pos] - mx);
+            sm[pos] = v;
+            ls += v;
+        }
+        part[tid] = ls;
+    }
+    const float total = block_sum(part);
+    const float inv = guard_zero_sum ? ((total > 0.0f) ? 1.0f / total : 0.0f) : 1.0f / total;
+    for (int pos = 0; pos < n_keys; ++pos) sm[pos] *= inv;
+    for (int d = 0; d < head_dim; ++d) {
+        float acc = 0.0f;
+        for (int pos = 0; pos < n_keys; ++pos)
+            acc = fmaf(sm[pos], h2f(vc[pos * stride + (size_t)kv_head * head_dim + d]), acc);
+        out[d] = acc;
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+// The reference's operator surface, same namespace / names / signatures as src/cuda/kernels.h,
+// so that the reference's unmodified host TUs link against this file (oracle/_ref/*).
+// =====================================================================================
+namespace nt {
+namespace cuda {
+
+void launch_gemv(float* y, const void* W, const float* x, int out_features, int in_features,
+                 DType weight_dtype, void* /*stream*/) {
+    const size_t rb = row_bytes(weight_dtype, in_features);
+    const uint8_t* base = static_cast<const uint8_t*>(W);
+    switch (weight_dtype) {
+        case DType::Q4_0: case DType::Q8_0: case DType::Q4_K_M: case DType::Q5_K: case DType::Q6_K:
+        case DType::F16: case DType::F32:
+            break;
+        default:  // gemm.cu:801-803: message only, y untouched
+            fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dt_name(weight_dtype));
+            return;
+    }
+    // x is read through shared memory in the reference; values are identical, so read x directly.
+    std::vector<float> xs(x, x + in_features);  // snapshot: y may alias x's storage in callers
+    const float* xv = xs.data();
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < out_features; ++r) {
+        const uint8_t* row = base + (size_t)r * rb;
+        float v;
+        switch (weight_dtype) {
+            case DType::Q4_0: v = gemv_q4_0_row(row, xv, in_features); break;
+            case DType::Q8_0: v = gemv_q8_0_row(row, xv, in_features); break;
+            case DType::Q4_K_M: v = gemv_q4_k_row(row, xv, in_features); break;
+            case DType::Q5_K: v = gemv_q5_k_row(row, xv, in_features); break;
+            case DType::Q6_K: v = gemv_q6_k_row(row, xv, in_features); break;
+            case DType::F16: v = gemv_f16_row((const uint16_t*)row, xv, in_features); break;
+            default: v = gemv_f32_row((const float*)row, xv, in_features); break;
+        }
+        y[r] = v;
+    }
+}
+
+void launch_gemv_add(float* y, const void* W, const float* x, int out_features, int in_features,
+                     DType weight_dtype, void* /*stream*/) {
+    if (weight_dtype != DType::F16) {  // gemm.cu:866-868
+        fprintf(stderr, "launch_gemv_add: only F16 supported (got %s)\n", dt_name(weight_dtype));
+        return;
+    }
+    std::vector<float> xs(x, x + in_features);
+    const uint16_t* w = static_cast<const uint16_t*>(W);
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < out_features; ++r)
+        y[r] += gemv_f16_row(w + (size_t)r * in_features, xs.data(), in_features);
+}
+
+void launch_silu_mul(float* output, const float* gate, const float* up, int size, void* /*stream*/) {
+    for (int i = 0; i < size; ++i) {  // gemm.cu:719-724
+        const float g = gate[i];
+        const float silu = g / (1.0f + expf(-g));
+        output[i] = silu * up[i];
+    }
+}
+
+void launch_rmsnorm(float* output, const float* input, const float* weight, int batch_size,
+                    int hidden_size, float eps, void* /*stream*/) {
+    const int bs = hidden_size <= 1024 ? 256 : (hidden_size <= 4096 ? 512 : 1024);  // rmsnorm.cu:141-147
+    for (int row = 0; row < batch_size; ++row) {
+        const float* x = input + (size_t)row * hidden_size;
+        float* y = output + (size_t)row * hidden_size;
+        std::vector<float> part((size_t)bs, 0.0f);
+        for (int tid = 0; tid < bs; ++tid) {
+            float s = 0.0f;
+            for (int i = tid; i < hidden_size; i += bs) s = fmaf(x[i], x[i], s);
+            part[tid] = s;
+        }
+        const float sum_sq = block_sum(part);
+        const float mean_sq = sum_sq / (float)hidden_size;
+        const float rms_inv = 1.0f / sqrtf(mean_sq + eps);  // rsqrtf in the reference
+        for (int i = 0; i < hidden_size; ++i) y[i] = x[i] * rms_inv * weight[i];
+    }
+}
+
+void launch_rope(float* q, float* k, const int* positions, int /*batch_size*/, int seq_len, int n_heads,
+                 int n_kv_heads, int head_dim, float theta_base, float freq_scale, bool interleaved,
+                 void* /*stream*/) {
+    const int half_dim = head_dim / 2;
+    for (int is_key = 0; is_key < 2; ++is_key) {
+        float* data = is_key ? k : q;
+        const int n_h = is_key ? n_kv_heads : n_heads;
+        for (int sp = 0; sp < seq_len; ++sp) {
+            const int pos = positions[sp];
+            for (int h = 0; h < n_h; ++h) {
+                float* v = data + (size_t)sp * n_h * head_dim + (size_t)h * head_dim;
+                for (int p = 0; p < half_dim; ++p) {
+                    const float freq = 1.0f / powf(theta_base, (2.0f * p) / head_dim);  // rotary.cu:47
+                    const float angle = pos * freq * freq_scale;
+                    const float c = cosf(angle), s = sinf(angle);
+                    const int i0 = interleaved ? 2 * p : p;
+                    const int i1 = interleaved ? 2 * p + 1 : p + half_dim;
+                    const float x0 = v[i0], x1 = v[i1];
+                    v[i0] = fmaf(x0, c, -(x1 * s));  // x0*c - x1*s, contracted as nvcc would
+                    v[i1] = fmaf(x1, c, x0 * s);
+                }
+            }
+        }
+    }
+}
+
+void launch_copy_to_kv_cache(void* k_cache, void* v_cache, const float* k, const float* v, int seq_len,
+                             int n_kv_heads, int head_dim, int start_pos, int max_seq, void* /*stream*/) {
+    uint16_t* kc = static_cast<uint16_t*>(k_cache);
+    uint16_t* vc = static_cast<uint16_t*>(v_cache);
+    const size_t per = (size_t)n_kv_heads * head_dim;
+    for (int t = 0; t < seq_len; ++t) {
+        const int cp = start_pos + t;
+        if (cp >= max_seq) continue;  // attention.cu:336
+        for (size_t e = 0; e < per; ++e) {
+            kc[cp * per + e] = f2h(k[t * per + e]);
+            vc[cp * per + e] = f2h(v[t * per + e]);
+        }
+    }
+}
+
+void launch_attention_decode(float* output, const float* q, const void* k_cache, const void* v_cache,
+                             int seq_len, int n_heads, int n_kv_heads, int head_dim, int /*max_seq*/,
+                             float scale, void* /*stream*/) {
+    const int bs = seq_len > 1024 ? 512 : 256;  // attention.cu:365-366
+    const int group = n_heads / n_kv_heads;
+#pragma omp parallel for schedule(static)
+    for (int h = 0; h < n_heads; ++h)
+        attend_one(output + (size_t)h * head_dim, q + (size_t)h * head_dim, (const uint16_t*)k_cache,
+                   (const uint16_t*)v_cache, seq_len, h / group, n_kv_heads, head_dim, scale, bs, false);
+}
+
+void launch_attention_prefill(float* output, const float* Q, const void* k_cache, const void* v_cache,
+                              int seq_len, int start_pos, int n_heads, int n_kv_heads, int head_dim,
+                              int /*max_seq*/, float scale, void* /*stream*/) {
+    const int group = n_heads / n_kv_heads;
+#pragma omp parallel for schedule(dynamic) collapse(2)
+    for (int qi = 0; qi < seq_len; ++qi)
+        for (int h = 0; h < n_heads; ++h) {
+            const size_t off = (size_t)qi * n_heads * head_dim + (size_t)h * head_dim;
+            attend_one(output + off, Q + off, (const uint16_t*)k_cache, (const uint16_t*)v_cache,
+                       start_pos + qi + 1, h / group, n_kv_heads, head_dim, scale, 256, true);
+        }
+}
+
+void launch_add(float* out, const float* a, const float* b, int size, void*) {
+    for (int i = 0; i < size; ++i) out[i] = a[i] + b[i];
+}
+void launch_add_inplace(float* a, const float* b, int size, void*) {
+    for (int i = 0; i < size; ++i) a[i] += b[i];
+}
+void launch_copy(float* dst, const float* src, int size, void*) {
+    if (size > 0) std::memmove(dst, src, (size_t)size * 4);
+}
+void launch_add_bias(float* y, const float* bias, int size, void*) {
+    for (int i = 0; i < size; ++i) y[i] += bias[i];
+}
+
+void launch_cosine_similarity(float* result, const float* a, const float* b, int size, void*) {
+    // elementwise.cu:49-84: 256 threads, strided partials, shared-memory tree 128..1
+    float dot[256], na[256], nb[256];
+    for (int tid = 0; tid < 256; ++tid) {
+        float d = 0, x = 0, y = 0;
+        for (int i = tid; i < size; i += 256) {
+            d = fmaf(a[i], b[i], d);
+            x = fmaf(a[i], a[i], x);
+            y = fmaf(b[i], b[i], y);
+        }
+        dot[tid] = d; na[tid] = x; nb[tid] = y;
+    }
+    for (int s = 128; s > 0; s >>= 1)
+        for (int tid = 0; tid < s; ++tid) {
+            dot[tid] += dot[tid + s]; na[tid] += na[tid + s]; nb[tid] += nb[tid + s];
+        }
+    const float denom = sqrtf(na[0]) * sqrtf(nb[0]);
+    *result = (denom > 1e-8f) ? dot[0] / denom : 0.0f;
+}
+
+}  // namespace cuda
+}  // namespace nt
+
+// =====================================================================================
+// Plain-C view for ctypes (tests/, bench.py cpu_baseline).  dtype = numeric nt::DType value.
+// =====================================================================================
+extern "C" {
+
+void oracle_gemv(float* y, const void* W, const float* x, int out_f, int in_f, int dtype) {
+    nt::cuda::launch_gemv(y, W, x, out_f, in_f, (nt::DType)dtype, nullptr);
+}
+void oracle_gemv_add(float* y, const void* W, const float* x, int out_f, int in_f, int dtype) {
+    nt::cuda::launch_gemv_add(y, W, x, out_f, in_f, (nt::DType)dtype, nullptr);
+}
+void oracle_silu_mul(float* o, const float* g, const float* u, int n) { nt::cuda::launch_silu_mul(o, g, u, n, nullptr); }
+void oracle_rmsnorm(float* o, const float* in, const float* w, int batch, int hidden, float eps) {
+    nt::cuda::launch_rmsnorm(o, in, w, batch, hidden, eps, nullptr);
+}
+void oracle_rope(float* q, float* k, const int* pos, int seq_len, int nh, int nkv, int hd, float theta,
+                 float fscale, int interleaved) {
+    nt::cuda::launch_rope(q, k, pos, 1, seq_len, nh, nkv, hd, theta, fscale, interleaved != 0, nullptr);
+}
+void oracle_copy_to_kv_cache(void* kc, void* vc, const float* k, const float* v, int seq_len, int nkv, int hd,
+                             int start_pos, int max_seq) {
+    nt::cuda::launch_copy_to_kv_cache(kc, vc, k, v, seq_len, nkv, hd, start_pos, max_seq, nullptr);
+}
+void oracle_attention_decode(float* out, const float* q, const void* kc, const void* vc, int seq_len, int nh,
+                             int nkv, int hd, int max_seq, float scale) {
+    nt::cuda::launch_attention_decode(out, q, kc, vc, seq_len, nh, nkv, hd, max_seq, scale, nullptr);
+}
+void oracle_attention_prefill(float* out, const float* Q, const void* kc, const void* vc, int seq_len,
+                              int start_pos, int nh, int nkv, int hd, int max_seq, float scale) {
+    nt::cuda::launch_attention_prefill(out, Q, kc, vc, seq_len, start_pos, nh, nkv, hd, max_seq, scale, nullptr);
+}
+void oracle_add(float* o, const float* a, const float* b, int n) { nt::cuda::launch_add(o, a, b, n, nullptr); }
+void oracle_add_inplace(float* a, const float* b, int n) { nt::cuda::launch_add_inplace(a, b, n, nullptr); }
+void oracle_copy(float* d, const float* s, int n) { nt::cuda::launch_copy(d, s, n, nullptr); }
+void oracle_cosine_similarity(float* r, const float* a, const float* b, int n) {
+    nt::cuda::launch_cosine_similarity(r, a, b, n, nullptr);
+}
+float oracle_h2f(uint16_t h) { return h2f(h); }
+uint16_t oracle_f2h(float f) { return f2h(f); }
+
+// Row dequant exactly as Transformer::embed_tokens does on the host (transformer.cpp:419-599).
+// Returns 0 on success, 1 when the reference has no branch for the dtype (it zero-fills: :595-598).
+int oracle_embed_row(float* out, const void* table, int token, int hidden, int dtype) {
+    const nt::DType dt = (nt::DType)dtype;
+    const uint8_t* raw = static_cast<const uint8_t*>(table);
+    if (dt == nt::DType::F32) {
+        std::memcpy(out, (const float*)table + (size_t)token * hidden, (size_t)hidden * 4);
+    } else if (dt == nt::DType::F16) {
+        const uint16_t* r = (const uint16_t*)table + (size_t)token * hidden;
+        for (int d = 0; d < hidden; ++d) out[d] = h2f(r[d]);
+    } else if (dt == nt::DType::Q8_0) {
+        const uint8_t* row = raw + (size_t)token * (hidden / 32) * 34;
+        for (int b = 0; b < hidden / 32; ++b) {
+            const float d = h2f(rd16(row + b * 34));
+            const int8_t* qs = (const int8_t*)(row + b * 34 + 2);
+            for (int j = 0; j < 32; ++j) out[b * 32 + j] = d * qs[j];
+        }
+    } else if (dt == nt::DType::Q4_0) {
+        const uint8_t* row = raw + (size_t)token * (hidden / 32) * 18;
+        for (int b = 0; b < hidden / 32; ++b) {
+            const float d = h2f(rd16(row + b * 18));
+            const uint8_t* qs = row + b * 18 + 2;
+            for (int j = 0; j < 16; ++j) {
+                out[b * 32 + j] = d * (float)(int8_t)((qs[j] & 0x0F) - 8);
+                out[b * 32 + j + 16] = d * (float)(int8_t)((qs[j] >> 4) - 8);
+            }
+        }
+    } else if (dt == nt::DType::Q6_K) {
+        const uint8_t* row = raw + (size_t)token * (hidden / 256) * 210;
+        for (int b = 0; b < hidden / 256; ++b) {
+            const uint8_t* blk = row + b * 210;
+            const float d = h2f(rd16(blk + 208));
+            const uint8_t* ql = blk; const uint8_t* qh = blk + 128; const int8_t* sc = (const int8_t*)(blk + 192);
+            float* y = out + b * 256;
+            for (int hf = 0; hf < 2; ++hf) {
+                for (int l = 0; l < 32; ++l) {
+                    const int is = l / 16;
+                    const int q1 = (int)((ql[l] & 0xF) | (((qh[l] >> 0) & 3) << 4)) - 32;
+                    const int q2 = (int)((ql[l + 32] & 0xF) | (((qh[l] >> 2) & 3) << 4)) - 32;
+                    const int q3 = (int)((ql[l] >> 4) | (((qh[l] >> 4) & 3) << 4)) - 32;
+                    const int q4 = (int)((ql[l + 32] >> 4) | (((qh[l] >> 6) & 3) << 4)) - 32;
+                    y[l] = d * (float)sc[is + 0] * q1;
+                    y[l + 32] = d * (float)sc[is + 2] * q2;
+                    y[l + 64] = d * (float)sc[is + 4] * q3;
+                    y[l + 96] = d * (float)sc[is + 6] * q4;
+                }
+                y += 128; ql += 64; qh += 32; sc += 8;
+            }
+        }
+    } else if (dt == nt::DType::Q4_K_M) {
+        const uint8_t* row = raw + (size_t)token * (hidden / 256) * 144;
+        for (int b = 0; b < hidden / 256; ++b) {
+            const uint8_t* blk = row + b * 144;
+            const float d = h2f(rd16(blk)), dmin = h2f(rd16(blk + 2));
+            const uint8_t* q = blk + 16;
+            float* y = out + b * 256;
+            for (int c = 0; c < 4; ++c) {
+                uint8_t sl, ml, sh, mh;
+                kq_scale_min(blk + 4, 2 * c, sl, ml);
+                kq_scale_min(blk + 4, 2 * c + 1, sh, mh);
+                const float d1 = d * sl, m1 = dmin * ml, d2 = d * sh, m2 = dmin * mh;
+                for (int l = 0; l < 32; ++l) {
+                    y[c * 64 + l] = d1 * (q[l] & 0xF) - m1;
+                    y[c * 64 + l + 32] = d2 * (q[l] >> 4) - m2;
+                }
+                q += 32;
+            }
+        }
+    } else {
+        std::memset(out, 0, (size_t)hidden * 4);
+        return 1;
+    }
+    return 0;
+}
+
+int oracle_abi_version(void) { return 1; }
+
+}  // extern "C"
