@@ -1,0 +1,178 @@
+/* include/ntk.h -- C ABI of the MI355X-native operator library (libntransformer_hip.so).
+ *
+ * This is the drop-in boundary for the reference's operator surface (reference src/cuda/kernels.h:14-71,
+ * namespace nt::cuda, 17 `launch_*(..., void* stream)` launchers) and its C runtime surface
+ * (reference src/core/device.h:79-88, `nt_cuda_*`).  Every entry point takes plain pointers and sizes.
+ *
+ * Conventions (they hold for every ntk_* launcher):
+ *   - same parameter order and meaning as the reference launcher it replaces (cited per function);
+ *   - `dtype` is the numeric value of nt::DType (reference src/core/types.h:24-35) -- NTK_DT_* below;
+ *   - `W` is the RAW GGUF block layout, row-major [out][in] (reference src/core/types.h:96-137);
+ *   - KV caches are IEEE half stored as 16-bit words, passed as void* (reference kernels.h:50);
+ *   - `stream` is a hipStream_t passed as void*; NULL = the library's compute stream (ntk_stream(0));
+ *   - asynchronous, stream ordered, never allocates, frees or synchronises: safe inside hipGraph capture;
+ *   - in-place aliasing the reference relies on is supported: rmsnorm(out==in), silu_mul(out==gate),
+ *     add_inplace, gemv never aliases y with x;
+ *   - returns NTK_OK or a negative NTK_E_* code.  Where the reference only prints (unsupported dtype,
+ *     reference src/cuda/gemm.cu:801-803) the C++ wrappers in include/nt_kernels.hpp print and continue.
+ */
+#ifndef NTK_H
+#define NTK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTK_ABI_VERSION 1
+
+/* status codes */
+#define NTK_OK          0
+#define NTK_E_DTYPE    (-1)  /* dtype not supported by this operator                      */
+#define NTK_E_SHAPE    (-2)  /* size not a multiple of the quant block, negative, too big */
+#define NTK_E_LAUNCH   (-3)  /* HIP reported a launch/runtime error                        */
+#define NTK_E_ALIGN    (-4)  /* pointer alignment below what the operator needs            */
+#define NTK_E_NULL     (-5)  /* required pointer is NULL                                   */
+#define NTK_E_NODEVICE (-6)  /* no usable GPU / HIP runtime not initialised                */
+#define NTK_E_NOMEM    (-7)
+#define NTK_E_IO       (-8)
+#define NTK_E_FORMAT   (-9)  /* malformed GGUF                                             */
+
+/* nt::DType numeric values (reference src/core/types.h:24-35) */
+enum {
+    NTK_DT_F32 = 0, NTK_DT_F16 = 1, NTK_DT_Q8_0 = 2, NTK_DT_Q4_0 = 3, NTK_DT_Q4_K = 4,
+    NTK_DT_Q6_K = 5, NTK_DT_Q5_K = 6, NTK_DT_Q2_K = 7, NTK_DT_I32 = 8
+};
+
+int         ntk_abi_version(void);
+const char* ntk_status_string(int status);
+/* bytes of one row of `n` elements in `dtype` encoding, 0 if unsupported (types.h:37-88) */
+size_t      ntk_row_bytes(int dtype, int64_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * Runtime surface (replaces reference src/core/device.{h,cu}: CUDADevice + nt_cuda_*)
+ * ------------------------------------------------------------------------------------------- */
+int    ntk_device_count(void);                       /* device.cu:29-33                          */
+int    ntk_device_init(int device_id);               /* CUDADevice::init, device.cu:26-69: selects the
+                                                        device, creates 3 non-blocking streams     */
+int    ntk_device_name(char* buf, size_t n);
+int    ntk_device_mem_info(size_t* free_b, size_t* total_b);   /* free_vram/total_vram              */
+void*  ntk_stream(int which);                        /* 0 compute, 1/2 transfer (device.h:29-34)   */
+int    ntk_stream_synchronize(void* stream);         /* synchronize_stream                         */
+int    ntk_device_synchronize(void);                 /* synchronize                                */
+void*  ntk_event_create(void);                       /* create_event ... elapsed_ms                */
+int    ntk_event_destroy(void* ev);
+int    ntk_event_record(void* ev, void* stream);
+int    ntk_event_synchronize(void* ev);
+int    ntk_event_elapsed_ms(void* start, void* end, float* ms);
+
+void*  nt_hip_malloc(size_t size);                   /* nt_cuda_malloc  device.cu:154-162 (NULL on failure) */
+void   nt_hip_free(void* p);
+void   nt_hip_memcpy_h2d(void* dst, const void* src, size_t size);   /* blocking, like the reference */
+void   nt_hip_memcpy_d2h(void* dst, const void* src, size_t size);
+void   nt_hip_memcpy_d2d(void* dst, const void* src, size_t size);
+void   nt_hip_memset(void* p, int value, size_t size);
+void*  nt_hip_malloc_host(size_t size);              /* pinned */
+void   nt_hip_free_host(void* p);
+int    ntk_memcpy_h2d_async(void* dst, const void* src, size_t size, void* stream);   /* device.cu:136-144 */
+int    ntk_memcpy_d2h_async(void* dst, const void* src, size_t size, void* stream);
+/* the reference's names, kept as aliases so its host code / tests link unchanged (device.h:79-88) */
+void*  nt_cuda_malloc(size_t size);
+void   nt_cuda_free(void* p);
+void   nt_cuda_memcpy_h2d(void* dst, const void* src, size_t size);
+void   nt_cuda_memcpy_d2h(void* dst, const void* src, size_t size);
+void   nt_cuda_memcpy_d2d(void* dst, const void* src, size_t size);
+void   nt_cuda_memset(void* p, int value, size_t size);
+void*  nt_cuda_malloc_host(size_t size);
+void   nt_cuda_free_host(void* p);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operator surface: one entry point per launcher of reference src/cuda/kernels.h
+ * ------------------------------------------------------------------------------------------- */
+/* launch_rmsnorm, kernels.h:15-17 / rmsnorm.cu:129-148.  y = x * rsqrt(mean(x^2)+eps) * w, per row. */
+int ntk_rmsnorm(float* output, const float* input, const float* weight, int batch_size, int hidden_size,
+                float eps, void* stream);
+/* launch_rmsnorm_f16, kernels.h:18-20 (dead in the reference): same, IEEE half output. */
+int ntk_rmsnorm_f16(void* output, const float* input, const float* weight, int batch_size, int hidden_size,
+                    float eps, void* stream);
+/* launch_rope, kernels.h:23-26 / rotary.cu:113-140.  In place on q [T,nh,hd] and k [T,nkv,hd];
+ * positions is a DEVICE int array [T]; pairs (i, i+hd/2) unless `interleaved`. batch_size is unused. */
+int ntk_rope(float* q, float* k, const int* positions, int batch_size, int seq_len, int n_heads, int n_kv_heads,
+             int head_dim, float theta_base, float freq_scale, int interleaved, void* stream);
+/* launch_softmax / launch_masked_softmax, kernels.h:29-32 (dead in the reference). mask: 1 byte per elt, !=0 keeps */
+int ntk_softmax(float* output, const float* input, int rows, int cols, void* stream);
+int ntk_masked_softmax(float* output, const float* input, const uint8_t* mask, int rows, int cols, void* stream);
+/* launch_gemv, kernels.h:35-37 / gemm.cu:748-805.  y[out] = W[out,in] . x[in]; W raw GGUF blocks. */
+int ntk_gemv(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype,
+             void* stream);
+/* launch_gemv_add, kernels.h:40-42 / gemm.cu:846-871.  y += W . x, F16 weights only. */
+int ntk_gemv_add(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype,
+                 void* stream);
+/* launch_gemm_f32, kernels.h:43-45 / gemm.cu:807-819 (dead): C[M,N] = A[M,K] . B[N,K]^T */
+int ntk_gemm_f32(float* C, const float* A, const float* B, int M, int N, int K, void* stream);
+/* launch_silu_mul, kernels.h:46-48 / gemm.cu:821-832: out = g/(1+exp(-g)) * u */
+int ntk_silu_mul(float* output, const float* gate, const float* up, int size, void* stream);
+/* launch_add_bias, kernels.h:49 (dead) */
+int ntk_add_bias(float* y, const float* bias, int size, void* stream);
+/* launch_attention_decode, kernels.h:52-55 / attention.cu:348-375.  One query token, seq_len keys in cache. */
+int ntk_attention_decode(float* output, const float* q, const void* k_cache, const void* v_cache, int seq_len,
+                         int n_heads, int n_kv_heads, int head_dim, int max_seq, float scale, void* stream);
+/* launch_attention_prefill, kernels.h:56-60 / attention.cu:377-403.  Causal: query t sees keys 0..start_pos+t. */
+int ntk_attention_prefill(float* output, const float* Q, const void* k_cache, const void* v_cache, int seq_len,
+                          int start_pos, int n_heads, int n_kv_heads, int head_dim, int max_seq, float scale,
+                          void* stream);
+/* launch_copy_to_kv_cache, kernels.h:61-64 / attention.cu:405-425.  F32 -> F16 (RNE) scatter at start_pos. */
+int ntk_copy_to_kv_cache(void* k_cache, void* v_cache, const float* k, const float* v, int seq_len,
+                         int n_kv_heads, int head_dim, int start_pos, int max_seq, void* stream);
+/* element-wise, kernels.h:67-72 / elementwise.cu:90-115 */
+int ntk_add(float* out, const float* a, const float* b, int size, void* stream);
+int ntk_add_inplace(float* a, const float* b, int size, void* stream);
+int ntk_copy(float* dst, const float* src, int size, void* stream);
+int ntk_cosine_similarity(float* result, const float* a, const float* b, int size, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Engine-level fused operators (no reference counterpart; they compute exactly what the listed
+ * sequence of reference launchers computes, in fewer launches, with device-resident positions so a
+ * whole token can be replayed from a hipGraph).  Used by nt_engine_*; exported for tests/benchmarks.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ntk_gemv_seg {
+    const void* W;      /* raw GGUF blocks [rows][in]              */
+    float*      y;      /* output [rows]                            */
+    int         rows;
+    int         dtype;  /* all segments of one call share one dtype */
+} ntk_gemv_seg;
+
+/* y_s = W_s . f(x) for up to 3 row segments sharing x (fused Q|K|V or gate|up):
+ *   norm_w != NULL : f(x) = rmsnorm(x, norm_w, eps)           (launch_rmsnorm + launch_gemv ...)
+ *   resid  != NULL : y_0[r] = resid[r] + (W_0 . f(x))[r]      (launch_gemv + launch_add_inplace); resid may == y_0
+ *   silu_pair != 0 : nseg == 2, y_0[r] = silu(W_0.f(x))[r] * (W_1.f(x))[r]   (2 x launch_gemv + launch_silu_mul) */
+int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w,
+                   float eps, const float* resid, int silu_pair, void* stream);
+
+/* RoPE(q,k at *d_pos) + KV store + GQA decode attention over keys 0..*d_pos, one launch
+ * (launch_rope + launch_copy_to_kv_cache + launch_attention_decode; attention.cpp:165-190).
+ * q [nh*hd], k,v [nkv*hd] are the raw projections (left untouched); d_pos is a DEVICE int. */
+int ntk_attention_decode_fused(float* output, const float* q, const float* k, const float* v, void* k_cache,
+                               void* v_cache, const int* d_pos, int n_heads, int n_kv_heads, int head_dim,
+                               int max_seq, float scale, float theta_base, float freq_scale, void* stream);
+
+/* Dequantise rows of a (quantised) embedding table on the device: out[t,:] = table[tokens[t],:].
+ * Same arithmetic as the host loop in reference src/model/transformer.cpp:419-599; Q5_K is zero-filled
+ * exactly as the reference does (:595-598).  tokens is a DEVICE int array. */
+int ntk_embed_rows(float* out, const void* table, const int* tokens, int n_tokens, int hidden, int dtype,
+                   void* stream);
+
+/* Greedy sampling on the device: first index of the maximum (reference src/inference/sampler.cpp:18-28).
+ * Writes the index to *d_out_token (device) -- and to *h_mirror if it is a pinned host pointer (may be NULL).
+ * scratch: device buffer of >= 2*1024 floats. */
+int ntk_argmax(const float* logits, int n, int* d_out_token, int* h_mirror, float* scratch, void* stream);
+
+/* *d_pos += 1 (one thread); keeps positions on the device across graph replays */
+int ntk_advance_pos(int* d_pos, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTK_H */

@@ -1,0 +1,103 @@
+/* include/ntransformer.h -- public C API of the MI355X-native engine.
+ *
+ * The first block is the reference's public header (reference include/ntransformer.h:12-38), name for name
+ * and signature for signature, so an embedder of the reference re-links without source changes.  The
+ * reference DECLARES this API but never implements it (no definition exists under reference src/); the
+ * semantics below are the ones its header comments promise.  The second block are extensions.
+ * No C++ exception crosses this boundary; every function tolerates a NULL engine.
+ */
+#ifndef NTRANSFORMER_H
+#define NTRANSFORMER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nt_engine_t;                       /* opaque handle */
+
+nt_engine_t nt_engine_create(void);              /* never loads anything; NULL only on out-of-memory */
+void        nt_engine_destroy(nt_engine_t engine);
+int         nt_engine_load(nt_engine_t engine, const char* model_path);   /* 0 = ok (context capped at 4096 like the CLI default) */
+/* Returns a malloc'd NUL-terminated UTF-8 string (free with nt_free), NULL on failure.
+ * repeat_penalty / seed keep the reference's GenerateConfig defaults (1.1 / 42). */
+char*       nt_engine_generate(nt_engine_t engine, const char* prompt, int max_tokens, float temperature,
+                               int top_k, float top_p);
+void        nt_free(char* ptr);
+int         nt_engine_vocab_size(nt_engine_t engine);    /* -1 when no model is loaded */
+int         nt_engine_n_layers(nt_engine_t engine);
+int         nt_engine_hidden_size(nt_engine_t engine);
+
+/* ------------------------------------------------------------------ extensions ------------------- */
+typedef struct nt_gen_params {
+    int      max_tokens;
+    float    temperature;
+    int      top_k;
+    float    top_p;
+    float    repeat_penalty;
+    int      repeat_window;
+    uint64_t seed;
+    int      stop_at_eos;
+} nt_gen_params;
+
+typedef struct nt_stats {      /* Engine::Stats of the reference (engine.h:76-84) */
+    int   prompt_tokens;
+    int   gen_tokens;
+    float prefill_ms;
+    float decode_ms;
+    float decode_tok_s;
+} nt_stats;
+
+typedef struct nt_synth_spec { /* seeded synthetic Llama-shaped model (no checkpoint exists offline) */
+    int hidden, inter, layers, heads, kv_heads, vocab, ctx;
+    float eps, theta;
+    int bos, eos;
+    const char* mix;           /* "Q8_0" "Q4_0" "Q4_K" "Q5_K" "Q6_K" "F16" "F32" "Q4_K_M" */
+    uint64_t seed;
+} nt_synth_spec;
+
+int  nt_engine_load_ex(nt_engine_t e, const char* model_path, int max_context);
+int  nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_context);
+/* "fused" / "graph" / "device_sampling" = "0" | "1" */
+int  nt_engine_set_option(nt_engine_t e, const char* key, const char* value);
+const char* nt_engine_last_error(nt_engine_t e);
+void nt_gen_params_default(nt_gen_params* p);
+/* The generate loop on token ids; writes up to out_cap generated ids, returns their count or a negative NTK_E_* */
+int  nt_engine_generate_tokens(nt_engine_t e, const int* prompt, int n_prompt, const nt_gen_params* p, int* out, int out_cap);
+int  nt_engine_last_stats(nt_engine_t e, nt_stats* out);
+/* Transformer::forward: tokens [n] at start_pos -> logits of the last position copied to host (vocab floats) */
+int  nt_engine_forward(nt_engine_t e, const int* tokens, int n, int start_pos, float* logits_out);
+/* one fused decode step for `token` at position `pos` (device-resident state), logits copied to host */
+int  nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, float* logits_out);
+int  nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int out_cap);   /* returns count */
+int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int out_cap);       /* returns bytes */
+uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */
+uint64_t nt_engine_weight_bytes(nt_engine_t e);
+int  nt_engine_max_context(nt_engine_t e);
+/* write a synthetic GGUF v3 file with the same generator (0 = ok) */
+int  nt_synth_write_gguf(const char* path, const nt_synth_spec* spec, int nthreads);
+/* fill one tensor of the synthetic plan into host memory (for CPU baselines); returns bytes or negative */
+int64_t nt_synth_tensor(const nt_synth_spec* spec, const char* name, void* dst, size_t dst_cap, int nthreads);
+
+
+/* ------------------------------------------------------------------ host-only entry points ---------
+ * GGUF parsing, tokenisation and sampling never touch the GPU; these let tools (and the CPU test-suite)
+ * use them without a device. */
+/* JSON description of a GGUF file: config, tensor table, vocab size. Returns bytes needed (excl. NUL) or negative. */
+int   nt_gguf_describe(const char* path, char* json_out, int cap);
+typedef void* nt_tokenizer_t;
+nt_tokenizer_t nt_tokenizer_open(const char* gguf_path);       /* NULL on failure */
+void  nt_tokenizer_close(nt_tokenizer_t t);
+int   nt_tokenizer_encode(nt_tokenizer_t t, const char* text, int text_len, int add_bos, int* out, int cap);
+int   nt_tokenizer_decode(nt_tokenizer_t t, const int* ids, int n, char* out, int cap);
+int   nt_tokenizer_is_gpt2(nt_tokenizer_t t);
+/* n_draws successive Sampler::sample calls on the same logits (penalty applied once per draw over `recent`) */
+int   nt_sampler_draw(const float* logits, int n, const nt_gen_params* p, const int* recent, int n_recent,
+                      int n_draws, int* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTRANSFORMER_H */

@@ -1,0 +1,101 @@
+"""ctypes loader for the product library libntransformer_hip.so (built by ntransformer_amd/csrc/Makefile).
+
+Fails loudly: there is NO CPU fallback anywhere in this package.  If the HIP extension is missing the
+import raises; if there is no GPU every operator returns NTK_E_NODEVICE and `check()` raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntransformer_hip.so")
+
+NTK_OK = 0
+_STATUS = {0: "ok", -1: "unsupported dtype", -2: "bad shape", -3: "HIP launch/runtime error", -4: "misaligned pointer",
+           -5: "null pointer", -6: "no usable GPU", -7: "out of memory", -8: "I/O error", -9: "malformed GGUF"}
+
+
+class NtkError(RuntimeError):
+    def __init__(self, status: int, what: str = ""):
+        self.status = status
+        super().__init__("ntk status %d (%s)%s" % (status, _STATUS.get(status, "?"), (": " + what) if what else ""))
+
+
+def check(status: int, what: str = "") -> None:
+    if status != NTK_OK:
+        raise NtkError(status, what)
+
+
+class GemvSeg(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("y", C.c_void_p), ("rows", C.c_int), ("dtype", C.c_int)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    sig = {
+        "ntk_abi_version": (i, []),
+        "ntk_status_string": (C.c_char_p, [i]),
+        "ntk_row_bytes": (sz, [i, C.c_int64]),
+        "ntk_device_count": (i, []),
+        "ntk_device_init": (i, [i]),
+        "ntk_device_name": (i, [C.c_char_p, sz]),
+        "ntk_device_mem_info": (i, [C.POINTER(sz), C.POINTER(sz)]),
+        "ntk_stream": (vp, [i]),
+        "ntk_stream_synchronize": (i, [vp]),
+        "ntk_device_synchronize": (i, []),
+        "ntk_event_create": (vp, []),
+        "ntk_event_destroy": (i, [vp]),
+        "ntk_event_record": (i, [vp, vp]),
+        "ntk_event_synchronize": (i, [vp]),
+        "ntk_event_elapsed_ms": (i, [vp, vp, C.POINTER(f)]),
+        "nt_hip_malloc": (vp, [sz]), "nt_hip_free": (None, [vp]),
+        "nt_hip_memcpy_h2d": (None, [vp, vp, sz]), "nt_hip_memcpy_d2h": (None, [vp, vp, sz]),
+        "nt_hip_memcpy_d2d": (None, [vp, vp, sz]), "nt_hip_memset": (None, [vp, i, sz]),
+        "nt_hip_malloc_host": (vp, [sz]), "nt_hip_free_host": (None, [vp]),
+        "ntk_memcpy_h2d_async": (i, [vp, vp, sz, vp]), "ntk_memcpy_d2h_async": (i, [vp, vp, sz, vp]),
+        "nt_cuda_malloc": (vp, [sz]), "nt_cuda_free": (None, [vp]),
+        "nt_cuda_memcpy_h2d": (None, [vp, vp, sz]), "nt_cuda_memcpy_d2h": (None, [vp, vp, sz]),
+        "nt_cuda_memcpy_d2d": (None, [vp, vp, sz]), "nt_cuda_memset": (None, [vp, i, sz]),
+        "nt_cuda_malloc_host": (vp, [sz]), "nt_cuda_free_host": (None, [vp]),
+        "ntk_rmsnorm": (i, [vp, vp, vp, i, i, f, vp]),
+        "ntk_rmsnorm_f16": (i, [vp, vp, vp, i, i, f, vp]),
+        "ntk_rope": (i, [vp, vp, vp, i, i, i, i, i, f, f, i, vp]),
+        "ntk_softmax": (i, [vp, vp, i, i, vp]),
+        "ntk_masked_softmax": (i, [vp, vp, vp, i, i, vp]),
+        "ntk_gemv": (i, [vp, vp, vp, i, i, i, vp]),
+        "ntk_gemv_add": (i, [vp, vp, vp, i, i, i, vp]),
+        "ntk_gemm_f32": (i, [vp, vp, vp, i, i, i, vp]),
+        "ntk_silu_mul": (i, [vp, vp, vp, i, vp]),
+        "ntk_add_bias": (i, [vp, vp, i, vp]),
+        "ntk_attention_decode": (i, [vp, vp, vp, vp, i, i, i, i, i, f, vp]),
+        "ntk_attention_prefill": (i, [vp, vp, vp, vp, i, i, i, i, i, i, f, vp]),
+        "ntk_copy_to_kv_cache": (i, [vp, vp, vp, vp, i, i, i, i, i, vp]),
+        "ntk_add": (i, [vp, vp, vp, i, vp]),
+        "ntk_add_inplace": (i, [vp, vp, i, vp]),
+        "ntk_copy": (i, [vp, vp, i, vp]),
+        "ntk_cosine_similarity": (i, [vp, vp, vp, i, vp]),
+        "ntk_gemv_fused": (i, [C.POINTER(GemvSeg), i, vp, i, vp, f, vp, i, vp]),
+        "ntk_attention_decode_fused": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, f, vp]),
+        "ntk_embed_rows": (i, [vp, vp, vp, i, i, i, vp]),
+        "ntk_argmax": (i, [vp, i, vp, vp, vp, vp]),
+        "ntk_advance_pos": (i, [vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)          # AttributeError here = the .so does not export what include/ntk.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS_NTK_H = None  # filled by tests from include/ntk.h

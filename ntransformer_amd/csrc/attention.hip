@@ -1,0 +1,323 @@
+// attention.hip -- RoPE, KV store and GQA KV-cache attention for gfx950 (wave64).
+//
+// Replaces: launch_rope (reference src/cuda/rotary.cu:16-140), launch_copy_to_kv_cache, launch_attention_decode,
+// launch_attention_prefill (reference src/cuda/attention.cu:108-425).  Same data contract: q/k/v and the
+// output are F32, the caches are IEEE half [max_seq][n_kv_heads][head_dim] per layer, math is F32, softmax
+// subtracts the row maximum, GQA maps head h to kv head h / (n_heads / n_kv_heads).
+//
+// What is different from the reference kernels: K and V rows are read 16 bytes per lane (8 halves), head_dim/8
+// lanes share one cache row so a wave covers 64/(head_dim/8) positions per instruction; the score dot products
+// reduce with wave shuffles instead of a serial per-thread loop; the P.V product is split over positions
+// across all waves (the reference walks the positions serially with one thread per output dim).  The
+// engine's decode path additionally fuses RoPE + KV store into the attention launch and takes the position
+// from device memory so the launch can be replayed from a hipGraph.
+#include "common.hip.h"
+#include <cfloat>
+
+namespace ntk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void unpack8(const u32x4 r, float (&f)[8]) {
+    f[0] = h2f((uint16_t)(r.x & 0xFFFF)); f[1] = h2f((uint16_t)(r.x >> 16));
+    f[2] = h2f((uint16_t)(r.y & 0xFFFF)); f[3] = h2f((uint16_t)(r.y >> 16));
+    f[4] = h2f((uint16_t)(r.z & 0xFFFF)); f[5] = h2f((uint16_t)(r.z >> 16));
+    f[6] = h2f((uint16_t)(r.w & 0xFFFF)); f[7] = h2f((uint16_t)(r.w >> 16));
+}
+
+// rotation of one (x0, x1) pair, reference rotary.cu:46-60
+__device__ __forceinline__ void rope_pair(float& x0, float& x1, int pos, int pair_idx, int head_dim, float theta, float fscale) {
+    const float freq = 1.0f / powf(theta, (2.0f * pair_idx) / head_dim);
+    const float angle = pos * freq * fscale;
+    const float c = cosf(angle), s = sinf(angle);
+    const float a = x0, b = x1;
+    x0 = a * c - b * s;
+    x1 = b * c + a * s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Core: softmax(q . K^T * scale) . V for ONE (head, query) pair, executed by one workgroup.
+//   qs      : LDS, post-RoPE query [hd]
+//   n_cache : keys/values 0..n_cache-1 are read from the cache
+//   extra   : optional one more (key, value) pair held in LDS as floats (the token being decoded)
+//   sc      : LDS scores [n_cache + 1]; part: LDS [nwaves][hd]; red: LDS [16]
+// LPR = lanes per cache row (head_dim / 8); 0 selects the generic any-head_dim path.
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ void attend(float* out, const float* qs, const uint16_t* kc, const uint16_t* vc, int n_cache,
+                       const float* k_extra, const float* v_extra, int kv_head, int n_kv_heads, int hd,
+                       float scale, float* sc, float* part, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const size_t stride = (size_t)n_kv_heads * hd;
+    const uint16_t* kbase = kc + (size_t)kv_head * hd;
+    const uint16_t* vbase = vc + (size_t)kv_head * hd;
+    const int n_keys = n_cache + (k_extra ? 1 : 0);
+
+    // ---- phase 1: scores ------------------------------------------------------------------------
+    if constexpr (LPR > 0) {
+        constexpr int PPW = 64 / LPR;               // positions per wave instruction
+        const int sub = lane / LPR, part_i = lane % LPR;
+        float qreg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
+        for (int p0 = wave * PPW; p0 < n_cache; p0 += nwaves * PPW) {
+            const int pos = p0 + sub;
+            float s = 0.0f;
+            if (pos < n_cache) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(kbase + pos * stride + 8 * part_i);
+                float kf[8];
+                unpack8(raw, kf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = fmaf(qreg[j], kf[j], s);
+            }
+#pragma unroll
+            for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            if (part_i == 0 && pos < n_cache) sc[pos] = s * scale;
+        }
+    } else {
+        for (int pos = tid; pos < n_cache; pos += blockDim.x) {
+            const uint16_t* k = kbase + pos * stride;
+            float s = 0.0f;
+            for (int d = 0; d < hd; ++d) s = fmaf(qs[d], h2f(k[d]), s);
+            sc[pos] = s * scale;
+        }
+    }
+    if (k_extra && wave == 0) {
+        float s = 0.0f;
+        for (int d = lane; d < hd; d += 64) s = fmaf(qs[d], k_extra[d], s);
+        s = wave_sum(s);
+        if (lane == 0) sc[n_cache] = s * scale;
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax over sc[0..n_keys) -----------------------------------------------------
+    float m = -FLT_MAX;
+    for (int pos = tid; pos < n_keys; pos += blockDim.x) m = fmaxf(m, sc[pos]);
+    m = block_max(m, red);
+    float l = 0.0f;
+    for (int pos = tid; pos < n_keys; pos += blockDim.x) {
+        const float e = expf(sc[pos] - m);
+        sc[pos] = e;
+        l += e;
+    }
+    l = block_sum(l, red);
+    const float inv = (l > 0.0f) ? 1.0f / l : 0.0f;   // reference attention.cu:293 (prefill guard); decode never hits 0
+    __syncthreads();
+
+    // ---- phase 3: out[d] = inv * sum_pos e[pos] V[pos][d] ------------------------------------------
+    if constexpr (LPR > 0) {
+        constexpr int PPW = 64 / LPR;
+        const int sub = lane / LPR, part_i = lane % LPR;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int p0 = wave * PPW; p0 < n_cache; p0 += nwaves * PPW) {
+            const int pos = p0 + sub;
+            if (pos < n_cache) {
+                const float pw = sc[pos];
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(vbase + pos * stride + 8 * part_i);
+                float vf[8];
+                unpack8(raw, vf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, vf[j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[wave * hd + 8 * part_i + j] = acc[j];
+        }
+        __syncthreads();
+        for (int d = tid; d < hd; d += blockDim.x) {
+            float t = 0.0f;
+            for (int w = 0; w < nwaves; ++w) t += part[w * hd + d];
+            if (v_extra) t = fmaf(sc[n_cache], v_extra[d], t);
+            out[d] = t * inv;
+        }
+    } else {
+        for (int d = tid; d < hd; d += blockDim.x) {
+            float t = 0.0f;
+            for (int pos = 0; pos < n_cache; ++pos) t = fmaf(sc[pos], h2f(vbase[pos * stride + d]), t);
+            if (v_extra) t = fmaf(sc[n_cache], v_extra[d], t);
+            out[d] = t * inv;
+        }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void attention_kernel(float* __restrict__ output, const float* __restrict__ Q,
+                                                        const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+                                                        int n_keys_base, int causal, int n_heads, int n_kv_heads, int hd,
+                                                        float scale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int head = blockIdx.x, qi = blockIdx.y;
+    const int n_keys = causal ? n_keys_base + qi + 1 : n_keys_base;   // prefill: keys 0..start_pos+qi
+    float* qs = lds;                        // [hd]
+    float* red = qs + hd;                   // [16]
+    float* part = red + 16;                 // [nwaves][hd]
+    float* sc = part + (blockDim.x >> 6) * hd;
+    const size_t qoff = ((size_t)qi * n_heads + head) * hd;
+    for (int d = threadIdx.x; d < hd; d += blockDim.x) qs[d] = Q[qoff + d];
+    __syncthreads();
+    attend<LPR>(output + qoff, qs, kc, vc, n_keys, nullptr, nullptr, head / (n_heads / n_kv_heads), n_kv_heads, hd,
+                scale, sc, part, red);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void attention_decode_fused_kernel(
+    float* __restrict__ output, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, int n_heads, int n_kv_heads,
+    int hd, int max_seq, float scale, float theta, float fscale) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int head = blockIdx.x;
+    const int group = n_heads / n_kv_heads, kv_head = head / group;
+    const int pos = *d_pos;
+    float* qs = lds;                        // [hd] post-RoPE query
+    float* kx = qs + hd;                    // [hd] post-RoPE key of this token, rounded through half
+    float* vx = kx + hd;                    // [hd] value of this token, rounded through half
+    float* red = vx + hd;
+    float* part = red + 16;
+    float* sc = part + (blockDim.x >> 6) * hd;
+    const int half_dim = hd / 2;
+    const size_t cache_row = ((size_t)pos * n_kv_heads + kv_head) * hd;
+    const bool writer = (head % group == 0) && pos < max_seq;   // one workgroup per kv head stores the row
+    for (int i = threadIdx.x; i < half_dim; i += blockDim.x) {
+        float a = q[(size_t)head * hd + i], b = q[(size_t)head * hd + i + half_dim];
+        rope_pair(a, b, pos, i, hd, theta, fscale);
+        qs[i] = a; qs[i + half_dim] = b;
+        float ka = k[(size_t)kv_head * hd + i], kb = k[(size_t)kv_head * hd + i + half_dim];
+        rope_pair(ka, kb, pos, i, hd, theta, fscale);
+        const uint16_t ha = f2h(ka), hb = f2h(kb);          // reference attention.cu:338 (__float2half, RNE)
+        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
+        if (writer) { kc[cache_row + i] = ha; kc[cache_row + i + half_dim] = hb; }
+    }
+    for (int i = threadIdx.x; i < hd; i += blockDim.x) {
+        const uint16_t hv = f2h(v[(size_t)kv_head * hd + i]);
+        vx[i] = h2f(hv);
+        if (writer) vc[cache_row + i] = hv;
+    }
+    __syncthreads();
+    attend<LPR>(output + (size_t)head * hd, qs, kc, vc, pos, kx, vx, kv_head, n_kv_heads, hd, scale, sc, part, red);
+}
+
+__global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, const int* __restrict__ positions, int seq_len,
+                            int n_heads, int n_kv_heads, int head_dim, float theta, float fscale, int interleaved) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half_dim = head_dim / 2;
+    const int total_q = seq_len * n_heads * half_dim, total_k = seq_len * n_kv_heads * half_dim;
+    if (idx >= total_q + total_k) return;
+    const bool is_key = idx >= total_q;
+    const int local = is_key ? idx - total_q : idx;
+    const int n_h = is_key ? n_kv_heads : n_heads;
+    const int pair = local % half_dim, head = (local / half_dim) % n_h, sp = local / (half_dim * n_h);
+    float* data = (is_key ? k : q) + ((size_t)sp * n_h + head) * head_dim;
+    const int i0 = interleaved ? 2 * pair : pair, i1 = interleaved ? 2 * pair + 1 : pair + half_dim;
+    float a = data[i0], b = data[i1];
+    rope_pair(a, b, positions[sp], pair, head_dim, theta, fscale);
+    data[i0] = a;
+    data[i1] = b;
+}
+
+__global__ void kv_store_kernel(uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const float* __restrict__ k,
+                                const float* __restrict__ v, int total, int per_pos, int start_pos, int max_seq) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int t = idx / per_pos, e = idx % per_pos;
+    const int cp = start_pos + t;
+    if (cp >= max_seq) return;   // reference attention.cu:336
+    kc[(size_t)cp * per_pos + e] = f2h(k[idx]);
+    vc[(size_t)cp * per_pos + e] = f2h(v[idx]);
+}
+
+static size_t attn_lds(int hd, int n_keys, int nvec) {
+    return sizeof(float) * ((size_t)nvec * hd + 16 + 4 * (size_t)hd + (size_t)n_keys + 1);
+}
+
+static int launch_attention(float* out, const float* Q, const void* kc, const void* vc, int T, int n_keys_base, int causal,
+                            int nh, int nkv, int hd, float scale, hipStream_t st) {
+    if (nh <= 0 || nkv <= 0 || hd <= 0 || nh % nkv != 0 || T < 0) return NTK_E_SHAPE;
+    if (T == 0) return NTK_OK;
+    const int max_keys = causal ? n_keys_base + T : n_keys_base;
+    const size_t lds = attn_lds(hd, max_keys, 1);
+    if (lds > 160 * 1024) return NTK_E_SHAPE;
+    const bool aligned = (reinterpret_cast<uintptr_t>(kc) & 15) == 0 && (reinterpret_cast<uintptr_t>(vc) & 15) == 0;
+    const uint16_t* k16 = static_cast<const uint16_t*>(kc);
+    const uint16_t* v16 = static_cast<const uint16_t*>(vc);
+    dim3 grid(nh, T), block(256);
+#define NTK_ATT(LPR_) hipLaunchKernelGGL(attention_kernel<LPR_>, grid, block, lds, st, out, Q, k16, v16, n_keys_base, causal, nh, nkv, hd, scale)
+    if (aligned && hd == 128) NTK_ATT(16);
+    else if (aligned && hd == 64) NTK_ATT(8);
+    else if (aligned && hd == 256) NTK_ATT(32);
+    else NTK_ATT(0);
+#undef NTK_ATT
+    return last_launch_status();
+}
+
+}  // namespace ntk
+
+extern "C" {
+
+int ntk_rope(float* q, float* k, const int* positions, int /*batch_size*/, int seq_len, int n_heads, int n_kv_heads,
+             int head_dim, float theta_base, float freq_scale, int interleaved, void* stream) {
+    if (!q || !k || !positions) return NTK_E_NULL;
+    if (seq_len < 0 || n_heads < 0 || n_kv_heads < 0 || head_dim <= 0 || (head_dim & 1)) return NTK_E_SHAPE;
+    const int total = seq_len * (n_heads + n_kv_heads) * (head_dim / 2);
+    if (total == 0) return NTK_OK;
+    hipLaunchKernelGGL(ntk::rope_kernel, dim3((total + 255) / 256), dim3(256), 0, ntk::resolve_stream(stream), q, k,
+                       positions, seq_len, n_heads, n_kv_heads, head_dim, theta_base, freq_scale, interleaved);
+    return ntk::last_launch_status();
+}
+
+int ntk_copy_to_kv_cache(void* k_cache, void* v_cache, const float* k, const float* v, int seq_len, int n_kv_heads,
+                         int head_dim, int start_pos, int max_seq, void* stream) {
+    if (!k_cache || !v_cache || !k || !v) return NTK_E_NULL;
+    if (seq_len < 0 || n_kv_heads <= 0 || head_dim <= 0 || start_pos < 0) return NTK_E_SHAPE;
+    const int per = n_kv_heads * head_dim, total = seq_len * per;
+    if (total == 0) return NTK_OK;
+    hipLaunchKernelGGL(ntk::kv_store_kernel, dim3((total + 255) / 256), dim3(256), 0, ntk::resolve_stream(stream),
+                       static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), k, v, total, per, start_pos, max_seq);
+    return ntk::last_launch_status();
+}
+
+int ntk_attention_decode(float* output, const float* q, const void* k_cache, const void* v_cache, int seq_len, int n_heads,
+                         int n_kv_heads, int head_dim, int /*max_seq*/, float scale, void* stream) {
+    if (!output || !q || !k_cache || !v_cache) return NTK_E_NULL;
+    if (seq_len <= 0) return NTK_E_SHAPE;
+    return ntk::launch_attention(output, q, k_cache, v_cache, 1, seq_len, 0, n_heads, n_kv_heads, head_dim, scale,
+                                 ntk::resolve_stream(stream));
+}
+
+int ntk_attention_prefill(float* output, const float* Q, const void* k_cache, const void* v_cache, int seq_len, int start_pos,
+                          int n_heads, int n_kv_heads, int head_dim, int /*max_seq*/, float scale, void* stream) {
+    if (!output || !Q || !k_cache || !v_cache) return NTK_E_NULL;
+    if (seq_len < 0 || start_pos < 0) return NTK_E_SHAPE;
+    return ntk::launch_attention(output, Q, k_cache, v_cache, seq_len, start_pos, 1, n_heads, n_kv_heads, head_dim, scale,
+                                 ntk::resolve_stream(stream));
+}
+
+int ntk_attention_decode_fused(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
+                               const int* d_pos, int n_heads, int n_kv_heads, int head_dim, int max_seq, float scale,
+                               float theta_base, float freq_scale, void* stream) {
+    if (!output || !q || !k || !v || !k_cache || !v_cache || !d_pos) return NTK_E_NULL;
+    if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || head_dim <= 0 || (head_dim & 1) || max_seq <= 0)
+        return NTK_E_SHAPE;
+    const size_t lds = ntk::attn_lds(head_dim, max_seq, 3);
+    if (lds > 160 * 1024) return NTK_E_SHAPE;
+    hipStream_t st = ntk::resolve_stream(stream);
+    const bool aligned = (reinterpret_cast<uintptr_t>(k_cache) & 15) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 15) == 0;
+    uint16_t* k16 = static_cast<uint16_t*>(k_cache);
+    uint16_t* v16 = static_cast<uint16_t*>(v_cache);
+#define NTK_ATTF(LPR_) hipLaunchKernelGGL(ntk::attention_decode_fused_kernel<LPR_>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, k16, v16, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
+    if (aligned && head_dim == 128) NTK_ATTF(16);
+    else if (aligned && head_dim == 64) NTK_ATTF(8);
+    else if (aligned && head_dim == 256) NTK_ATTF(32);
+    else NTK_ATTF(0);
+#undef NTK_ATTF
+    return ntk::last_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// elementwise.hip -- RMSNorm, softmax, SwiGLU, residual/element-wise ops, embedding gather, greedy argmax.
+//
+// Replaces: launch_rmsnorm / launch_rmsnorm_f16 (reference src/cuda/rmsnorm.cu:16-170), launch_softmax /
+// launch_masked_softmax (reference src/cuda/softmax.cu:17-205), launch_silu_mul / launch_add_bias /
+// launch_gemm_f32 (reference src/cuda/gemm.cu:677-725,807-844), launch_add / launch_add_inplace / launch_copy /
+// launch_cosine_similarity (reference src/cuda/elementwise.cu:11-115).  ntk_embed_rows moves the host loop of
+// reference src/model/transformer.cpp:419-599 onto the device; ntk_argmax is reference
+// src/inference/sampler.cpp:18-28 on the device.  All are latency-level kernels (<= a few hundred KB).
+#include "common.hip.h"
+#include <cfloat>
+
+namespace ntk {
+
+template <bool HALF_OUT>
+__global__ __launch_bounds__(1024) void rmsnorm_kernel(void* __restrict__ output, const float* __restrict__ input,
+                                                       const float* __restrict__ weight, int hidden, float eps) {
+    __shared__ float red[16];
+    const float* x = input + (size_t)blockIdx.x * hidden;
+    float ssq = 0.0f;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) ssq = fmaf(x[i], x[i], ssq);
+    const float tot = block_sum(ssq, red);
+    const float rms_inv = 1.0f / sqrtf(tot / (float)hidden + eps);   // rsqrtf(mean_sq + eps), rmsnorm.cu:60-61
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+        const float v = x[i] * rms_inv * weight[i];                  // rmsnorm.cu:68 (output may alias input)
+        if constexpr (HALF_OUT) reinterpret_cast<uint16_t*>(output)[(size_t)blockIdx.x * hidden + i] = f2h(v);
+        else reinterpret_cast<float*>(output)[(size_t)blockIdx.x * hidden + i] = v;
+    }
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(1024) void softmax_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                       const uint8_t* __restrict__ mask, int cols) {
+    __shared__ float red[16];
+    const float* x = in + (size_t)blockIdx.x * cols;
+    const uint8_t* mk = MASKED ? mask + (size_t)blockIdx.x * cols : nullptr;
+    float* y = out + (size_t)blockIdx.x * cols;
+    float m = -FLT_MAX;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x)
+        if (!MASKED || mk[i]) m = fmaxf(m, x[i]);
+    m = block_max(m, red);
+    float l = 0.0f;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x)
+        if (!MASKED || mk[i]) l += expf(x[i] - m);
+    l = block_sum(l, red);
+    const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+    for (int i = threadIdx.x; i < cols; i += blockDim.x) y[i] = (!MASKED || mk[i]) ? expf(x[i] - m) * inv : 0.0f;
+}
+
+__global__ void silu_mul_kernel(float* __restrict__ out, const float* __restrict__ gate, const float* __restrict__ up, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float g = gate[i];
+        out[i] = g / (1.0f + expf(-g)) * up[i];   // gemm.cu:719-724
+    }
+}
+__global__ void add_kernel(float* __restrict__ o, const float* __restrict__ a, const float* __restrict__ b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+__global__ void copy_kernel(float* __restrict__ d, const float* __restrict__ s, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = s[i];
+}
+__global__ void gemm_f32_kernel(float* __restrict__ C, const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y * blockDim.y + threadIdx.y;
+    if (row >= M || col >= N) return;
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s = fmaf(A[(size_t)row * K + k], B[(size_t)col * K + k], s);   // gemm.cu:689-693
+    C[(size_t)row * N + col] = s;
+}
+__global__ __launch_bounds__(256) void cosine_kernel(float* __restrict__ result, const float* __restrict__ a,
+                                                     const float* __restrict__ b, int n) {
+    __shared__ float red[16];
+    float d = 0.0f, na = 0.0f, nb = 0.0f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        d = fmaf(a[i], b[i], d); na = fmaf(a[i], a[i], na); nb = fmaf(b[i], b[i], nb);
+    }
+    d = block_sum(d, red); na = block_sum(na, red); nb = block_sum(nb, red);
+    if (threadIdx.x == 0) {
+        const float den = sqrtf(na) * sqrtf(nb);
+        *result = den > 1e-8f ? d / den : 0.0f;   // elementwise.cu:80-83
+    }
+}
+
+// ---- embedding rows: element e of row `tok`, bit-for-bit the host arithmetic of transformer.cpp:419-599
+//      (__fmul_rn / __fsub_rn keep the device compiler from fusing what the host code does not fuse) ----
+__device__ float embed_elem(const uint8_t* __restrict__ table, int tok, int hidden, int dt, int e) {
+    switch (dt) {
+        case NTK_DT_F32: return reinterpret_cast<const float*>(table)[(size_t)tok * hidden + e];
+        case NTK_DT_F16: return h2f(reinterpret_cast<const uint16_t*>(table)[(size_t)tok * hidden + e]);
+        case NTK_DT_Q8_0: {
+            const uint8_t* b = table + ((size_t)tok * (hidden / 32) + e / 32) * 34;
+            const float d = h2f((uint16_t)(b[0] | (b[1] << 8)));
+            return __fmul_rn(d, (float)(int8_t)b[2 + (e & 31)]);
+        }
+        case NTK_DT_Q4_0: {
+            const uint8_t* b = table + ((size_t)tok * (hidden / 32) + e / 32) * 18;
+            const float d = h2f((uint16_t)(b[0] | (b[1] << 8)));
+            const int j = e & 31;
+            const int nib = j < 16 ? (b[2 + j] & 0x0F) : (b[2 + j - 16] >> 4);
+            return __fmul_rn(d, (float)(nib - 8));
+        }
+        case NTK_DT_Q4_K: {
+            const uint8_t* b = table + ((size_t)tok * (hidden / 256) + e / 256) * 144;
+            const float d = h2f((uint16_t)(b[0] | (b[1] << 8))), dmin = h2f((uint16_t)(b[2] | (b[3] << 8)));
+            const int w = e & 255, sub = w >> 5, l = w & 31, chunk = sub >> 1;
+            const uint8_t* s = b + 4;
+            uint32_t sc, mn;
+            if (sub < 4) { sc = s[sub] & 63; mn = s[sub + 4] & 63; }
+            else { sc = (s[sub + 4] & 0x0F) | ((s[sub - 4] >> 6) << 4); mn = (s[sub + 4] >> 4) | ((s[sub] >> 6) << 4); }
+            const uint8_t qb = b[16 + 32 * chunk + l];
+            const int nib = (sub & 1) ? (qb >> 4) : (qb & 0x0F);
+            return __fsub_rn(__fmul_rn(__fmul_rn(d, (float)sc), (float)nib), __fmul_rn(dmin, (float)mn));
+        }
+        case NTK_DT_Q6_K: {
+            const uint8_t* b = table + ((size_t)tok * (hidden / 256) + e / 256) * 210;
+            const float d = h2f((uint16_t)(b[208] | (b[209] << 8)));
+            const int w = e & 255, hf = w >> 7, g = (w >> 5) & 3, l = w & 31, is = l >> 4;
+            const uint8_t* ql = b + 64 * hf;
+            const uint8_t* qh = b + 128 + 32 * hf;
+            const int8_t sc = (int8_t)b[192 + 8 * hf + is + 2 * g];
+            const uint8_t qlb = ql[l + 32 * (g & 1)];
+            const int lo = (g >> 1) ? (qlb >> 4) : (qlb & 0x0F);
+            const int q = (lo | (((qh[l] >> (2 * g)) & 3) << 4)) - 32;
+            return __fmul_rn(__fmul_rn(d, (float)sc), (float)q);
+        }
+        default: return 0.0f;   // Q5_K and anything else: the reference zero-fills (transformer.cpp:595-598)
+    }
+}
+__global__ void embed_rows_kernel(float* __restrict__ out, const uint8_t* __restrict__ table, const int* __restrict__ tokens,
+                                  int hidden, int dt) {
+    const int tok = tokens[blockIdx.x];
+    for (int e = threadIdx.x; e < hidden; e += blockDim.x) out[(size_t)blockIdx.x * hidden + e] = embed_elem(table, tok, hidden, dt, e);
+}
+
+// ---- greedy argmax, first maximum wins (sampler.cpp:18-28: strict '>' scanning upwards) ----------------
+__device__ __forceinline__ void amax_merge(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__global__ __launch_bounds__(256) void argmax_stage1(const float* __restrict__ x, int n, float* __restrict__ sv, int* __restrict__ si) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    float v = -FLT_MAX;
+    int idx = 0x7FFFFFFF;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) amax_merge(v, idx, x[i], i);
+    for (int off = 32; off > 0; off >>= 1) amax_merge(v, idx, __shfl_xor(v, off, 64), __shfl_xor(idx, off, 64));
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = v; ri[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax_merge(v, idx, rv[w], ri[w]);
+        sv[blockIdx.x] = v; si[blockIdx.x] = idx;
+    }
+}
+__global__ __launch_bounds__(256) void argmax_stage2(const float* __restrict__ sv, const int* __restrict__ si, int nblk,
+                                                     int* __restrict__ d_out, int* __restrict__ h_mirror) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    float v = -FLT_MAX;
+    int idx = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) amax_merge(v, idx, sv[i], si[i]);
+    for (int off = 32; off > 0; off >>= 1) amax_merge(v, idx, __shfl_xor(v, off, 64), __shfl_xor(idx, off, 64));
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = v; ri[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax_merge(v, idx, rv[w], ri[w]);
+        if (idx == 0x7FFFFFFF) idx = 0;   // all NaN / empty: the reference returns 0
+        *d_out = idx;
+        if (h_mirror) *h_mirror = idx;
+    }
+}
+__global__ void advance_pos_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
+
+static inline dim3 g1(int n) { return dim3((n + 255) / 256); }
+
+}  // namespace ntk
+
+extern "C" {
+using namespace ntk;
+
+static int rms_block(int hidden) { return hidden <= 1024 ? 256 : (hidden <= 4096 ? 512 : 1024); }   // rmsnorm.cu:141-147
+
+int ntk_rmsnorm(float* output, const float* input, const float* weight, int batch_size, int hidden_size, float eps, void* stream) {
+    if (!output || !input || !weight) return NTK_E_NULL;
+    if (batch_size < 0 || hidden_size <= 0) return NTK_E_SHAPE;
+    if (batch_size == 0) return NTK_OK;
+    hipLaunchKernelGGL(rmsnorm_kernel<false>, dim3(batch_size), dim3(rms_block(hidden_size)), 0, resolve_stream(stream),
+                       (void*)output, input, weight, hidden_size, eps);
+    return last_launch_status();
+}
+int ntk_rmsnorm_f16(void* output, const float* input, const float* weight, int batch_size, int hidden_size, float eps, void* stream) {
+    if (!output || !input || !weight) return NTK_E_NULL;
+    if (batch_size < 0 || hidden_size <= 0) return NTK_E_SHAPE;
+    if (batch_size == 0) return NTK_OK;
+    hipLaunchKernelGGL(rmsnorm_kernel<true>, dim3(batch_size), dim3(rms_block(hidden_size)), 0, resolve_stream(stream),
+                       output, input, weight, hidden_size, eps);
+    return last_launch_status();
+}
+int ntk_softmax(float* output, const float* input, int rows, int cols, void* stream) {
+    if (!output || !input) return NTK_E_NULL;
+    if (rows < 0 || cols <= 0) return NTK_E_SHAPE;
+    if (rows == 0) return NTK_OK;
+    hipLaunchKernelGGL(softmax_kernel<false>, dim3(rows), dim3(cols <= 1024 ? 256 : 1024), 0, resolve_stream(stream), output,
+                       input, (const uint8_t*)nullptr, cols);
+    return last_launch_status();
+}
+int ntk_masked_softmax(float* output, const float* input, const uint8_t* mask, int rows, int cols, void* stream) {
+    if (!output || !input || !mask) return NTK_E_NULL;
+    if (rows < 0 || cols <= 0) return NTK_E_SHAPE;
+    if (rows == 0) return NTK_OK;
+    hipLaunchKernelGGL(softmax_kernel<true>, dim3(rows), dim3(cols <= 1024 ? 256 : 1024), 0, resolve_stream(stream), output,
+                       input, mask, cols);
+    return last_launch_status();
+}
+int ntk_gemm_f32(float* C, const float* A, const float* B, int M, int N, int K, void* stream) {
+    if (!C || !A || !B) return NTK_E_NULL;
+    if (M < 0 || N < 0 || K < 0) return NTK_E_SHAPE;
+    if (M == 0 || N == 0) return NTK_OK;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(16, 16), 0, resolve_stream(stream), C, A, B, M, N, K);
+    return last_launch_status();
+}
+int ntk_silu_mul(float* output, const float* gate, const float* up, int size, void* stream) {
+    if (!output || !gate || !up) return NTK_E_NULL;
+    if (size < 0) return NTK_E_SHAPE;
+    if (size == 0) return NTK_OK;
+    hipLaunchKernelGGL(silu_mul_kernel, g1(size), dim3(256), 0, resolve_stream(stream), output, gate, up, size);
+    return last_launch_status();
+}
+int ntk_add(float* out, const float* a, const float* b, int size, void* stream) {
+    if (!out || !a || !b) return NTK_E_NULL;
+    if (size < 0) return NTK_E_SHAPE;
+    if (size == 0) return NTK_OK;
+    hipLaunchKernelGGL(add_kernel, g1(size), dim3(256), 0, resolve_stream(stream), out, a, b, size);
+    return last_launch_status();
+}
+int ntk_add_inplace(float* a, const float* b, int size, void* stream) { return ntk_add(a, a, b, size, stream); }
+int ntk_add_bias(float* y, const float* bias, int size, void* stream) { return ntk_add(y, y, bias, size, stream); }
+int ntk_copy(float* dst, const float* src, int size, void* stream) {
+    if (!dst || !src) return NTK_E_NULL;
+    if (size < 0) return NTK_E_SHAPE;
+    if (size == 0) return NTK_OK;
+    hipLaunchKernelGGL(copy_kernel, g1(size), dim3(256), 0, resolve_stream(stream), dst, src, size);
+    return last_launch_status();
+}
+int ntk_cosine_similarity(float* result, const float* a, const float* b, int size, void* stream) {
+    if (!result || !a || !b) return NTK_E_NULL;
+    if (size < 0) return NTK_E_SHAPE;
+    hipLaunchKernelGGL(cosine_kernel, dim3(1), dim3(256), 0, resolve_stream(stream), result, a, b, size);
+    return last_launch_status();
+}
+int ntk_embed_rows(float* out, const void* table, const int* tokens, int n_tokens, int hidden, int dtype, void* stream) {
+    if (!out || !table || !tokens) return NTK_E_NULL;
+    if (n_tokens < 0 || hidden <= 0) return NTK_E_SHAPE;
+    if (n_tokens == 0) return NTK_OK;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(n_tokens), dim3(256), 0, resolve_stream(stream), out, (const uint8_t*)table,
+                       tokens, hidden, dtype);
+    const int st = last_launch_status();
+    if (st != NTK_OK) return st;
+    switch (dtype) {   // rows were zero-filled for anything the reference host path has no branch for
+        case NTK_DT_F32: case NTK_DT_F16: case NTK_DT_Q8_0: case NTK_DT_Q4_0: case NTK_DT_Q4_K: case NTK_DT_Q6_K: return NTK_OK;
+        default: return NTK_E_DTYPE;
+    }
+}
+int ntk_argmax(const float* logits, int n, int* d_out_token, int* h_mirror, float* scratch, void* stream) {
+    if (!logits || !d_out_token || !scratch) return NTK_E_NULL;
+    if (n <= 0) return NTK_E_SHAPE;
+    const int nblk = n < 256 * 8 ? 1 : (n / (256 * 8) < 1024 ? n / (256 * 8) : 1024);
+    float* sv = scratch;
+    int* si = reinterpret_cast<int*>(scratch + 1024);
+    hipStream_t st = resolve_stream(stream);
+    hipLaunchKernelGGL(argmax_stage1, dim3(nblk), dim3(256), 0, st, logits, n, sv, si);
+    hipLaunchKernelGGL(argmax_stage2, dim3(1), dim3(256), 0, st, (const float*)sv, (const int*)si, nblk, d_out_token, h_mirror);
+    return last_launch_status();
+}
+int ntk_advance_pos(int* d_pos, void* stream) {
+    if (!d_pos) return NTK_E_NULL;
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, resolve_stream(stream), d_pos);
+    return last_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// engine/capi.cpp -- C API (include/ntransformer.h).  The reference declares nt_engine_* in its public header
+// but ships no implementation (reference include/ntransformer.h:15-38, SURVEY.md finding 5).
+#include "../../../include/ntransformer.h"
+#include "../../../include/ntk.h"
+#include "engine.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <thread>
+
+using nt::Engine;
+
+namespace {
+Engine* E(nt_engine_t e) { return static_cast<Engine*>(e); }
+nt::SynthSpec to_spec(const nt_synth_spec& s) {
+    nt::SynthSpec o;
+    o.hidden = s.hidden; o.inter = s.inter; o.layers = s.layers; o.heads = s.heads; o.kv_heads = s.kv_heads;
+    o.vocab = s.vocab; o.ctx = s.ctx; o.eps = s.eps; o.theta = s.theta; o.bos = s.bos; o.eos = s.eos;
+    o.mix = s.mix ? s.mix : "Q8_0";
+    o.seed = s.seed;
+    return o;
+}
+int threads_or_default(int n) {
+    if (n > 0) return n;
+    const int h = (int)std::thread::hardware_concurrency();
+    return h > 0 ? h : 8;
+}
+}  // namespace
+
+extern "C" {
+
+nt_engine_t nt_engine_create(void) { return new (std::nothrow) Engine(); }
+void nt_engine_destroy(nt_engine_t e) { delete E(e); }
+
+int nt_engine_load(nt_engine_t e, const char* path) { return nt_engine_load_ex(e, path, 4096); }
+
+int nt_engine_load_ex(nt_engine_t e, const char* path, int max_context) {
+    if (!e || !path) return NTK_E_NULL;
+    try { return E(e)->load(path, max_context > 0 ? max_context : 4096); } catch (...) { return NTK_E_NOMEM; }
+}
+
+int nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_context) {
+    if (!e || !spec) return NTK_E_NULL;
+    try { return E(e)->load_synthetic(to_spec(*spec), max_context > 0 ? max_context : 4096); } catch (...) { return NTK_E_NOMEM; }
+}
+
+int nt_engine_set_option(nt_engine_t e, const char* key, const char* value) {
+    if (!e || !key || !value) return NTK_E_NULL;
+    const bool on = atoi(value) != 0;
+    const std::string k = key;
+    if (k == "fused") E(e)->options().fused = on;
+    else if (k == "graph") E(e)->options().graph = on;
+    else if (k == "device_sampling") E(e)->options().device_sampling = on;
+    else if (k == "synth_threads") E(e)->options().synth_threads = atoi(value);
+    else return NTK_E_SHAPE;
+    return NTK_OK;
+}
+
+const char* nt_engine_last_error(nt_engine_t e) { return e ? E(e)->error().c_str() : "null engine"; }
+
+void nt_gen_params_default(nt_gen_params* p) {
+    if (!p) return;
+    const nt::GenerateConfig d;
+    p->max_tokens = d.max_tokens; p->temperature = d.temperature; p->top_k = d.top_k; p->top_p = d.top_p;
+    p->repeat_penalty = d.repeat_penalty; p->repeat_window = d.repeat_window; p->seed = d.seed; p->stop_at_eos = 1;
+}
+
+char* nt_engine_generate(nt_engine_t e, const char* prompt, int max_tokens, float temperature, int top_k, float top_p) {
+    if (!e || !prompt || !E(e)->loaded()) return nullptr;
+    try {
+        nt::GenerateConfig c;
+        c.max_tokens = max_tokens; c.temperature = temperature; c.top_k = top_k; c.top_p = top_p;
+        c.verbose = false;
+        const std::string out = E(e)->generate(prompt, c);
+        char* r = static_cast<char*>(malloc(out.size() + 1));
+        if (!r) return nullptr;
+        memcpy(r, out.c_str(), out.size() + 1);
+        return r;
+    } catch (...) { return nullptr; }
+}
+void nt_free(char* p) { free(p); }
+
+int nt_engine_vocab_size(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().config().vocab_size : -1; }
+int nt_engine_n_layers(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().config().n_layers : -1; }
+int nt_engine_hidden_size(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().config().hidden_size : -1; }
+int nt_engine_max_context(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().config().max_seq_len : -1; }
+
+int nt_engine_generate_tokens(nt_engine_t e, const int* prompt, int n_prompt, const nt_gen_params* p, int* out, int out_cap) {
+    if (!e || !prompt || !p || (!out && out_cap > 0)) return NTK_E_NULL;
+    if (n_prompt <= 0) return NTK_E_SHAPE;
+    try {
+        nt::GenerateConfig c;
+        c.max_tokens = p->max_tokens; c.temperature = p->temperature; c.top_k = p->top_k; c.top_p = p->top_p;
+        c.repeat_penalty = p->repeat_penalty; c.repeat_window = p->repeat_window; c.seed = p->seed;
+        std::vector<int> gen;
+        const int rc = E(e)->generate_tokens(std::vector<int>(prompt, prompt + n_prompt), c, gen, p->stop_at_eos != 0);
+        if (rc != NTK_OK) return rc;
+        const int n = (int)std::min<size_t>(gen.size(), (size_t)out_cap);
+        for (int i = 0; i < n; ++i) out[i] = gen[i];
+        return n;
+    } catch (...) { return NTK_E_NOMEM; }
+}
+
+int nt_engine_last_stats(nt_engine_t e, nt_stats* o) {
+    if (!e || !o) return NTK_E_NULL;
+    const nt::Stats& s = E(e)->last_stats();
+    o->prompt_tokens = s.prompt_tokens; o->gen_tokens = s.gen_tokens; o->prefill_ms = s.prefill_ms;
+    o->decode_ms = s.decode_ms; o->decode_tok_s = s.decode_tok_s();
+    return NTK_OK;
+}
+
+int nt_engine_forward(nt_engine_t e, const int* tokens, int n, int start_pos, float* logits_out) {
+    if (!e || !tokens || !logits_out) return NTK_E_NULL;
+    if (!E(e)->loaded()) return NTK_E_NULL;
+    float* d = E(e)->model().forward(tokens, n, start_pos);
+    if (!d) return NTK_E_LAUNCH;
+    return E(e)->model().copy_logits(logits_out);
+}
+
+int nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, float* logits_out) {
+    if (!e || !logits_out || !E(e)->loaded()) return NTK_E_NULL;
+    nt::Model& m = E(e)->model();
+    if (pos < 0 || pos >= m.config().max_seq_len) return NTK_E_SHAPE;
+    m.set_device_pos(pos);
+    int rc = m.set_device_token(token);
+    if (rc != NTK_OK) return rc;
+    rc = m.decode_step_fused(false, use_graph != 0);
+    if (rc != NTK_OK) return rc;
+    return m.copy_logits(logits_out);
+}
+
+int nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int cap) {
+    if (!e || !text || !E(e)->loaded()) return NTK_E_NULL;
+    const std::vector<int> ids = E(e)->tokenizer().encode(text, add_bos != 0);
+    for (int i = 0; i < (int)ids.size() && i < cap; ++i) out[i] = ids[i];
+    return (int)ids.size();
+}
+
+int nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int cap) {
+    if (!e || !ids || !E(e)->loaded()) return NTK_E_NULL;
+    const std::string s = E(e)->tokenizer().decode(std::vector<int>(ids, ids + n));
+    if (out && cap > 0) {
+        const size_t k = std::min<size_t>(s.size(), (size_t)cap - 1);
+        memcpy(out, s.data(), k);
+        out[k] = 0;
+    }
+    return (int)s.size();
+}
+
+uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos) { return e && E(e)->loaded() ? E(e)->model().bytes_per_token(pos) : 0; }
+uint64_t nt_engine_weight_bytes(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().weight_bytes() : 0; }
+
+int nt_synth_write_gguf(const char* path, const nt_synth_spec* spec, int nthreads) {
+    if (!path || !spec) return NTK_E_NULL;
+    try { return nt::synth_write_gguf(path, to_spec(*spec), threads_or_default(nthreads)); } catch (...) { return NTK_E_NOMEM; }
+}
+
+int64_t nt_synth_tensor(const nt_synth_spec* spec, const char* name, void* dst, size_t cap, int nthreads) {
+    if (!spec || !name) return NTK_E_NULL;
+    std::vector<nt::SynthTensor> plan;
+    const nt::SynthSpec s = to_spec(*spec);
+    if (!nt::synth_plan(s, plan)) return NTK_E_SHAPE;
+    for (const auto& t : plan) {
+        if (t.name != name) continue;
+        if (!dst) return (int64_t)t.nbytes;
+        if (cap < t.nbytes) return NTK_E_SHAPE;
+        nt::synth_fill(dst, t, s.seed, threads_or_default(nthreads));
+        return (int64_t)t.nbytes;
+    }
+    return NTK_E_FORMAT;
+}
+
+// ---- host-only entry points --------------------------------------------------------------------------
+static void json_escape(std::string& o, const std::string& s) {
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { o.push_back('\\'); o.push_back((char)c); }
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+        else o.push_back((char)c);
+    }
+}
+
+int nt_gguf_describe(const char* path, char* out, int cap) {
+    if (!path) return NTK_E_NULL;
+    try {
+        nt::GgufFile f;
+        const int st = f.open(path);
+        if (st != NTK_OK) return st;
+        const nt::ModelConfig& c = f.config();
+        std::string j = "{";
+        char b[512];
+        snprintf(b, sizeof b,
+                 "\"version\":%u,\"data_offset\":%zu,\"vocab_size\":%d,\"hidden_size\":%d,\"intermediate_size\":%d,"
+                 "\"n_layers\":%d,\"n_heads\":%d,\"n_kv_heads\":%d,\"head_dim\":%d,\"max_seq_len\":%d,\"norm_eps\":%.9g,"
+                 "\"rope_theta\":%.9g,\"bos\":%d,\"eos\":%d,\"n_vocab_tokens\":%zu,\"n_scores\":%zu,\"n_token_types\":%zu,",
+                 f.version(), f.data_offset(), c.vocab_size, c.hidden_size, c.intermediate_size, c.n_layers, c.n_heads,
+                 c.n_kv_heads, c.head_dim, c.max_seq_len, (double)c.norm_eps, (double)c.rope_theta, c.bos_token_id,
+                 c.eos_token_id, f.vocab().tokens.size(), f.vocab().scores.size(), f.vocab().token_types.size());
+        j += b;
+        j += "\"architecture\":\""; json_escape(j, c.architecture); j += "\",\"name\":\""; json_escape(j, c.model_name);
+        j += "\",\"tensors\":[";
+        bool first = true;
+        for (const auto& t : f.tensors()) {
+            if (!first) j += ",";
+            first = false;
+            j += "{\"name\":\""; json_escape(j, t.name); j += "\",\"dims\":[";
+            for (size_t d = 0; d < t.dims.size(); ++d) { if (d) j += ","; j += std::to_string(t.dims[d]); }
+            snprintf(b, sizeof b, "],\"ggml_type\":%u,\"dtype\":%d,\"offset\":%llu,\"nbytes\":%zu}", t.ggml_type, t.dtype,
+                     (unsigned long long)t.offset, t.nbytes);
+            j += b;
+        }
+        j += "]}";
+        if (out && cap > 0) {
+            const size_t k = std::min<size_t>(j.size(), (size_t)cap - 1);
+            memcpy(out, j.data(), k);
+            out[k] = 0;
+        }
+        return (int)j.size();
+    } catch (...) { return NTK_E_NOMEM; }
+}
+
+nt_tokenizer_t nt_tokenizer_open(const char* path) {
+    if (!path) return nullptr;
+    try {
+        nt::GgufFile f;
+        if (f.open(path) != NTK_OK) return nullptr;
+        auto* t = new nt::Tokenizer();
+        t->init(f.vocab(), f.config().bos_token_id, f.config().eos_token_id);
+        return t;
+    } catch (...) { return nullptr; }
+}
+void nt_tokenizer_close(nt_tokenizer_t t) { delete static_cast<nt::Tokenizer*>(t); }
+int nt_tokenizer_encode(nt_tokenizer_t t, const char* text, int len, int add_bos, int* out, int cap) {
+    if (!t || !text) return NTK_E_NULL;
+    const std::vector<int> ids = static_cast<nt::Tokenizer*>(t)->encode(std::string(text, len < 0 ? strlen(text) : (size_t)len), add_bos != 0);
+    for (int i = 0; i < (int)ids.size() && i < cap; ++i) out[i] = ids[i];
+    return (int)ids.size();
+}
+int nt_tokenizer_decode(nt_tokenizer_t t, const int* ids, int n, char* out, int cap) {
+    if (!t || !ids) return NTK_E_NULL;
+    const std::string s = static_cast<nt::Tokenizer*>(t)->decode(std::vector<int>(ids, ids + n));
+    if (out && cap > 0) {
+        const size_t k = std::min<size_t>(s.size(), (size_t)cap - 1);
+        memcpy(out, s.data(), k);
+        out[k] = 0;
+    }
+    return (int)s.size();
+}
+int nt_tokenizer_is_gpt2(nt_tokenizer_t t) { return t && static_cast<nt::Tokenizer*>(t)->gpt2_mode() ? 1 : 0; }
+
+int nt_sampler_draw(const float* logits, int n, const nt_gen_params* p, const int* recent, int n_recent, int n_draws, int* out) {
+    if (!logits || !p || !out || n <= 0) return NTK_E_NULL;
+    nt::Sampler s;
+    nt::SamplerConfig c;
+    c.temperature = p->temperature; c.top_k = p->top_k; c.top_p = p->top_p; c.repeat_penalty = p->repeat_penalty;
+    c.repeat_window = p->repeat_window; c.seed = p->seed;
+    s.init(c);
+    std::vector<int> rec(recent ? recent : nullptr, recent ? recent + n_recent : nullptr);
+    std::vector<float> l(n);
+    for (int d = 0; d < n_draws; ++d) {
+        std::copy(logits, logits + n, l.begin());
+        s.apply_repeat_penalty(l.data(), n, rec);
+        out[d] = s.sample(l.data(), n);
+        rec.push_back(out[d]);
+    }
+    return n_draws;
+}
+
+}  // extern "C"

@@ -1,0 +1,165 @@
+// engine/engine.cpp -- see engine.h
+#include "engine.h"
+#include "../../../include/ntk.h"
+
+#include <chrono>
+#include <cstdio>
+#include <iostream>
+#include <thread>
+
+namespace nt {
+
+using Clock = std::chrono::high_resolution_clock;
+static float ms_since(Clock::time_point t0) { return std::chrono::duration<float, std::milli>(Clock::now() - t0).count(); }
+
+int Engine::load(const std::string& path, int max_context) {
+    loaded_ = false;
+    const int st = model_.load(path, max_context);
+    if (st != NTK_OK) { err_ = model_.error(); return st; }
+    tok_.init(model_.vocab(), model_.config().bos_token_id, model_.config().eos_token_id);   // engine.cpp:21
+    loaded_ = true;
+    return NTK_OK;
+}
+
+int Engine::load_synthetic(const SynthSpec& spec, int max_context) {
+    loaded_ = false;
+    int nt = opt_.synth_threads > 0 ? opt_.synth_threads : (int)std::thread::hardware_concurrency();
+    const int st = model_.load_synthetic(spec, max_context, nt > 0 ? nt : 8);
+    if (st != NTK_OK) { err_ = model_.error(); return st; }
+    tok_.init(model_.vocab(), model_.config().bos_token_id, model_.config().eos_token_id);
+    loaded_ = true;
+    return NTK_OK;
+}
+
+// One generation, reference engine.cpp:40-145 step for step:
+//   prefill (timed) -> logits -> repeat penalty -> sample first token -> decode loop (timed as a whole;
+//   gen_tokens counts loop iterations, so the first sampled token is not counted) -> stop at EOS.
+// `tokens` holds the prompt on entry and prompt + generated ids on return.
+int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string* text, TokenCallback cb, bool print, bool stop_at_eos) {
+    stats_ = Stats();
+    if (!loaded_) { err_ = "model not loaded"; return NTK_E_NULL; }
+    if (tokens.empty()) { err_ = "empty prompt"; return NTK_E_SHAPE; }
+    Sampler sampler;
+    SamplerConfig sc;
+    sc.temperature = cfg.temperature; sc.top_k = cfg.top_k; sc.top_p = cfg.top_p;
+    sc.repeat_penalty = cfg.repeat_penalty; sc.repeat_window = cfg.repeat_window; sc.seed = cfg.seed;
+    sampler.init(sc);
+    const int V = model_.config().vocab_size;
+    const int eos = tok_.eos_id();
+    const bool dev_greedy = opt_.fused && opt_.device_sampling && sampler.is_pure_greedy();
+    stats_.prompt_tokens = (int)tokens.size();
+    if (cfg.verbose) fprintf(stderr, "Prompt tokens: %d\n", stats_.prompt_tokens);
+
+    auto t0 = Clock::now();
+    float* logits = model_.forward(tokens.data(), (int)tokens.size(), 0);
+    stats_.prefill_ms = ms_since(t0);
+    if (!logits) { err_ = model_.error(); return NTK_E_LAUNCH; }
+
+    std::vector<float> host(V);
+    if (model_.copy_logits(host.data()) != NTK_OK) return NTK_E_LAUNCH;
+    sampler.apply_repeat_penalty(host.data(), V, tokens);
+    int next = sampler.sample(host.data(), V);
+    tokens.push_back(next);
+    auto emit = [&](int id) -> bool {
+        const std::string piece = tok_.decode_token(id);
+        if (text) *text += piece;
+        if (cb) return cb(piece, id);
+        if (print) { fputs(piece.c_str(), stdout); fflush(stdout); }
+        return true;
+    };
+    if (!emit(next)) return NTK_OK;
+
+    int pos = stats_.prompt_tokens;
+    const int max_pos = model_.config().max_seq_len;
+    int rc = NTK_OK;
+    auto d0 = Clock::now();
+    if (opt_.fused) {
+        model_.set_device_pos(pos);
+        model_.set_device_token(next);
+    }
+    for (int i = 1; i < cfg.max_tokens; ++i) {
+        if (stop_at_eos && next == eos) break;              // engine.cpp:106
+        if (pos >= max_pos) { fprintf(stderr, "\n[context of %d tokens exhausted]\n", max_pos); break; }
+        if (opt_.fused) {
+            rc = model_.decode_step_fused(dev_greedy, opt_.graph);
+            if (rc != NTK_OK) break;
+            if (dev_greedy) {
+                if ((rc = model_.sync()) != NTK_OK) break;
+                next = model_.host_token();                 // first max, same as Sampler::argmax
+            } else {
+                if ((rc = model_.copy_logits(host.data())) != NTK_OK) break;
+                sampler.apply_repeat_penalty(host.data(), V, tokens);
+                next = sampler.sample(host.data(), V);
+                model_.set_device_token(next);
+            }
+        } else {
+            logits = model_.forward(&next, 1, pos);          // engine.cpp:109
+            if (!logits) { rc = NTK_E_LAUNCH; break; }
+            if ((rc = model_.copy_logits(host.data())) != NTK_OK) break;
+            sampler.apply_repeat_penalty(host.data(), V, tokens);
+            next = sampler.sample(host.data(), V);
+        }
+        ++pos;
+        tokens.push_back(next);
+        ++stats_.gen_tokens;
+        if (!emit(next)) break;
+    }
+    stats_.decode_ms = ms_since(d0);
+    if (rc != NTK_OK) err_ = std::string("decode failed: ") + ntk_status_string(rc);
+    return rc;
+}
+
+std::string Engine::generate(const std::string& prompt, const GenerateConfig& cfg, TokenCallback cb) {
+    std::vector<int> tokens = tok_.encode(prompt, true);
+    std::string out;
+    run(tokens, cfg, &out, cb, cfg.verbose, true);
+    if (cfg.verbose) { fprintf(stdout, "\n"); print_stats(stats_); }
+    return out;
+}
+
+int Engine::generate_tokens(const std::vector<int>& prompt, const GenerateConfig& cfg, std::vector<int>& out, bool stop_at_eos) {
+    std::vector<int> tokens = prompt;
+    GenerateConfig c = cfg;
+    c.verbose = false;
+    const int rc = run(tokens, c, nullptr, nullptr, false, stop_at_eos);
+    out.assign(tokens.begin() + (long)prompt.size(), tokens.end());
+    return rc;
+}
+
+void Engine::chat(const GenerateConfig& cfg) {   // engine.cpp:545-570: stateless turns
+    fprintf(stdout, "NTransformer Chat (type 'quit' to exit)\nModel: %s (%d params)\n---\n", model_.config().model_name.c_str(),
+            model_.config().n_layers);
+    std::string line;
+    for (;;) {
+        fprintf(stdout, "> ");
+        fflush(stdout);
+        if (!std::getline(std::cin, line)) break;
+        if (line == "quit" || line == "exit") break;
+        if (line.empty()) continue;
+        generate(line, cfg);
+        fprintf(stdout, "\n");
+    }
+}
+
+void Engine::benchmark(const std::string& prompt, int n_tokens) {   // engine.cpp:572-593
+    GenerateConfig c;
+    c.max_tokens = n_tokens;
+    c.temperature = 0.0f;
+    c.verbose = false;
+    fprintf(stderr, "=== Benchmark ===\nPrompt: \"%s\"\nMax tokens: %d\n", prompt.c_str(), n_tokens);
+    auto t0 = Clock::now();
+    const std::string out = generate(prompt, c);
+    fprintf(stderr, "Total time: %.1f ms\nOutput length: %zu chars\n", ms_since(t0), out.size());
+    print_stats(stats_);   // the reference prints nothing here because verbose is false; the numbers are the point of a benchmark
+}
+
+void Engine::print_stats(const Stats& st) const {   // engine.cpp:595-607
+    fprintf(stderr, "\n--- Stats ---\n");
+    fprintf(stderr, "Prompt: %d tokens, %.1f ms (%.1f tok/s)\n", st.prompt_tokens, st.prefill_ms, st.prefill_tok_s());
+    fprintf(stderr, "Decode: %d tokens, %.1f ms (%.1f tok/s)\n", st.gen_tokens, st.decode_ms, st.decode_tok_s());
+    size_t fr = 0, tot = 0;
+    ntk_device_mem_info(&fr, &tot);
+    fprintf(stderr, "VRAM: %.1f / %.1f GB\n", (tot - fr) / 1073741824.0, tot / 1073741824.0);
+}
+
+}  // namespace nt

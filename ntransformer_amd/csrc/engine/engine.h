@@ -1,0 +1,72 @@
+// engine/engine.h -- text generation loop and its statistics.
+// Replaces reference src/inference/engine.{h,cpp}: Engine::load / generate / chat / benchmark / print_stats.
+// The speculative and self-speculative variants (engine.cpp:150-540) depend on the tiered streaming mode
+// and are out of scope.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+#include "model.h"
+#include "sampler.h"
+#include "tokenizer.h"
+
+namespace nt {
+
+struct GenerateConfig {   // reference engine.h:17-26, same defaults
+    int max_tokens = 256;
+    float temperature = 0.7f;
+    int top_k = 40;
+    float top_p = 0.9f;
+    float repeat_penalty = 1.1f;
+    int repeat_window = 64;
+    uint64_t seed = 42;
+    bool verbose = true;
+};
+
+struct Stats {            // reference engine.h:76-84
+    int prompt_tokens = 0;
+    int gen_tokens = 0;
+    float prefill_ms = 0;
+    float decode_ms = 0;
+    float prefill_tok_s() const { return prefill_ms > 0 ? prompt_tokens / (prefill_ms / 1000.0f) : 0.0f; }
+    float decode_tok_s() const { return decode_ms > 0 ? gen_tokens / (decode_ms / 1000.0f) : 0.0f; }
+};
+
+using TokenCallback = std::function<bool(const std::string& piece, int token_id)>;
+
+struct EngineOptions {
+    bool fused = true;            // fused 5-launch/layer decode path (false: the reference's 15-launch sequence)
+    bool graph = true;            // replay the fused token from a hipGraph
+    bool device_sampling = true;  // greedy argmax on the device when temperature <= 0 and repeat_penalty <= 1
+    int synth_threads = 0;        // 0 = hardware concurrency
+};
+
+class Engine {
+public:
+    int load(const std::string& path, int max_context = 4096);
+    int load_synthetic(const SynthSpec& spec, int max_context = 4096);
+    std::string generate(const std::string& prompt, const GenerateConfig& cfg, TokenCallback cb = nullptr);
+    // the generate loop on token ids (no tokenizer, no printing): used by bench.py and the parity tests
+    int generate_tokens(const std::vector<int>& prompt, const GenerateConfig& cfg, std::vector<int>& out, bool stop_at_eos);
+    void chat(const GenerateConfig& cfg);
+    void benchmark(const std::string& prompt, int n_tokens);
+    void print_stats(const Stats& st) const;
+
+    Model& model() { return model_; }
+    const Tokenizer& tokenizer() const { return tok_; }
+    const Stats& last_stats() const { return stats_; }
+    EngineOptions& options() { return opt_; }
+    const std::string& error() const { return err_; }
+    bool loaded() const { return loaded_; }
+
+private:
+    int run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string* text, TokenCallback cb, bool print, bool stop_at_eos);
+    Model model_;
+    Tokenizer tok_;
+    Stats stats_;
+    EngineOptions opt_;
+    std::string err_;
+    bool loaded_ = false;
+};
+
+}  // namespace nt

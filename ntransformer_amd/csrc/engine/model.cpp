@@ -1,0 +1,402 @@
+// engine/model.cpp -- see model.h
+#include "model.h"
+#include "../../../include/ntk.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace nt {
+
+#define NT_TRY(expr)                       \
+    do {                                   \
+        const int st__ = (expr);           \
+        if (st__ != NTK_OK) return st__;   \
+    } while (0)
+
+static bool is_quant(int dt) {
+    return dt == NTK_DT_Q8_0 || dt == NTK_DT_Q4_0 || dt == NTK_DT_Q4_K || dt == NTK_DT_Q5_K || dt == NTK_DT_Q6_K;
+}
+
+Model::~Model() { free_all(); }
+
+void Model::free_all() {
+    if (graph_greedy_) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_greedy_));
+    if (graph_logits_) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_logits_));
+    graph_greedy_ = graph_logits_ = nullptr;
+    for (void* p : allocs_) nt_hip_free(p);
+    allocs_.clear();
+    if (h_token_) nt_hip_free_host(h_token_);
+    h_token_ = nullptr;
+    layers_.clear();
+}
+
+int Model::upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int64_t out_f, size_t nbytes) {
+    void* d = nt_hip_malloc((nbytes + 255) / 256 * 256 + 256);   // tail padding: kernels may read the last 16-byte chunk whole
+    if (!d) { err_ = "out of device memory"; return NTK_E_NOMEM; }
+    allocs_.push_back(d);
+    if (host) nt_hip_memcpy_h2d(d, host, nbytes);
+    dst.ptr = d; dst.dtype = dtype; dst.in_f = in_f; dst.out_f = out_f; dst.nbytes = nbytes;
+    weight_bytes_ += nbytes;
+    return NTK_OK;
+}
+
+int Model::load(const std::string& path, int max_context) {
+    free_all();
+    fprintf(stderr, "Loading model: %s\n", path.c_str());
+    GgufFile f;
+    int st = f.open(path);
+    if (st != NTK_OK) { err_ = f.error(); fprintf(stderr, "%s\n", err_.c_str()); return st; }
+    cfg_ = f.config();
+    vocab_ = f.vocab();
+    if (cfg_.max_seq_len > max_context) {   // transformer.cpp:70-74
+        fprintf(stderr, "Note: Capping context from %d to %d tokens (use --ctx-size to change)\n", cfg_.max_seq_len, max_context);
+        cfg_.max_seq_len = max_context;
+    }
+    cfg_.print();
+    f.print_info();
+    int dev = 0;
+    if (const char* e = getenv("NTK_DEVICE")) dev = atoi(e);
+    st = ntk_device_init(dev);
+    if (st != NTK_OK) { err_ = "no usable GPU (HIP device init failed)"; fprintf(stderr, "%s\n", err_.c_str()); return st; }
+
+    const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim;
+    const int64_t qd = (int64_t)cfg_.n_heads * hd, kvd = (int64_t)cfg_.n_kv_heads * hd;
+    auto take = [&](const std::string& name, DevTensor& dst, int64_t in_f, int64_t out_f, bool vec) -> int {
+        const GgufTensor* t = f.find(name);
+        if (!t) { err_ = "Tensor not found: " + name; return NTK_E_FORMAT; }
+        if (t->numel() != in_f * out_f || (!vec && (t->dims.size() != 2 || t->dims[0] != in_f))) {
+            err_ = "Unexpected shape for " + name;
+            return NTK_E_SHAPE;
+        }
+        if (vec && t->dtype != NTK_DT_F32) { err_ = name + " must be F32"; return NTK_E_DTYPE; }
+        if (t->nbytes == 0) { err_ = "Unsupported tensor type for " + name; return NTK_E_DTYPE; }
+        return upload(dst, f.data(*t), t->dtype, in_f, out_f, t->nbytes);
+    };
+    NT_TRY(take("token_embd.weight", token_embd_, H, cfg_.vocab_size, false));
+    if (f.find("output.weight")) {   // transformer.cpp:92-99
+        NT_TRY(take("output.weight", output_, H, cfg_.vocab_size, false));
+    } else {
+        output_ = token_embd_;
+        output_tied_ = true;
+    }
+    NT_TRY(take("output_norm.weight", output_norm_, H, 1, true));
+    layers_.resize(cfg_.n_layers);
+    for (int i = 0; i < cfg_.n_layers; ++i) {   // transformer.cpp:286-328
+        const std::string p = "blk." + std::to_string(i) + ".";
+        LayerWeights& L = layers_[i];
+        NT_TRY(take(p + "attn_norm.weight", L.attn_norm, H, 1, true));
+        NT_TRY(take(p + "attn_q.weight", L.wq, H, qd, false));
+        NT_TRY(take(p + "attn_k.weight", L.wk, H, kvd, false));
+        NT_TRY(take(p + "attn_v.weight", L.wv, H, kvd, false));
+        NT_TRY(take(p + "attn_output.weight", L.wo, qd, H, false));
+        NT_TRY(take(p + "ffn_norm.weight", L.ffn_norm, H, 1, true));
+        NT_TRY(take(p + "ffn_gate.weight", L.w_gate, H, I, false));
+        NT_TRY(take(p + "ffn_up.weight", L.w_up, H, I, false));
+        NT_TRY(take(p + "ffn_down.weight", L.w_down, I, H, false));
+    }
+    return finish_load(max_context);
+}
+
+int Model::load_synthetic(const SynthSpec& spec, int max_context, int nthreads) {
+    free_all();
+    std::vector<SynthTensor> plan;
+    if (!synth_plan(spec, plan)) { err_ = "bad synthetic spec"; return NTK_E_SHAPE; }
+    cfg_ = ModelConfig();
+    cfg_.model_name = "synthetic-" + spec.mix;
+    cfg_.vocab_size = spec.vocab; cfg_.hidden_size = spec.hidden; cfg_.intermediate_size = spec.inter;
+    cfg_.n_layers = spec.layers; cfg_.n_heads = spec.heads; cfg_.n_kv_heads = spec.kv_heads;
+    cfg_.head_dim = spec.hidden / spec.heads;
+    cfg_.norm_eps = spec.eps; cfg_.rope_theta = spec.theta;
+    cfg_.max_seq_len = std::min(spec.ctx, max_context);
+    cfg_.bos_token_id = spec.bos; cfg_.eos_token_id = spec.eos;
+    synth_vocab(spec, vocab_.tokens, vocab_.token_types);
+    int dev = 0;
+    if (const char* e = getenv("NTK_DEVICE")) dev = atoi(e);
+    const int st = ntk_device_init(dev);
+    if (st != NTK_OK) { err_ = "no usable GPU (HIP device init failed)"; return st; }
+
+    size_t biggest = 0;
+    for (const auto& t : plan) biggest = std::max(biggest, t.nbytes);
+    void* stage = nt_hip_malloc_host(biggest);
+    if (!stage) { err_ = "pinned staging allocation failed"; return NTK_E_NOMEM; }
+    layers_.resize(cfg_.n_layers);
+    int rc = NTK_OK;
+    for (const auto& t : plan) {
+        synth_fill(stage, t, spec.seed, nthreads);
+        DevTensor* dst = nullptr;
+        if (t.name == "token_embd.weight") dst = &token_embd_;
+        else if (t.name == "output.weight") dst = &output_;
+        else if (t.name == "output_norm.weight") dst = &output_norm_;
+        else {
+            int li = 0;
+            char what[64] = {0};
+            if (sscanf(t.name.c_str(), "blk.%d.%63s", &li, what) != 2) { rc = NTK_E_FORMAT; break; }
+            LayerWeights& L = layers_[li];
+            const std::string w = what;
+            dst = w == "attn_norm.weight" ? &L.attn_norm : w == "attn_q.weight" ? &L.wq : w == "attn_k.weight" ? &L.wk
+                : w == "attn_v.weight" ? &L.wv : w == "attn_output.weight" ? &L.wo : w == "ffn_norm.weight" ? &L.ffn_norm
+                : w == "ffn_gate.weight" ? &L.w_gate : w == "ffn_up.weight" ? &L.w_up : &L.w_down;
+        }
+        rc = upload(*dst, stage, ggml_type_to_dtype((uint32_t)t.ggml_type), t.in_f, t.out_f, t.nbytes);
+        if (rc != NTK_OK) break;
+    }
+    nt_hip_free_host(stage);
+    if (rc != NTK_OK) return rc;
+    return finish_load(max_context);
+}
+
+int Model::finish_load(int /*max_context*/) {
+    stream_ = ntk_stream(0);
+    if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
+    NT_TRY(alloc_buffers());
+    size_t fr = 0, tot = 0;
+    ntk_device_mem_info(&fr, &tot);
+    fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights)\nFree VRAM: %.1f GB\n",
+            weight_bytes_ / 1073741824.0, fr / 1073741824.0);
+    return NTK_OK;
+}
+
+int Model::alloc_buffers() {   // transformer.cpp:330-391
+    const size_t S = (size_t)cfg_.max_seq_len, H = (size_t)cfg_.hidden_size, L = (size_t)cfg_.n_layers;
+    const size_t per = (size_t)cfg_.n_kv_heads * cfg_.head_dim;
+    auto dev = [&](size_t bytes, bool zero) -> void* {
+        void* p = nt_hip_malloc(bytes + 256);
+        if (p) { allocs_.push_back(p); if (zero) nt_hip_memset(p, 0, bytes); }
+        return p;
+    };
+    const size_t kvb = L * S * per * sizeof(uint16_t);
+    k_cache_ = (uint16_t*)dev(kvb, true);
+    v_cache_ = (uint16_t*)dev(kvb, true);
+    hidden_ = (float*)dev(std::max<size_t>(S, 2) * H * 4, false);
+    residual_ = (float*)dev(std::max<size_t>(S, 2) * H * 4, false);
+    logits_ = (float*)dev((size_t)cfg_.vocab_size * 4, false);
+    const size_t attn_ws = S * (size_t)(2 * cfg_.n_heads + 2 * cfg_.n_kv_heads) * cfg_.head_dim;
+    const size_t ffn_ws = 2 * S * (size_t)cfg_.intermediate_size;
+    workspace_floats_ = std::max(attn_ws, ffn_ws);
+    workspace_ = (float*)dev(workspace_floats_ * 4, false);
+    positions_ = (int*)dev(S * 4, false);
+    tokens_dev_ = (int*)dev(S * 4, false);
+    d_pos_ = (int*)dev(64, true);
+    d_token_ = (int*)dev(64, true);
+    argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
+    h_token_ = (int*)nt_hip_malloc_host(64);
+    if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
+        !d_pos_ || !d_token_ || !argmax_scratch_ || !h_token_) {
+        err_ = "buffer allocation failed";
+        return NTK_E_NOMEM;
+    }
+    *h_token_ = 0;
+    return NTK_OK;
+}
+
+uint64_t Model::bytes_per_token(int pos) const {
+    uint64_t b = 0;
+    for (const auto& L : layers_)
+        b += L.wq.nbytes + L.wk.nbytes + L.wv.nbytes + L.wo.nbytes + L.w_gate.nbytes + L.w_up.nbytes + L.w_down.nbytes;
+    b += output_.nbytes;
+    b += (uint64_t)(2 * cfg_.n_layers + 1) * cfg_.hidden_size * 4;
+    const uint64_t kv_row = (uint64_t)cfg_.n_kv_heads * cfg_.head_dim * 2;
+    b += 2ull * cfg_.n_layers * kv_row * (uint64_t)(pos + 1) + 2ull * cfg_.n_layers * kv_row;
+    b += ntk_row_bytes(token_embd_.dtype, cfg_.hidden_size);
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1:1 path: the reference's own launcher sequence (transformer.cpp:604-669, attention.cpp:120-211,
+// ffn.cpp:85-134), through the same C ABI an external caller would use
+// ---------------------------------------------------------------------------------------------------
+float* Model::forward(const int* tokens, int T, int start_pos) {
+    if (T <= 0 || start_pos < 0 || start_pos + T > cfg_.max_seq_len) { err_ = "forward: sequence exceeds context"; return nullptr; }
+    const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
+    const int qd = nh * hd, kvd = nkv * hd;
+    void* s = stream_;
+    // embedding rows are dequantised on the device (the reference does it on the host and uploads, :419-599)
+    if (ntk_memcpy_h2d_async(tokens_dev_, tokens, (size_t)T * 4, s) != NTK_OK) return nullptr;
+    const int est = ntk_embed_rows(hidden_, token_embd_.ptr, tokens_dev_, T, H, token_embd_.dtype, s);
+    if (est == NTK_E_DTYPE) fprintf(stderr, "Error: Unsupported embedding dtype: %s\n", dtype_name(token_embd_.dtype));
+    else if (est != NTK_OK) return nullptr;
+    std::vector<int> pos(T);
+    for (int i = 0; i < T; ++i) pos[i] = start_pos + i;
+    if (ntk_memcpy_h2d_async(positions_, pos.data(), (size_t)T * 4, s) != NTK_OK) return nullptr;
+    if (ntk_stream_synchronize(s) != NTK_OK) return nullptr;   // `pos` / `tokens` are host temporaries
+
+    const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
+    const float scale = 1.0f / sqrtf((float)hd);
+    float* q_buf = workspace_;
+    float* k_buf = q_buf + (size_t)T * qd;
+    float* v_buf = k_buf + (size_t)T * kvd;
+    float* attn_out = v_buf + (size_t)T * kvd;
+    float* gate_buf = workspace_;
+    float* up_buf = gate_buf + (size_t)T * I;
+    int rc = NTK_OK;
+    auto ok = [&](int st) { if (st != NTK_OK && rc == NTK_OK) rc = st; };
+    auto gemv = [&](float* y, const DevTensor& w, const float* x) {
+        const int st = ntk_gemv(y, w.ptr, x, (int)w.out_f, (int)w.in_f, w.dtype, s);
+        if (st == NTK_E_DTYPE) fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dtype_name(w.dtype));   // gemm.cu:801-803
+        else ok(st);
+    };
+    for (int i = 0; i < cfg_.n_layers; ++i) {
+        const LayerWeights& L = layers_[i];
+        uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
+        uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
+        ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.attn_norm.ptr, T, H, cfg_.norm_eps, s));
+        for (int t = 0; t < T; ++t) {
+            const float* x = residual_ + (size_t)t * H;
+            gemv(q_buf + (size_t)t * qd, L.wq, x);
+            gemv(k_buf + (size_t)t * kvd, L.wk, x);
+            gemv(v_buf + (size_t)t * kvd, L.wv, x);
+        }
+        ok(ntk_rope(q_buf, k_buf, positions_, 1, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, s));
+        ok(ntk_copy_to_kv_cache(kc, vc, k_buf, v_buf, T, nkv, hd, start_pos, cfg_.max_seq_len, s));
+        if (T == 1) ok(ntk_attention_decode(attn_out, q_buf, kc, vc, start_pos + T, nh, nkv, hd, cfg_.max_seq_len, scale, s));
+        else ok(ntk_attention_prefill(attn_out, q_buf, kc, vc, T, start_pos, nh, nkv, hd, cfg_.max_seq_len, scale, s));
+        for (int t = 0; t < T; ++t) gemv(residual_ + (size_t)t * H, L.wo, attn_out + (size_t)t * qd);
+        ok(ntk_add_inplace(hidden_, residual_, T * H, s));
+        ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.ffn_norm.ptr, T, H, cfg_.norm_eps, s));
+        for (int t = 0; t < T; ++t) {
+            const float* x = residual_ + (size_t)t * H;
+            float* g = gate_buf + (size_t)t * I;
+            float* u = up_buf + (size_t)t * I;
+            gemv(g, L.w_gate, x);
+            gemv(u, L.w_up, x);
+            ok(ntk_silu_mul(g, g, u, I, s));
+            gemv(residual_ + (size_t)t * H, L.w_down, g);
+        }
+        ok(ntk_add_inplace(hidden_, residual_, T * H, s));
+        if (rc != NTK_OK) break;
+    }
+    float* last = hidden_ + (size_t)(T - 1) * H;
+    ok(ntk_rmsnorm(last, last, (const float*)output_norm_.ptr, 1, H, cfg_.norm_eps, s));   // in place, :658-659
+    gemv(logits_, output_, last);
+    ok(ntk_stream_synchronize(s));
+    if (rc != NTK_OK) { err_ = std::string("forward failed: ") + ntk_status_string(rc); return nullptr; }
+    return logits_;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused single-token path
+// ---------------------------------------------------------------------------------------------------
+int Model::set_device_token(int token) {
+    *h_token_ = token;
+    return ntk_memcpy_h2d_async(d_token_, h_token_, 4, stream_);
+}
+int Model::set_device_pos(int pos) {
+    // small blocking copy: callers do this once per generation
+    nt_hip_memcpy_h2d(d_pos_, &pos, 4);
+    return NTK_OK;
+}
+int Model::sync() { return ntk_stream_synchronize(stream_); }
+int Model::host_token() const { return *h_token_; }
+int Model::copy_logits(float* host) {
+    NT_TRY(ntk_memcpy_d2h_async(host, logits_, (size_t)cfg_.vocab_size * 4, stream_));
+    return ntk_stream_synchronize(stream_);
+}
+
+int Model::enqueue_token(bool greedy) {
+    const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
+    const int qd = nh * hd, kvd = nkv * hd;
+    void* s = stream_;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
+    float* q_buf = workspace_;
+    float* k_buf = q_buf + qd;
+    float* v_buf = k_buf + kvd;
+    float* attn_out = v_buf + kvd;
+    float* gate_buf = workspace_;
+    float* up_buf = gate_buf + I;
+
+    // y_k = W_k . f(x) for n <= 3 matrices sharing x.  Matrices with one quantised dtype go out as one fused
+    // launch (RMSNorm prologue when `norm`, residual epilogue when `resid`, n == 1); dense F16/F32 tensors take
+    // the 1:1 launchers.  Scratch: residual_[0,H) = dense output before the residual add, residual_[H,2H) = norm(x).
+    auto project = [&](const DevTensor* const* ws, float* const* ys, int n, const float* x, const DevTensor* norm,
+                       const float* resid) -> int {
+        const float* nw = norm ? (const float*)norm->ptr : nullptr;
+        bool done[3] = {false, false, false};
+        for (int a = 0; a < n; ++a) {
+            if (done[a]) continue;
+            const DevTensor& w = *ws[a];
+            if (!is_quant(w.dtype)) {
+                const float* xin = x;
+                if (nw) {
+                    NT_TRY(ntk_rmsnorm(residual_ + H, x, nw, 1, (int)w.in_f, cfg_.norm_eps, s));
+                    xin = residual_ + H;
+                }
+                float* y = resid ? residual_ : ys[a];
+                NT_TRY(ntk_gemv(y, w.ptr, xin, (int)w.out_f, (int)w.in_f, w.dtype, s));
+                if (resid) NT_TRY(ntk_add(ys[a], resid, residual_, (int)w.out_f, s));
+                done[a] = true;
+                continue;
+            }
+            ntk_gemv_seg segs[3];
+            int m = 0;
+            for (int b = a; b < n; ++b) {
+                if (done[b] || ws[b]->dtype != w.dtype) continue;
+                segs[m++] = {ws[b]->ptr, ys[b], (int)ws[b]->out_f, ws[b]->dtype};
+                done[b] = true;
+            }
+            NT_TRY(ntk_gemv_fused(segs, m, x, (int)w.in_f, nw, cfg_.norm_eps, resid, 0, s));
+        }
+        return NTK_OK;
+    };
+    auto project1 = [&](const DevTensor& w, float* y, const float* x, const DevTensor* norm, const float* resid) -> int {
+        const DevTensor* ws[1] = {&w};
+        float* ys[1] = {y};
+        return project(ws, ys, 1, x, norm, resid);
+    };
+
+    const int est = ntk_embed_rows(hidden_, token_embd_.ptr, d_token_, 1, H, token_embd_.dtype, s);
+    if (est != NTK_OK && est != NTK_E_DTYPE) return est;
+    for (int i = 0; i < cfg_.n_layers; ++i) {
+        const LayerWeights& L = layers_[i];
+        uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
+        uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
+        {
+            const DevTensor* ws[3] = {&L.wq, &L.wk, &L.wv};
+            float* ys[3] = {q_buf, k_buf, v_buf};
+            NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
+        }
+        NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, nh, nkv, hd, cfg_.max_seq_len, scale,
+                                          cfg_.rope_theta, cfg_.rope_freq_scale, s));
+        NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
+        if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
+            ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
+            NT_TRY(ntk_gemv_fused(segs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s));
+        } else {
+            const DevTensor* ws[2] = {&L.w_gate, &L.w_up};
+            float* ys[2] = {gate_buf, up_buf};
+            NT_TRY(project(ws, ys, 2, hidden_, &L.ffn_norm, nullptr));
+            NT_TRY(ntk_silu_mul(gate_buf, gate_buf, up_buf, I, s));
+        }
+        NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_));
+    }
+    NT_TRY(project1(output_, logits_, hidden_, &output_norm_, nullptr));
+    if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
+    NT_TRY(ntk_advance_pos(d_pos_, s));
+    return NTK_OK;
+}
+
+int Model::decode_step_fused(bool greedy, bool use_graph) {
+    if (!use_graph) return enqueue_token(greedy);
+    ihipGraphExec_t*& slot = greedy ? graph_greedy_ : graph_logits_;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return NTK_E_LAUNCH;
+        const int rc = enqueue_token(greedy);
+        const hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc != NTK_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return rc != NTK_OK ? rc : NTK_E_LAUNCH; }
+        hipGraphExec_t ex = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) return NTK_E_LAUNCH;
+        slot = reinterpret_cast<ihipGraphExec_t*>(ex);
+    }
+    return hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(slot), st) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+
+}  // namespace nt

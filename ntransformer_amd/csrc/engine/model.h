@@ -1,0 +1,100 @@
+// engine/model.h -- resident-weights Llama model on one MI355X.
+// Replaces the resident subset of reference src/model/{transformer,attention,ffn,norm}.{h,cpp}
+// (Transformer::load / load_layer / allocate_buffers / embed_tokens / forward, Attention::forward,
+// FFN::forward, RMSNorm::forward).  The reference's streaming / tiered / delta / speculative paths exist
+// to fit 24 GB of VRAM and are dropped: 288 GB of HBM holds every target model resident.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "gguf.h"
+#include "synth.h"
+
+struct ihipGraphExec_t;   // hipGraphExec_t
+
+namespace nt {
+
+struct DevTensor {
+    void* ptr = nullptr;   // device
+    int dtype = 0;
+    int64_t in_f = 0, out_f = 0;
+    size_t nbytes = 0;
+};
+
+struct LayerWeights {
+    DevTensor attn_norm, wq, wk, wv, wo, ffn_norm, w_gate, w_up, w_down;
+};
+
+class Model {
+public:
+    Model() = default;
+    ~Model();
+    Model(const Model&) = delete;
+    Model& operator=(const Model&) = delete;
+
+    // reference Transformer::load (transformer.cpp:59-126): parse, cap context, weights -> HBM, buffers
+    int load(const std::string& gguf_path, int max_context);
+    // same model object built from the seeded generator, tensor by tensor, without a file
+    int load_synthetic(const SynthSpec& spec, int max_context, int nthreads);
+
+    // reference Transformer::forward (transformer.cpp:604-669): the reference's launcher sequence, 1:1,
+    // any seq_len (prefill = per-token GEMV loops like the reference).  Returns device logits [vocab].
+    float* forward(const int* tokens, int seq_len, int start_pos);
+
+    // Fused single-token step: 5 launches per layer, position and token id stay on the device so the whole
+    // token is one hipGraph replay.  Token comes from d_token_ (set_device_token / previous argmax).
+    // If greedy: also runs the device argmax and advances the position.
+    int decode_step_fused(bool greedy, bool use_graph);
+    int set_device_token(int token);
+    int set_device_pos(int pos);
+    int sync();
+    int host_token() const;                 // token written by the last device argmax (after sync)
+    float* logits_ptr() { return logits_; }
+    int copy_logits(float* host);           // D2H of [vocab] floats (blocking)
+
+    const ModelConfig& config() const { return cfg_; }
+    const GgufVocab& vocab() const { return vocab_; }
+    const std::string& error() const { return err_; }
+    uint64_t weight_bytes() const { return weight_bytes_; }
+    // algorithmic bytes one decode token must move at position `pos`
+    uint64_t bytes_per_token(int pos) const;
+    void set_fuse(bool on) { fuse_ = on; }
+    void* stream() const { return stream_; }
+
+private:
+    int finish_load(int max_context);
+    int alloc_buffers();
+    int upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int64_t out_f, size_t nbytes);
+    void free_all();
+    int enqueue_token(bool greedy);   // the fused launch sequence for one token
+
+    ModelConfig cfg_;
+    GgufVocab vocab_;
+    std::string err_;
+    std::vector<LayerWeights> layers_;
+    DevTensor token_embd_, output_norm_, output_;
+    bool output_tied_ = false;
+    uint64_t weight_bytes_ = 0;
+    std::vector<void*> allocs_;
+
+    // buffers (reference transformer.cpp:330-391)
+    uint16_t* k_cache_ = nullptr;   // [L][max_seq][nkv][hd] half
+    uint16_t* v_cache_ = nullptr;
+    float* hidden_ = nullptr;       // [max_seq][H]
+    float* residual_ = nullptr;     // [max_seq][H]
+    float* workspace_ = nullptr;    // max(attention, ffn) floats, shared by all layers
+    size_t workspace_floats_ = 0;
+    float* logits_ = nullptr;       // [V]
+    int* positions_ = nullptr;      // [max_seq]
+    int* tokens_dev_ = nullptr;     // [max_seq]
+    int* d_pos_ = nullptr;          // device scalar: position of the token being decoded
+    int* d_token_ = nullptr;        // device scalar: id of the token being decoded
+    int* h_token_ = nullptr;        // pinned mirror of the argmax result
+    float* argmax_scratch_ = nullptr;
+    void* stream_ = nullptr;
+    bool fuse_ = true;
+    ihipGraphExec_t* graph_greedy_ = nullptr;
+    ihipGraphExec_t* graph_logits_ = nullptr;
+};
+
+}  // namespace nt

@@ -1,0 +1,264 @@
+// engine/synth.cpp -- see synth.h
+#include "synth.h"
+#include "../../../include/ntk.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+namespace nt {
+namespace {
+
+inline uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+    return h;
+}
+inline double u01(uint64_t r) { return (double)(r >> 11) * (1.0 / 9007199254740992.0); }
+inline uint16_t f2h(float f) {
+    const _Float16 h = (_Float16)f;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+inline void put16(uint8_t* p, uint16_t v) { memcpy(p, &v, 2); }
+
+struct BlockInfo { int bw, bb; };
+BlockInfo block_of(int gt) {
+    switch (gt) {
+        case 0: return {1, 4};
+        case 1: return {1, 2};
+        case 2: return {32, 18};
+        case 8: return {32, 34};
+        case 12: return {256, 144};
+        case 13: return {256, 176};
+        case 14: return {256, 210};
+        default: return {0, 0};
+    }
+}
+
+void fill_random(uint8_t* p, size_t n, uint64_t& st) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { const uint64_t r = splitmix(st); memcpy(p + i, &r, 8); }
+    if (i < n) { const uint64_t r = splitmix(st); memcpy(p + i, &r, n - i); }
+}
+
+// one quant block (or 256 dense elements) starting at element index e0
+void fill_unit(uint8_t* dst, int gt, uint64_t key, uint64_t unit, double tgt) {
+    uint64_t st = key ^ (unit * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull);
+    const double jit = 1.0 + 0.25 * (2.0 * u01(splitmix(st)) - 1.0);
+    switch (gt) {
+        case 8: {   // Q8_0: d, 32 x int8
+            fill_random(dst + 2, 32, st);
+            put16(dst, f2h((float)(tgt / 73.9 * jit)));
+            break;
+        }
+        case 2: {   // Q4_0
+            fill_random(dst + 2, 16, st);
+            put16(dst, f2h((float)(tgt / 4.6 * jit)));
+            break;
+        }
+        case 12: case 13: {   // Q4_K / Q5_K: d, dmin, scales[12], (qh[32],) qs[128]
+            const int bb = gt == 12 ? 144 : 176;
+            fill_random(dst + 4, (size_t)bb - 4, st);
+            const double mean_q = gt == 12 ? 7.5 : 15.5, dev_q = gt == 12 ? 4.6 : 9.2;
+            const double d = tgt / (32.0 * dev_q * 1.6) * jit;
+            put16(dst, f2h((float)d));
+            put16(dst + 2, f2h((float)(d * mean_q)));
+            break;
+        }
+        case 14: {  // Q6_K: ql[128], qh[64], int8 scales[16] in [-64,63], d
+            fill_random(dst, 208, st);
+            for (int i = 0; i < 16; ++i) dst[192 + i] = (uint8_t)(int8_t)((int)(dst[192 + i] & 0x7F) - 64);
+            put16(dst + 208, f2h((float)(tgt / (37.0 * 18.5) * jit)));
+            break;
+        }
+        default: break;
+    }
+}
+
+void fill_dense(uint8_t* dst, int gt, uint64_t key, int64_t e0, int64_t n, double tgt, bool norm_vec) {
+    for (int64_t e = 0; e < n; ++e) {
+        uint64_t st = key ^ ((uint64_t)(e0 + e) * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull);
+        float v;
+        if (norm_vec) {
+            v = (float)(1.0 + 0.05 * (2.0 * u01(splitmix(st)) - 1.0));
+        } else {   // ~N(0,1) via sum of 4 uniforms, scaled
+            double a = 0;
+            for (int k = 0; k < 4; ++k) a += u01(splitmix(st));
+            v = (float)((a - 2.0) * 1.7320508 * tgt);
+        }
+        if (gt == 0) memcpy(dst + 4 * e, &v, 4);
+        else put16(dst + 2 * e, f2h(v));
+    }
+}
+
+int mix_type(const std::string& mix) {
+    if (mix == "Q8_0") return 8;
+    if (mix == "Q4_0") return 2;
+    if (mix == "Q4_K") return 12;
+    if (mix == "Q5_K") return 13;
+    if (mix == "Q6_K") return 14;
+    if (mix == "F16") return 1;
+    if (mix == "F32") return 0;
+    return -1;
+}
+bool use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n / 8) % 3 == 2; }   // llama.cpp Q4_K_M rule
+
+}  // namespace
+
+bool synth_plan(const SynthSpec& s, std::vector<SynthTensor>& out) {
+    out.clear();
+    const bool km = s.mix == "Q4_K_M";
+    const int base = km ? 12 : mix_type(s.mix);
+    if (base < 0 || s.heads <= 0 || s.kv_heads <= 0 || s.hidden % s.heads) return false;
+    const int hd = s.hidden / s.heads;
+    const int64_t q_dim = (int64_t)s.heads * hd, kv_dim = (int64_t)s.kv_heads * hd;
+    auto add = [&](const std::string& name, int gt, int64_t in_f, int64_t out_f, double sigma) {
+        const BlockInfo b = block_of(gt);
+        out.push_back({name, gt, in_f, out_f, sigma, (size_t)(in_f * out_f / b.bw) * b.bb});
+    };
+    const int embd_t = km ? 12 : (base == 13 ? 12 : base);   // Q5_K files keep a Q4_K embedding (see gguf.py)
+    add("token_embd.weight", embd_t, s.hidden, s.vocab, std::sqrt((double)s.hidden));
+    for (int i = 0; i < s.layers; ++i) {
+        const std::string p = "blk." + std::to_string(i) + ".";
+        const bool more = km && use_more_bits(i, s.layers);
+        const int v_t = more ? 14 : (km && s.heads / s.kv_heads >= 4 && s.hidden >= 8192 ? 13 : base);
+        const int down_t = more ? 14 : base;
+        add(p + "attn_norm.weight", 0, s.hidden, 1, 0);
+        add(p + "attn_q.weight", base, s.hidden, q_dim, 1);
+        add(p + "attn_k.weight", base, s.hidden, kv_dim, 1);
+        add(p + "attn_v.weight", v_t, s.hidden, kv_dim, 1);
+        add(p + "attn_output.weight", base, q_dim, s.hidden, 1);
+        add(p + "ffn_norm.weight", 0, s.hidden, 1, 0);
+        add(p + "ffn_gate.weight", base, s.hidden, s.inter, 1);
+        add(p + "ffn_up.weight", base, s.hidden, s.inter, 1);
+        add(p + "ffn_down.weight", down_t, s.inter, s.hidden, 1);
+    }
+    add("output_norm.weight", 0, s.hidden, 1, 0);
+    add("output.weight", km ? 14 : base, s.hidden, s.vocab, 2.0);
+    return true;
+}
+
+void synth_fill(void* dst, const SynthTensor& t, uint64_t seed, int nthreads) {
+    const BlockInfo b = block_of(t.ggml_type);
+    const uint64_t key = seed * 0x9E3779B97F4A7C15ull ^ fnv1a(t.name);
+    const bool norm_vec = t.sigma == 0;
+    const double tgt = norm_vec ? 0 : t.sigma / std::sqrt((double)t.in_f);
+    const int64_t n_el = t.in_f * t.out_f;
+    const int64_t units = b.bw > 1 ? n_el / b.bw : (n_el + 255) / 256;
+    nthreads = std::max(1, std::min<int>(nthreads, (int)std::min<int64_t>(units, 256)));
+    auto work = [&](int tid) {
+        const int64_t u0 = units * tid / nthreads, u1 = units * (tid + 1) / nthreads;
+        uint8_t* p = static_cast<uint8_t*>(dst);
+        for (int64_t u = u0; u < u1; ++u) {
+            if (b.bw > 1) fill_unit(p + (size_t)u * b.bb, t.ggml_type, key, (uint64_t)u, tgt);
+            else fill_dense(p + (size_t)u * 256 * b.bb, t.ggml_type, key, u * 256, std::min<int64_t>(256, n_el - u * 256), tgt, norm_vec);
+        }
+    };
+    if (nthreads == 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (int i = 0; i < nthreads; ++i) th.emplace_back(work, i);
+    for (auto& x : th) x.join();
+}
+
+void synth_vocab(const SynthSpec& s, std::vector<std::string>& tokens, std::vector<int>& types) {
+    tokens.clear();
+    types.clear();
+    int next = 0;
+    auto utf8 = [](unsigned cp) {
+        std::string u;
+        if (cp < 0x80) u.push_back((char)cp);
+        else if (cp < 0x800) { u.push_back((char)(0xC0 | (cp >> 6))); u.push_back((char)(0x80 | (cp & 0x3F))); }
+        else { u.push_back((char)(0xE0 | (cp >> 12))); u.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); u.push_back((char)(0x80 | (cp & 0x3F))); }
+        return u;
+    };
+    std::vector<std::string> alpha(256);
+    for (int b = 0; b < 256 && (int)tokens.size() < s.vocab; ++b) {
+        const bool keep = (b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174);
+        alpha[b] = utf8(keep ? (unsigned)b : 256u + (unsigned)next++);
+        tokens.push_back(alpha[b]);
+        types.push_back(1);
+    }
+    uint64_t st = s.seed ^ 0x7777ull;
+    static const char letters[] = "abcdefghijklmnopqrstuvwxyz";
+    while ((int)tokens.size() < s.vocab) {
+        const int id = (int)tokens.size();
+        if (id == s.bos || id == s.eos) { tokens.push_back("<|special_" + std::to_string(id) + "|>"); types.push_back(3); continue; }
+        // unique by construction: base-26 digits of the id, optionally led by the space glyph
+        std::string t = (splitmix(st) & 1) ? alpha[0x20] : std::string();
+        for (int v = id; v > 0; v /= 26) t.push_back(letters[v % 26]);
+        t.push_back(letters[splitmix(st) % 26]);
+        tokens.push_back(t);
+        types.push_back(1);
+    }
+}
+
+int synth_write_gguf(const std::string& path, const SynthSpec& s, int nthreads) {
+    std::vector<SynthTensor> plan;
+    if (!synth_plan(s, plan)) return NTK_E_SHAPE;
+    std::vector<std::string> toks;
+    std::vector<int> types;
+    synth_vocab(s, toks, types);
+
+    std::string head;
+    auto u32 = [&](uint32_t v) { head.append(reinterpret_cast<const char*>(&v), 4); };
+    auto u64 = [&](uint64_t v) { head.append(reinterpret_cast<const char*>(&v), 8); };
+    auto f32 = [&](float v) { head.append(reinterpret_cast<const char*>(&v), 4); };
+    auto str = [&](const std::string& v) { u64(v.size()); head += v; };
+    auto kv_u32 = [&](const char* k, uint32_t v) { str(k); u32(4); u32(v); };
+    auto kv_f32 = [&](const char* k, float v) { str(k); u32(6); f32(v); };
+    auto kv_str = [&](const char* k, const std::string& v) { str(k); u32(8); str(v); };
+    u32(0x46554747u); u32(3); u64(plan.size()); u64(16);
+    kv_str("general.architecture", "llama");
+    kv_str("general.name", "synthetic-" + s.mix);
+    kv_u32("general.alignment", 32);
+    kv_u32("llama.vocab_size", (uint32_t)s.vocab);
+    kv_u32("llama.embedding_length", (uint32_t)s.hidden);
+    kv_u32("llama.feed_forward_length", (uint32_t)s.inter);
+    kv_u32("llama.block_count", (uint32_t)s.layers);
+    kv_u32("llama.attention.head_count", (uint32_t)s.heads);
+    kv_u32("llama.attention.head_count_kv", (uint32_t)s.kv_heads);
+    kv_u32("llama.context_length", (uint32_t)s.ctx);
+    kv_f32("llama.attention.layer_norm_rms_epsilon", s.eps);
+    kv_f32("llama.rope.freq_base", s.theta);
+    str("tokenizer.ggml.tokens"); u32(9); u32(8); u64(toks.size());
+    for (const auto& t : toks) str(t);
+    str("tokenizer.ggml.token_type"); u32(9); u32(5); u64(types.size());
+    for (int t : types) u32((uint32_t)t);
+    kv_u32("tokenizer.ggml.bos_token_id", (uint32_t)s.bos);
+    kv_u32("tokenizer.ggml.eos_token_id", (uint32_t)s.eos);
+    uint64_t off = 0;
+    for (const auto& t : plan) {
+        str(t.name);
+        if (t.out_f == 1 && t.sigma == 0) { u32(1); u64((uint64_t)t.in_f); }
+        else { u32(2); u64((uint64_t)t.in_f); u64((uint64_t)t.out_f); }
+        u32((uint32_t)t.ggml_type);
+        u64(off);
+        off += (t.nbytes + 31) / 32 * 32;
+    }
+    head.append((32 - head.size() % 32) % 32, '\0');
+
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return NTK_E_IO;
+    bool ok = fwrite(head.data(), 1, head.size(), f) == head.size();
+    std::vector<uint8_t> buf;
+    for (const auto& t : plan) {
+        const size_t padded = (t.nbytes + 31) / 32 * 32;
+        buf.assign(padded, 0);
+        synth_fill(buf.data(), t, s.seed, nthreads);
+        ok = ok && fwrite(buf.data(), 1, padded, f) == padded;
+        if (!ok) break;
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? NTK_OK : NTK_E_IO;
+}
+
+}  // namespace nt

@@ -1,0 +1,606 @@
+// gemv.hip -- dequant-fused GEMV for batch-1 decode on gfx950 (CDNA4, wave64).
+//
+// Replaces: launch_gemv / launch_gemv_add and the seven gemv_*_kernel of the reference
+// (reference src/cuda/gemm.cu:32-671, 748-871).  Same inputs (RAW GGUF blocks, row-major [out][in], F32 x)
+// and the same per-block arithmetic (integer quant x F32 activation, F32 accumulate, FP16 scale applied per
+// block / sub-block); the decomposition is new:
+//
+//   * A lane owns 64 consecutive COLUMNS of a <=4096-column slice for the whole launch, so its 64
+//     activations (optionally RMS-normalised on the fly) live in VGPRs; the reference re-reads x from
+//     shared memory for every weight (4 B of LDS traffic per weight).
+//   * A wave streams the slice of each row it owns as a BYTE stream: coalesced 16 B/lane non-temporal
+//     loads (1 KiB per wave instruction), software-prefetched one row ahead into VGPRs.  GGUF blocks are
+//     34/18/144/176/210 bytes and only 2-byte aligned, so the stream is bounced through a wave-private LDS
+//     image (ds_write_b128, no barrier: a wave's DS ops execute in order) and each lane pulls the bytes of
+//     ITS columns back with aligned dword reads + v_alignbyte.  LDS carries ~2 B per weight byte instead
+//     of 4 B per weight; the reference's "lane b reads block b" pattern would be a 34-byte-stride gather.
+//   * Rows longer than 4096 columns are split across the waves of one workgroup (slice s = wave % ns);
+//     partial sums meet in LDS once per batch of 4 rows (one barrier, fixed summation order).
+//   * Fusions the engine uses (ntk_gemv_fused): RMSNorm prologue, Q|K|V or gate|up row segments sharing
+//     one x, residual-add epilogue, SiLU(gate)*up epilogue.
+//
+// HBM-bound: algorithmic bytes per launch = rows * row_bytes (+ in*4 for x per workgroup from L2).
+#include "common.hip.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace ntk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RB = 4;            // rows (items) per batch between cross-wave combines
+constexpr int XPITCH = 68;       // floats per 64-column lane row in the prologue LDS image (conflict-free b128)
+constexpr int MAX_SEG = 3;
+
+template <int DT> struct Fmt;
+// BW/BB: weights / bytes per GGUF block; NL: 1 KiB chunks per <=4096-column slice (+15 alignment bytes);
+// MINW: waves per SIMD the register allocator must leave room for (4 -> <=128 VGPRs, 3 -> <=168: the 5/6-bit
+// decoders keep more packed dwords live and would otherwise spill the prefetch registers)
+template <> struct Fmt<NTK_DT_Q8_0> { static constexpr int BW = 32, BB = 34, NL = 5, MINW = 4; };
+template <> struct Fmt<NTK_DT_Q4_0> { static constexpr int BW = 32, BB = 18, NL = 3, MINW = 4; };
+template <> struct Fmt<NTK_DT_Q4_K> { static constexpr int BW = 256, BB = 144, NL = 3, MINW = 4; };
+template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, NL = 3, MINW = 3; };
+template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 3; };
+
+struct GemvSeg {
+    const uint8_t* W;   // 16-byte-aligned-down base of the segment
+    float* y;
+    int rows;
+    int delta;          // true W = W + delta (0..15)
+};
+
+struct GemvParams {
+    GemvSeg seg[MAX_SEG];
+    int nseg;
+    int total_rows;     // silu_pair: rows of ONE matrix
+    const float* x;
+    int in;
+    int ns;             // column slices per row (waves cooperating on one row)
+    int rw;             // row groups per workgroup
+    int slice_cols;
+    int nbatch;         // uniform batch count per row group
+    int x_vec;          // x (and norm_w) 16-byte aligned -> float4 loads
+    const float* norm_w;
+    float eps;
+    const float* resid;
+    int silu_pair;
+    unsigned row_bytes;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Per-format decode of one lane's 64 columns from the staged byte image.
+//   st    : wave-private LDS image of the slice's bytes, st[shift + k] = byte k of the slice
+//   ncols : how many of the lane's 64 columns exist (0, 32 or 64)
+//   xr    : the lane's activations, sx16/sx32 their run sums
+// ------------------------------------------------------------------------------------------------
+template <int DT> struct Dot;
+
+template <> struct Dot<NTK_DT_Q8_0> {   // reference gemm.cu:129-141: sum += d * sum_j q_j x_j
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+                                const float (&)[4], const float (&)[2]) {
+        float acc = 0.0f;
+        const int o = shift + 68 * lane;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (ncols > 32 * h) {
+                const int ob = o + 34 * h;
+                const float d = h2f(lds_u16_at(st, ob));
+                uint32_t q[8];
+                lds_read_dwords<8>(q, st, ob + 2);
+                float bs = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bs = fmaf(sb2f(q[i], k), xr[32 * h + 4 * i + k], bs);
+                }
+                acc = fmaf(d, bs, acc);
+            }
+        }
+        return acc;
+    }
+};
+
+template <> struct Dot<NTK_DT_Q4_0> {   // reference gemm.cu:60-75: w_j = d (lo-8), w_{j+16} = d (hi-8)
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+                                const float (&)[4], const float (&sx32)[2]) {
+        float acc = 0.0f;
+        const int o = shift + 36 * lane;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (ncols > 32 * h) {
+                const int ob = o + 18 * h;
+                const float d = h2f(lds_u16_at(st, ob));
+                uint32_t q[4];
+                lds_read_dwords<4>(q, st, ob + 2);
+                float bs = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t lo = q[i] & 0x0F0F0F0Fu, hi = (q[i] >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        bs = fmaf(ub2f(lo, k), xr[32 * h + 4 * i + k], bs);
+                        bs = fmaf(ub2f(hi, k), xr[32 * h + 16 + 4 * i + k], bs);
+                    }
+                }
+                acc = fmaf(d, fmaf(-8.0f, sx32[h], bs), acc);   // sum (n-8) x = sum n x - 8 sum x
+            }
+        }
+        return acc;
+    }
+};
+
+// K-quant header: d, dmin and the (scale, min) pairs of sub-blocks 2c, 2c+1
+__device__ __forceinline__ void kq_header(const uint8_t* st, int ob, int c, float& d1, float& m1, float& d2, float& m2) {
+    uint32_t hd[4];
+    lds_read_dwords<4>(hd, st, ob);
+    const float d = h2f((uint16_t)(hd[0] & 0xFFFFu)), dmin = h2f((uint16_t)(hd[0] >> 16));
+    float s_lo, n_lo, s_hi, n_hi;
+    kq_scale_min(hd[1], hd[2], hd[3], 2 * c, s_lo, n_lo);
+    kq_scale_min(hd[1], hd[2], hd[3], 2 * c + 1, s_hi, n_hi);
+    d1 = d * s_lo; m1 = dmin * n_lo; d2 = d * s_hi; m2 = dmin * n_hi;
+}
+
+template <> struct Dot<NTK_DT_Q4_K> {   // reference gemm.cu:190-244
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+                                const float (&)[4], const float (&sx32)[2]) {
+        if (ncols <= 0) return 0.0f;
+        const int c = lane & 3, ob = shift + 144 * (lane >> 2);
+        float d1, m1, d2, m2;
+        kq_header(st, ob, c, d1, m1, d2, m2);
+        uint32_t q[8];
+        lds_read_dwords<8>(q, st, ob + 16 + 32 * c);
+        float s_lo = 0.0f, s_hi = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t lo = q[i] & 0x0F0F0F0Fu, hi = (q[i] >> 4) & 0x0F0F0F0Fu;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s_lo = fmaf(ub2f(lo, k), xr[4 * i + k], s_lo);
+                s_hi = fmaf(ub2f(hi, k), xr[32 + 4 * i + k], s_hi);
+            }
+        }
+        float t = d1 * s_lo;
+        t = fmaf(-m1, sx32[0], t);
+        t = fmaf(d2, s_hi, t);
+        t = fmaf(-m2, sx32[1], t);
+        return t;
+    }
+};
+
+template <> struct Dot<NTK_DT_Q5_K> {   // reference gemm.cu:297-354
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+                                const float (&)[4], const float (&sx32)[2]) {
+        if (ncols <= 0) return 0.0f;
+        const int c = lane & 3, ob = shift + 176 * (lane >> 2);
+        float d1, m1, d2, m2;
+        kq_header(st, ob, c, d1, m1, d2, m2);
+        float s_lo = 0.0f, s_hi = 0.0f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {   // two 16-byte halves: keeps the live dword count low
+            uint32_t qh[4], ql[4];
+            lds_read_dwords<4>(qh, st, ob + 16 + 16 * hh);
+            lds_read_dwords<4>(ql, st, ob + 48 + 32 * c + 16 * hh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lo = (ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c)) & 0x01010101u) << 4);
+                const uint32_t hi = ((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c + 1)) & 0x01010101u) << 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s_lo = fmaf(ub2f(lo, k), xr[16 * hh + 4 * i + k], s_lo);
+                    s_hi = fmaf(ub2f(hi, k), xr[32 + 16 * hh + 4 * i + k], s_hi);
+                }
+            }
+        }
+        float t = d1 * s_lo;
+        t = fmaf(-m1, sx32[0], t);
+        t = fmaf(d2, s_hi, t);
+        t = fmaf(-m2, sx32[1], t);
+        return t;
+    }
+};
+
+template <> struct Dot<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (block, half, t): groups g = 2t, 2t+1
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+                                const float (&sx16)[4], const float (&)[2]) {
+        if (ncols <= 0) return 0.0f;
+        const int t = lane & 1, hf = (lane >> 1) & 1, ob = shift + 210 * (lane >> 2);
+        const uint32_t scw = lds_u32_at(st, ob + 192 + 8 * hf + 4 * t);   // sc[is + 2gg], bytes: (gg0,is0)(gg0,is1)(gg1,is0)(gg1,is1)
+        const float d = h2f(lds_u16_at(st, ob + 208));
+        float Sa[2] = {0.0f, 0.0f}, Sb[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int is = 0; is < 2; ++is) {   // the two 16-column runs of each group (sub-scale index is)
+            uint32_t A[4], B[4], H[4];
+            lds_read_dwords<4>(A, st, ob + 64 * hf + 16 * is);
+            lds_read_dwords<4>(B, st, ob + 64 * hf + 32 + 16 * is);
+            lds_read_dwords<4>(H, st, ob + 128 + 32 * hf + 16 * is);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t qa = ((A[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t)) & 0x03030303u) << 4);
+                const uint32_t qb = ((B[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t + 2)) & 0x03030303u) << 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    Sa[is] = fmaf(ub2f(qa, k), xr[16 * is + 4 * i + k], Sa[is]);
+                    Sb[is] = fmaf(ub2f(qb, k), xr[32 + 16 * is + 4 * i + k], Sb[is]);
+                }
+            }
+        }
+        const float Sa0 = Sa[0], Sa1 = Sa[1], Sb0 = Sb[0], Sb1 = Sb[1];
+        // sum (q-32) x = sum q x - 32 sum x, per 16-column run, times the run's int8 sub-scale
+        float bs = sb2f(scw, 0) * fmaf(-32.0f, sx16[0], Sa0);
+        bs = fmaf(sb2f(scw, 1), fmaf(-32.0f, sx16[1], Sa1), bs);
+        bs = fmaf(sb2f(scw, 2), fmaf(-32.0f, sx16[2], Sb0), bs);
+        bs = fmaf(sb2f(scw, 3), fmaf(-32.0f, sx16[3], Sb1), bs);
+        return d * bs;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The kernel.  blockDim.x = 64 * ns * rw.  Dynamic LDS:
+//   [0, A)   prologue x (+ norm weight) image, afterwards nwaves * STAGE wave-private byte images
+//   [A, ..)  partial sums [2][rw][ns][RB] + 16 floats reduction scratch
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
+    using F = Fmt<DT>;
+    constexpr int NL = F::NL;
+    constexpr int STAGE = NL * 1024 + 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = p.ns * p.rw;
+    const int s = wave % p.ns;        // column slice of this wave
+    const int g = wave / p.ns;        // row group of this wave
+    const bool norm = p.norm_w != nullptr;
+
+    const size_t regionA = (size_t)std::max(nwaves * STAGE, (norm ? 2 : 1) * 64 * XPITCH * 4);
+    float* part = reinterpret_cast<float*>(smem + regionA);
+    float* red = part + 2 * p.rw * p.ns * RB;
+
+    // ---- item bookkeeping + first prefetch (issued before the prologue so HBM latency overlaps it) ----
+    uint8_t* stage = smem + (size_t)wave * STAGE;
+    const int my_len = min(p.slice_cols, p.in - s * p.slice_cols);
+    const int ncols = min(64, max(0, my_len - 64 * lane));
+    const unsigned slice_byte0 = (unsigned)((size_t)s * p.slice_cols / F::BW * F::BB);
+    const unsigned slice_bytes = (unsigned)(my_len / F::BW * F::BB);
+    const int group = blockIdx.x * p.rw + g;
+    const int ngroups = gridDim.x * p.rw;
+    const int mats = p.silu_pair ? 2 : 1;
+    const int n_my = (p.total_rows > group) ? ((p.total_rows - 1 - group) / ngroups + 1) * mats : 0;
+
+    // item q of this wave -> (segment, row inside the segment); q < n_my
+    auto locate = [&](int q, int& seg, int& row) {
+        int r = group + (q / mats) * ngroups;
+        if (p.silu_pair) { seg = q & 1; row = r; return; }
+        seg = 0;
+        while (seg + 1 < p.nseg && r >= p.seg[seg].rows) { r -= p.seg[seg].rows; ++seg; }
+        row = r;
+    };
+
+    u32x4 pf[NL];
+    auto issue = [&](int q) {
+        int seg, row;
+        locate(q, seg, row);
+        const size_t rel = (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + slice_byte0;
+        const unsigned nbytes = (unsigned)(rel & 15) + slice_bytes;
+        const unsigned last = (nbytes - 1u) & ~15u;
+        const uint8_t* a = p.seg[seg].W + (rel & ~(size_t)15);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const unsigned off = min(16u * (unsigned)(lane + 64 * j), last);
+            pf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + off));
+        }
+    };
+    if (n_my > 0 && slice_bytes > 0) issue(0);
+
+    // ---- prologue: this lane's 64 activations into registers (through a padded LDS image: coalesced
+    //      global reads, conflict-free ds_read_b128), optional RMSNorm (reference rmsnorm.cu:16-70) ----
+    float xr[64];
+    {
+        float* ximg = reinterpret_cast<float*>(smem);
+        float* wimg = ximg + 64 * XPITCH;
+        // pass 1 (NORM only): sum of squares over the whole row, every thread a strided share
+        float rms_inv = 1.0f;
+        if (norm) {
+            float ssq = 0.0f;
+            if (p.x_vec && (p.in & 3) == 0) {
+                for (int c = tid * 4; c < p.in; c += blockDim.x * 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(p.x + c);
+                    ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq);
+                    ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
+                }
+            } else {
+                for (int c = tid; c < p.in; c += blockDim.x) ssq = fmaf(p.x[c], p.x[c], ssq);
+            }
+            const float tot = block_sum(ssq, red);
+            rms_inv = 1.0f / sqrtf(tot / (float)p.in + p.eps);
+        }
+        // pass 2: slice by slice through the padded image; the owning waves pull their 64 columns
+        const int ncols_l = ncols;
+        for (int sp = 0; sp < p.ns; ++sp) {
+            const int c0 = sp * p.slice_cols;
+            const int len = min(p.slice_cols, p.in - c0);
+            __syncthreads();
+            if (p.x_vec && (len & 3) == 0) {
+                for (int c = tid * 4; c < len; c += blockDim.x * 4) {
+                    *reinterpret_cast<float4*>(ximg + (c >> 6) * XPITCH + (c & 63)) =
+                        *reinterpret_cast<const float4*>(p.x + c0 + c);
+                    if (norm)
+                        *reinterpret_cast<float4*>(wimg + (c >> 6) * XPITCH + (c & 63)) =
+                            *reinterpret_cast<const float4*>(p.norm_w + c0 + c);
+                }
+            } else {
+                for (int c = tid; c < len; c += blockDim.x) {
+                    ximg[(c >> 6) * XPITCH + (c & 63)] = p.x[c0 + c];
+                    if (norm) wimg[(c >> 6) * XPITCH + (c & 63)] = p.norm_w[c0 + c];
+                }
+            }
+            __syncthreads();
+            if (s == sp) {
+#pragma unroll
+                for (int j = 0; j < 64; j += 4) {
+                    float4 v = *reinterpret_cast<const float4*>(ximg + lane * XPITCH + j);
+                    if (norm) {   // x * rms_inv * w, the reference's association (rmsnorm.cu:68)
+                        const float4 w = *reinterpret_cast<const float4*>(wimg + lane * XPITCH + j);
+                        v.x = v.x * rms_inv * w.x; v.y = v.y * rms_inv * w.y;
+                        v.z = v.z * rms_inv * w.z; v.w = v.w * rms_inv * w.w;
+                    }
+                    xr[j] = (j < ncols_l) ? v.x : 0.0f;
+                    xr[j + 1] = (j + 1 < ncols_l) ? v.y : 0.0f;
+                    xr[j + 2] = (j + 2 < ncols_l) ? v.z : 0.0f;
+                    xr[j + 3] = (j + 3 < ncols_l) ? v.w : 0.0f;
+                }
+            }
+        }
+        __syncthreads();   // LDS region A becomes the staging area
+    }
+    float sx16[4], sx32[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += xr[16 * r + j];
+        sx16[r] = t;
+    }
+    sx32[0] = sx16[0] + sx16[1];
+    sx32[1] = sx16[2] + sx16[3];
+    float gate_carry = 0.0f;
+
+    // cross-slice combine of one batch (ns > 1): wave s == 0 of each row group sums the ns partials of
+    // item i in slice order and applies the epilogue; `cnt` items of batch b are valid
+    auto combine = [&](int b, int cnt) {
+        if (s != 0) return;
+        const float* pg = part + (size_t)(b & 1) * p.rw * p.ns * RB + (size_t)(g * p.ns) * RB;
+        float t = 0.0f;
+        if (lane < cnt)
+            for (int ss = 0; ss < p.ns; ++ss) t += pg[ss * RB + lane];
+        const float nxt = __shfl_down(t, 1, 64);
+        if (lane < cnt) {
+            int seg, row;
+            locate(b * RB + lane, seg, row);
+            if (p.silu_pair) {
+                if ((lane & 1) == 0) p.seg[0].y[row] = t / (1.0f + expf(-t)) * nxt;
+            } else {
+                float v = t;
+                if (p.resid != nullptr && seg == 0) v = p.resid[row] + v;
+                p.seg[seg].y[row] = v;
+            }
+        }
+    };
+
+    // ---- row streaming ---------------------------------------------------------------------------
+    // Every wave walks its own list of (segment,row) items; the valid ones are a prefix of length n_my.
+    // All loads / LDS writes are unpredicated (lanes past the slice end re-read its last chunk) so the loop
+    // body is straight-line code: hipcc then waits for the prefetch exactly once, right before the ds_writes.
+    for (int q = 0; q < n_my; ++q) {
+        int seg, row;
+        locate(q, seg, row);
+        const size_t rel = (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + slice_byte0;
+        const int shift = (int)(rel & 15);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(stage + 16 * (lane + 64 * j)) = pf[j];
+        __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
+        if (q + 1 < n_my) issue(q + 1);    // next row's bytes fly while this one is decoded
+        const float acc = Dot<DT>::run(stage, shift, lane, ncols, xr, sx16, sx32);
+        __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
+        const float tot = wave_sum(acc);
+
+        if (p.ns == 1) {
+            if (lane == 0) {
+                if (p.silu_pair) {
+                    if ((q & 1) == 0) gate_carry = tot;
+                    else p.seg[0].y[row] = gate_carry / (1.0f + expf(-gate_carry)) * tot;   // reference gemm.cu:719-724
+                } else {
+                    float v = tot;
+                    if (p.resid != nullptr && seg == 0) v = p.resid[row] + v;             // reference elementwise.cu:23-32
+                    p.seg[seg].y[row] = v;
+                }
+            }
+        } else {
+            const int b = q / RB, i = q % RB;
+            if (lane == 0) part[(size_t)(b & 1) * p.rw * p.ns * RB + (size_t)(g * p.ns + s) * RB + i] = tot;
+            if (i == RB - 1) {
+                __syncthreads();
+                combine(b, RB);
+            }
+        }
+    }
+    if (p.ns > 1) {   // close a partial batch, then keep barrier counts equal across the workgroup
+        int done = n_my / RB;
+        if (n_my % RB) {
+            __syncthreads();
+            combine(done, n_my % RB);
+            ++done;
+        }
+        for (; done < p.nbatch; ++done) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense F16 / F32 rows (reference gemm.cu:476-671): one wave per row, 16-byte lane loads when the row
+// is aligned, scalar otherwise (the reference's own F32 test uses in = 3).  Not on any target config.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void gemv_dense_kernel(float* __restrict__ y, const T* __restrict__ W,
+                                                         const float* __restrict__ x, int out, int in) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (blockDim.x >> 6);
+    constexpr int V = 16 / (int)sizeof(T);
+    for (int r = wave; r < out; r += nwaves) {
+        const T* w = W + (size_t)r * in;
+        float acc = 0.0f;
+        int done = 0;
+        if ((reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+            const int nv = in / V;
+            for (int i = lane; i < nv; i += 64) {
+                const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w) + i);
+                if constexpr (sizeof(T) == 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(x + 4 * i);
+                    acc = fmaf(__uint_as_float(raw.x), xv.x, acc); acc = fmaf(__uint_as_float(raw.y), xv.y, acc);
+                    acc = fmaf(__uint_as_float(raw.z), xv.z, acc); acc = fmaf(__uint_as_float(raw.w), xv.w, acc);
+                } else {
+                    const float4 x0 = *reinterpret_cast<const float4*>(x + 8 * i);
+                    const float4 x1 = *reinterpret_cast<const float4*>(x + 8 * i + 4);
+                    acc = fmaf(h2f((uint16_t)(raw.x & 0xFFFF)), x0.x, acc); acc = fmaf(h2f((uint16_t)(raw.x >> 16)), x0.y, acc);
+                    acc = fmaf(h2f((uint16_t)(raw.y & 0xFFFF)), x0.z, acc); acc = fmaf(h2f((uint16_t)(raw.y >> 16)), x0.w, acc);
+                    acc = fmaf(h2f((uint16_t)(raw.z & 0xFFFF)), x1.x, acc); acc = fmaf(h2f((uint16_t)(raw.z >> 16)), x1.y, acc);
+                    acc = fmaf(h2f((uint16_t)(raw.w & 0xFFFF)), x1.z, acc); acc = fmaf(h2f((uint16_t)(raw.w >> 16)), x1.w, acc);
+                }
+            }
+            done = nv * V;
+        }
+        for (int i = done + lane; i < in; i += 64) {
+            float wv;
+            if constexpr (sizeof(T) == 4) wv = (float)w[i]; else wv = h2f((uint16_t)w[i]);
+            acc = fmaf(wv, x[i], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) y[r] = ADD ? y[r] + acc : acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static bool is_quant(int dt) {
+    return dt == NTK_DT_Q8_0 || dt == NTK_DT_Q4_0 || dt == NTK_DT_Q4_K || dt == NTK_DT_Q5_K || dt == NTK_DT_Q6_K;
+}
+
+template <int DT>
+static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w, float eps,
+                        const float* resid, int silu_pair, hipStream_t st) {
+    using F = Fmt<DT>;
+    if (in <= 0 || in % F::BW != 0) return NTK_E_SHAPE;
+    GemvParams p{};
+    long total = 0;
+    const size_t row_bytes = (size_t)in / F::BW * F::BB;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].rows < 0) return NTK_E_SHAPE;
+        if (segs[i].rows > 0 && (!segs[i].W || !segs[i].y)) return NTK_E_NULL;
+        if ((size_t)segs[i].rows * row_bytes > 0xFFFFFFF0ull) return NTK_E_SHAPE;
+        const uintptr_t w = reinterpret_cast<uintptr_t>(segs[i].W);
+        if (w & 1) return NTK_E_ALIGN;
+        p.seg[i].W = reinterpret_cast<const uint8_t*>(w & ~(uintptr_t)15);
+        p.seg[i].delta = (int)(w & 15);
+        p.seg[i].y = segs[i].y;
+        p.seg[i].rows = segs[i].rows;
+        total += segs[i].rows;
+    }
+    if (silu_pair) {
+        if (nseg != 2 || segs[0].rows != segs[1].rows || resid) return NTK_E_SHAPE;
+        total = segs[0].rows;
+    }
+    if (total == 0) return NTK_OK;
+    p.nseg = nseg;
+    p.total_rows = (int)total;
+    p.x = x;
+    p.in = in;
+    const int align = F::BW == 256 ? 256 : 64;
+    p.ns = (in + 4095) / 4096;
+    p.slice_cols = ((in + p.ns - 1) / p.ns + align - 1) / align * align;
+    if (p.ns > 8 || (long)(p.ns - 1) * p.slice_cols >= in) return NTK_E_SHAPE;   // in_features > 32768 not supported
+    // waves per workgroup = ns * rw ~ 8: one x prologue feeds eight row streams
+    p.rw = p.ns == 1 ? 8 : (p.ns == 2 ? 4 : (p.ns <= 4 ? 2 : 1));
+    const int nwaves = p.ns * p.rw;
+    p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+               (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? 1 : 0;
+    p.norm_w = norm_w;
+    p.eps = eps;
+    p.resid = resid;
+    p.silu_pair = silu_pair;
+    p.row_bytes = (unsigned)row_bytes;
+    const int mats = silu_pair ? 2 : 1;
+    // enough workgroups to fill 256 CUs twice over, but never more row groups than rows
+    static const int max_wg = [] { const char* e = getenv("NTK_GEMV_MAX_WG"); return e ? std::max(1, atoi(e)) : 512; }();
+    int grid = (int)std::min<long>((total + p.rw - 1) / p.rw, max_wg);
+    grid = std::max(grid, 1);
+    const long ngroups = (long)grid * p.rw;
+    const long rows_per_group = (total + ngroups - 1) / ngroups;
+    p.nbatch = (int)((rows_per_group * mats + RB - 1) / RB);
+    constexpr int STAGE = F::NL * 1024 + 64;
+    const size_t regionA = (size_t)std::max(nwaves * STAGE, (norm_w ? 2 : 1) * 64 * XPITCH * 4);
+    const size_t lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16) * sizeof(float);
+    hipLaunchKernelGGL(gemv_quant_kernel<DT>, dim3(grid), dim3(64 * nwaves), lds, st, p);
+    return last_launch_status();
+}
+
+static int dispatch_quant(int dt, const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w,
+                          float eps, const float* resid, int silu_pair, hipStream_t st) {
+    switch (dt) {
+        case NTK_DT_Q8_0: return launch_quant<NTK_DT_Q8_0>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        case NTK_DT_Q4_0: return launch_quant<NTK_DT_Q4_0>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        case NTK_DT_Q4_K: return launch_quant<NTK_DT_Q4_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        case NTK_DT_Q5_K: return launch_quant<NTK_DT_Q5_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        case NTK_DT_Q6_K: return launch_quant<NTK_DT_Q6_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        default: return NTK_E_DTYPE;
+    }
+}
+
+template <bool ADD>
+static int launch_dense(float* y, const void* W, const float* x, int out, int in, int dt, hipStream_t st) {
+    if (out == 0) return NTK_OK;
+    const int grid = std::min((out + 3) / 4, 2048);
+    if (dt == NTK_DT_F32)
+        hipLaunchKernelGGL((gemv_dense_kernel<float, ADD>), dim3(grid), dim3(256), 0, st, y, (const float*)W, x, out, in);
+    else
+        hipLaunchKernelGGL((gemv_dense_kernel<uint16_t, ADD>), dim3(grid), dim3(256), 0, st, y, (const uint16_t*)W, x, out, in);
+    return last_launch_status();
+}
+
+}  // namespace ntk
+
+extern "C" {
+
+int ntk_gemv(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype, void* stream) {
+    if (!y || !W || !x) return NTK_E_NULL;
+    if (out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
+    hipStream_t st = ntk::resolve_stream(stream);
+    if (weight_dtype == NTK_DT_F32 || weight_dtype == NTK_DT_F16)
+        return ntk::launch_dense<false>(y, W, x, out_features, in_features, weight_dtype, st);
+    if (!ntk::is_quant(weight_dtype)) return NTK_E_DTYPE;
+    ntk_gemv_seg seg{W, y, out_features, weight_dtype};
+    return ntk::dispatch_quant(weight_dtype, &seg, 1, x, in_features, nullptr, 0.0f, nullptr, 0, st);
+}
+
+int ntk_gemv_add(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype, void* stream) {
+    if (!y || !W || !x) return NTK_E_NULL;
+    if (out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
+    if (weight_dtype != NTK_DT_F16) return NTK_E_DTYPE;   // reference gemm.cu:861-869
+    return ntk::launch_dense<true>(y, W, x, out_features, in_features, weight_dtype, ntk::resolve_stream(stream));
+}
+
+int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                   const float* resid, int silu_pair, void* stream) {
+    if (!segs || !x) return NTK_E_NULL;
+    if (nseg < 1 || nseg > ntk::MAX_SEG) return NTK_E_SHAPE;
+    for (int i = 1; i < nseg; ++i)
+        if (segs[i].dtype != segs[0].dtype) return NTK_E_DTYPE;
+    if (!ntk::is_quant(segs[0].dtype)) return NTK_E_DTYPE;
+    return ntk::dispatch_quant(segs[0].dtype, segs, nseg, x, in_features, norm_w, eps, resid, silu_pair,
+                               ntk::resolve_stream(stream));
+}
+
+}  // extern "C"

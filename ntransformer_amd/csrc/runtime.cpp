@@ -1,0 +1,192 @@
+// runtime.cpp -- HIP runtime layer: device selection, the three streams, events, memory.
+//
+// Replaces reference src/core/device.{h,cu} (CUDADevice singleton + extern "C" nt_cuda_*).  Same surface
+// and behaviour (3 non-blocking streams, blocking nt_*_memcpy_*, malloc returns NULL + message on failure),
+// talking to HIP directly.  One process drives one GPU; replicas are separate processes.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include "../../include/ntk.h"
+
+namespace ntk {
+
+struct Runtime {
+    std::mutex mu;
+    bool ready = false;
+    int device = -1;
+    hipStream_t streams[3] = {nullptr, nullptr, nullptr};
+    hipDeviceProp_t prop{};
+};
+static Runtime& rt() {
+    static Runtime r;
+    return r;
+}
+
+static int init_locked(Runtime& r, int device_id) {
+    if (r.ready && r.device == device_id) return NTK_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return NTK_E_NODEVICE;
+    if (device_id < 0 || device_id >= n) return NTK_E_NODEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return NTK_E_NODEVICE;
+    if (hipGetDeviceProperties(&r.prop, device_id) != hipSuccess) return NTK_E_NODEVICE;
+    for (auto& s : r.streams)
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return NTK_E_LAUNCH;
+    r.device = device_id;
+    r.ready = true;
+    return NTK_OK;
+}
+
+static int ensure_ready() {
+    Runtime& r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.ready) return NTK_OK;
+    int dev = 0;
+    if (const char* e = getenv("NTK_DEVICE")) dev = atoi(e);
+    return init_locked(r, dev);
+}
+
+hipStream_t resolve_stream(void* s) {
+    if (s) return static_cast<hipStream_t>(s);
+    if (ensure_ready() != NTK_OK) return nullptr;
+    return rt().streams[0];
+}
+
+int last_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return NTK_OK;
+    fprintf(stderr, "ntk: HIP launch error: %s\n", hipGetErrorString(e));
+    return NTK_E_LAUNCH;
+}
+
+}  // namespace ntk
+
+extern "C" {
+using namespace ntk;
+
+int ntk_abi_version(void) { return NTK_ABI_VERSION; }
+
+const char* ntk_status_string(int st) {
+    switch (st) {
+        case NTK_OK: return "ok";
+        case NTK_E_DTYPE: return "unsupported dtype";
+        case NTK_E_SHAPE: return "bad shape";
+        case NTK_E_LAUNCH: return "HIP launch/runtime error";
+        case NTK_E_ALIGN: return "misaligned pointer";
+        case NTK_E_NULL: return "null pointer";
+        case NTK_E_NODEVICE: return "no usable GPU";
+        case NTK_E_NOMEM: return "out of memory";
+        case NTK_E_IO: return "I/O error";
+        case NTK_E_FORMAT: return "malformed GGUF";
+        default: return "unknown status";
+    }
+}
+
+size_t ntk_row_bytes(int dtype, int64_t n) {
+    if (n < 0) return 0;
+    switch (dtype) {   // reference src/core/types.h:37-88
+        case NTK_DT_F32: case NTK_DT_I32: return (size_t)n * 4;
+        case NTK_DT_F16: return (size_t)n * 2;
+        case NTK_DT_Q8_0: return n % 32 ? 0 : (size_t)(n / 32) * 34;
+        case NTK_DT_Q4_0: return n % 32 ? 0 : (size_t)(n / 32) * 18;
+        case NTK_DT_Q4_K: return n % 256 ? 0 : (size_t)(n / 256) * 144;
+        case NTK_DT_Q5_K: return n % 256 ? 0 : (size_t)(n / 256) * 176;
+        case NTK_DT_Q6_K: return n % 256 ? 0 : (size_t)(n / 256) * 210;
+        case NTK_DT_Q2_K: return n % 256 ? 0 : (size_t)(n / 256) * 84;
+        default: return 0;
+    }
+}
+
+int ntk_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+int ntk_device_init(int device_id) {
+    Runtime& r = rt();
+    std::lock_guard<std::mutex> lk(r.mu);
+    return init_locked(r, device_id);
+}
+int ntk_device_name(char* buf, size_t n) {
+    if (!buf || n == 0) return NTK_E_NULL;
+    if (ensure_ready() != NTK_OK) return NTK_E_NODEVICE;
+    snprintf(buf, n, "%s (%s, %d CUs)", rt().prop.name, rt().prop.gcnArchName, rt().prop.multiProcessorCount);
+    return NTK_OK;
+}
+int ntk_device_mem_info(size_t* free_b, size_t* total_b) {
+    if (ensure_ready() != NTK_OK) return NTK_E_NODEVICE;
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) return NTK_E_LAUNCH;
+    if (free_b) *free_b = f;
+    if (total_b) *total_b = t;
+    return NTK_OK;
+}
+void* ntk_stream(int which) {
+    if (which < 0 || which > 2 || ensure_ready() != NTK_OK) return nullptr;
+    return rt().streams[which];
+}
+int ntk_stream_synchronize(void* stream) {
+    hipStream_t s = resolve_stream(stream);
+    return hipStreamSynchronize(s) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+int ntk_device_synchronize(void) {
+    if (ensure_ready() != NTK_OK) return NTK_E_NODEVICE;
+    return hipDeviceSynchronize() == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+void* ntk_event_create(void) {
+    if (ensure_ready() != NTK_OK) return nullptr;
+    hipEvent_t e;
+    return hipEventCreate(&e) == hipSuccess ? static_cast<void*>(e) : nullptr;
+}
+int ntk_event_destroy(void* ev) { return ev && hipEventDestroy(static_cast<hipEvent_t>(ev)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH; }
+int ntk_event_record(void* ev, void* stream) {
+    if (!ev) return NTK_E_NULL;
+    return hipEventRecord(static_cast<hipEvent_t>(ev), resolve_stream(stream)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+int ntk_event_synchronize(void* ev) {
+    if (!ev) return NTK_E_NULL;
+    return hipEventSynchronize(static_cast<hipEvent_t>(ev)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+int ntk_event_elapsed_ms(void* start, void* end, float* ms) {
+    if (!start || !end || !ms) return NTK_E_NULL;
+    return hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(end)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+
+void* nt_hip_malloc(size_t size) {
+    if (ensure_ready() != NTK_OK) { fprintf(stderr, "ntk: no GPU available for hipMalloc\n"); return nullptr; }
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, size ? size : 1);
+    if (e != hipSuccess) {   // reference device.cu:154-162: message + NULL
+        fprintf(stderr, "hipMalloc failed (%zu bytes): %s\n", size, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+void nt_hip_free(void* p) { if (p) (void)hipFree(p); }
+void nt_hip_memcpy_h2d(void* d, const void* s, size_t n) { if (n) (void)hipMemcpy(d, s, n, hipMemcpyHostToDevice); }
+void nt_hip_memcpy_d2h(void* d, const void* s, size_t n) { if (n) (void)hipMemcpy(d, s, n, hipMemcpyDeviceToHost); }
+void nt_hip_memcpy_d2d(void* d, const void* s, size_t n) { if (n) (void)hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
+void nt_hip_memset(void* p, int v, size_t n) { if (n) (void)hipMemset(p, v, n); }
+void* nt_hip_malloc_host(size_t size) {
+    if (ensure_ready() != NTK_OK) return nullptr;
+    void* p = nullptr;
+    return hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void nt_hip_free_host(void* p) { if (p) (void)hipHostFree(p); }
+int ntk_memcpy_h2d_async(void* d, const void* s, size_t n, void* stream) {
+    return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, resolve_stream(stream)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+int ntk_memcpy_d2h_async(void* d, const void* s, size_t n, void* stream) {
+    return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, resolve_stream(stream)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+
+// the reference's symbol names (reference src/core/device.h:79-88)
+void* nt_cuda_malloc(size_t n) { return nt_hip_malloc(n); }
+void nt_cuda_free(void* p) { nt_hip_free(p); }
+void nt_cuda_memcpy_h2d(void* d, const void* s, size_t n) { nt_hip_memcpy_h2d(d, s, n); }
+void nt_cuda_memcpy_d2h(void* d, const void* s, size_t n) { nt_hip_memcpy_d2h(d, s, n); }
+void nt_cuda_memcpy_d2d(void* d, const void* s, size_t n) { nt_hip_memcpy_d2d(d, s, n); }
+void nt_cuda_memset(void* p, int v, size_t n) { nt_hip_memset(p, v, n); }
+void* nt_cuda_malloc_host(size_t n) { return nt_hip_malloc_host(n); }
+void nt_cuda_free_host(void* p) { nt_hip_free_host(p); }
+
+}  // extern "C"

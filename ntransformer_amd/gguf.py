@@ -500,6 +500,18 @@ def make_synthetic_llama(path: str, shape: LlamaShape, mix: str = "Q8_0", seed: 
     return types
 
 
+def write_vocab_gguf(path: str, tokens: Sequence[bytes], scores: Optional[Sequence[float]], types: Sequence[int],
+                     bos: int, eos: int) -> None:
+    """A GGUF that carries only a vocabulary (plus one dummy tensor): tokenizer fixtures."""
+    kvs = [kv_str("general.architecture", "llama"), kv_str("general.name", "vocab-only"), kv_u32("general.alignment", 32),
+           kv_u32("llama.embedding_length", 32), kv_u32("llama.attention.head_count", 1), kv_u32("llama.block_count", 0),
+           kv_arr_str("tokenizer.ggml.tokens", tokens), kv_arr_i32("tokenizer.ggml.token_type", types),
+           kv_u32("tokenizer.ggml.bos_token_id", bos), kv_u32("tokenizer.ggml.eos_token_id", eos)]
+    if scores is not None:
+        kvs.append(kv_arr_f32("tokenizer.ggml.scores", scores))
+    write_gguf(path, kvs, [TensorSpec("dummy.weight", (32,), GGML_F32, np.zeros(32, "<f4").tobytes())])
+
+
 def algorithmic_bytes_per_token(shape: LlamaShape, types: Dict[str, int], pos: int = 0) -> int:
     """B_tok of SURVEY.md section 8(d): matrices once in GGUF encoding + norms + KV r/w + 1 embedding row."""
     hd = shape.hidden // shape.heads

@@ -1,0 +1,185 @@
+"""Python mirror of the reference's operator surface (reference src/cuda/kernels.h:14-71) over the C ABI in
+include/ntk.h: same function names (`launch_*`), same argument order and meaning, device pointers in and out.
+`DeviceBuffer` is a minimal stand-in for the reference's Tensor on Device::CUDA (reference src/core/tensor.h).
+Everything here runs on the GPU through libntransformer_hip.so; nothing falls back to the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import GemvSeg, check
+
+
+class DeviceBuffer:
+    """Owned device allocation with numpy upload/download (blocking copies, like nt_cuda_memcpy_*)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        self.ptr = _lib.lib().nt_hip_malloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise _lib.NtkError(-7, "hipMalloc(%d)" % nbytes)
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        if a.nbytes:
+            _lib.lib().nt_hip_memcpy_h2d(b.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes)
+        return b
+
+    @classmethod
+    def zeros(cls, nbytes: int) -> "DeviceBuffer":
+        b = cls(nbytes)
+        _lib.lib().nt_hip_memset(b.ptr, 0, nbytes)
+        return b
+
+    def upload(self, a: np.ndarray, offset: int = 0) -> None:
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        _lib.lib().nt_hip_memcpy_h2d(self.ptr + offset, a.ctypes.data_as(C.c_void_p), a.nbytes)
+
+    def numpy(self, dtype=np.float32, count: Optional[int] = None, offset: int = 0) -> np.ndarray:
+        dt = np.dtype(dtype)
+        n = (self.nbytes - offset) // dt.itemsize if count is None else count
+        out = np.empty(n, dt)
+        if n:
+            _lib.lib().nt_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr + offset, out.nbytes)
+        return out
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + byte_offset
+
+    def free(self) -> None:
+        if self.ptr:
+            _lib.lib().nt_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _p(x) -> Optional[int]:
+    if x is None:
+        return None
+    return x.ptr if isinstance(x, DeviceBuffer) else int(x)
+
+
+def init(device_id: int = 0) -> None:
+    check(_lib.lib().ntk_device_init(device_id), "ntk_device_init")
+
+
+def synchronize(stream=None) -> None:
+    check(_lib.lib().ntk_stream_synchronize(stream), "stream sync")
+
+
+# ---- the 17 launchers of kernels.h, 1:1 ---------------------------------------------------------------
+def launch_rmsnorm(output, input, weight, batch_size, hidden_size, eps, stream=None):
+    check(_lib.lib().ntk_rmsnorm(_p(output), _p(input), _p(weight), batch_size, hidden_size, eps, stream), "rmsnorm")
+
+
+def launch_rmsnorm_f16(output, input, weight, batch_size, hidden_size, eps, stream=None):
+    check(_lib.lib().ntk_rmsnorm_f16(_p(output), _p(input), _p(weight), batch_size, hidden_size, eps, stream), "rmsnorm_f16")
+
+
+def launch_rope(q, k, positions, batch_size, seq_len, n_heads, n_kv_heads, head_dim, theta_base, freq_scale,
+                interleaved, stream=None):
+    check(_lib.lib().ntk_rope(_p(q), _p(k), _p(positions), batch_size, seq_len, n_heads, n_kv_heads, head_dim,
+                              theta_base, freq_scale, int(bool(interleaved)), stream), "rope")
+
+
+def launch_softmax(output, input, rows, cols, stream=None):
+    check(_lib.lib().ntk_softmax(_p(output), _p(input), rows, cols, stream), "softmax")
+
+
+def launch_masked_softmax(output, input, mask, rows, cols, stream=None):
+    check(_lib.lib().ntk_masked_softmax(_p(output), _p(input), _p(mask), rows, cols, stream), "masked_softmax")
+
+
+def launch_gemv(y, W, x, out_features, in_features, weight_dtype, stream=None):
+    check(_lib.lib().ntk_gemv(_p(y), _p(W), _p(x), out_features, in_features, int(weight_dtype), stream), "gemv")
+
+
+def launch_gemv_add(y, W, x, out_features, in_features, weight_dtype, stream=None):
+    check(_lib.lib().ntk_gemv_add(_p(y), _p(W), _p(x), out_features, in_features, int(weight_dtype), stream), "gemv_add")
+
+
+def launch_gemm_f32(Cm, A, B, M, N, K, stream=None):
+    check(_lib.lib().ntk_gemm_f32(_p(Cm), _p(A), _p(B), M, N, K, stream), "gemm_f32")
+
+
+def launch_silu_mul(output, gate, up, size, stream=None):
+    check(_lib.lib().ntk_silu_mul(_p(output), _p(gate), _p(up), size, stream), "silu_mul")
+
+
+def launch_add_bias(y, bias, size, stream=None):
+    check(_lib.lib().ntk_add_bias(_p(y), _p(bias), size, stream), "add_bias")
+
+
+def launch_attention_decode(output, q, k_cache, v_cache, seq_len, n_heads, n_kv_heads, head_dim, max_seq, scale, stream=None):
+    check(_lib.lib().ntk_attention_decode(_p(output), _p(q), _p(k_cache), _p(v_cache), seq_len, n_heads, n_kv_heads,
+                                          head_dim, max_seq, scale, stream), "attention_decode")
+
+
+def launch_attention_prefill(output, Q, k_cache, v_cache, seq_len, start_pos, n_heads, n_kv_heads, head_dim, max_seq,
+                             scale, stream=None):
+    check(_lib.lib().ntk_attention_prefill(_p(output), _p(Q), _p(k_cache), _p(v_cache), seq_len, start_pos, n_heads,
+                                           n_kv_heads, head_dim, max_seq, scale, stream), "attention_prefill")
+
+
+def launch_copy_to_kv_cache(k_cache, v_cache, k, v, seq_len, n_kv_heads, head_dim, start_pos, max_seq, stream=None):
+    check(_lib.lib().ntk_copy_to_kv_cache(_p(k_cache), _p(v_cache), _p(k), _p(v), seq_len, n_kv_heads, head_dim,
+                                          start_pos, max_seq, stream), "copy_to_kv_cache")
+
+
+def launch_add(out, a, b, size, stream=None):
+    check(_lib.lib().ntk_add(_p(out), _p(a), _p(b), size, stream), "add")
+
+
+def launch_add_inplace(a, b, size, stream=None):
+    check(_lib.lib().ntk_add_inplace(_p(a), _p(b), size, stream), "add_inplace")
+
+
+def launch_copy(dst, src, size, stream=None):
+    check(_lib.lib().ntk_copy(_p(dst), _p(src), size, stream), "copy")
+
+
+def launch_cosine_similarity(result, a, b, size, stream=None):
+    check(_lib.lib().ntk_cosine_similarity(_p(result), _p(a), _p(b), size, stream), "cosine_similarity")
+
+
+# ---- engine-level fused operators -----------------------------------------------------------------------
+def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resid=None, silu_pair=False, stream=None):
+    """segs: [(W, y, rows, dtype), ...] (<= 3, same dtype)."""
+    arr = (GemvSeg * len(segs))()
+    for i, (W, y, rows, dt) in enumerate(segs):
+        arr[i].W, arr[i].y, arr[i].rows, arr[i].dtype = _p(W), _p(y), rows, int(dt)
+    check(_lib.lib().ntk_gemv_fused(arr, len(segs), _p(x), in_features, _p(norm_w), eps, _p(resid), int(silu_pair),
+                                    stream), "gemv_fused")
+
+
+def attention_decode_fused(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale,
+                           theta_base, freq_scale=1.0, stream=None):
+    check(_lib.lib().ntk_attention_decode_fused(_p(output), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(d_pos),
+                                                n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale,
+                                                stream), "attention_decode_fused")
+
+
+def embed_rows(out, table, tokens, n_tokens, hidden, dtype, stream=None, allow_unsupported=False):
+    st = _lib.lib().ntk_embed_rows(_p(out), _p(table), _p(tokens), n_tokens, hidden, int(dtype), stream)
+    if not (allow_unsupported and st == -1):
+        check(st, "embed_rows")
+    return st
+
+
+def argmax(logits, n, d_out_token, scratch, h_mirror=None, stream=None):
+    check(_lib.lib().ntk_argmax(_p(logits), n, _p(d_out_token), _p(h_mirror), _p(scratch), stream), "argmax")
+
+
+def advance_pos(d_pos, stream=None):
+    check(_lib.lib().ntk_advance_pos(_p(d_pos), stream), "advance_pos")

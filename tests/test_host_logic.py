@@ -1,0 +1,143 @@
+"""Host-side logic of the product library, on the CPU (no GPU needed): the C ABI loads and exports every symbol
+the headers declare, and the GGUF reader / tokenizer / sampler agree with goldens produced by the reference's
+own unmodified classes (oracle/_ref/ref_host, tools/make_golden.py -> tests/golden/host_logic.json)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from ntransformer_amd import _lib
+from ntransformer_amd import gguf as G
+
+
+class GenParams(C.Structure):
+    _fields_ = [("max_tokens", C.c_int), ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float),
+                ("repeat_penalty", C.c_float), ("repeat_window", C.c_int), ("seed", C.c_uint64), ("stop_at_eos", C.c_int)]
+
+
+def declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:ntk|nt)_[a-z0-9_]+)\s*\(", src)) - {"nt_engine_t", "nt_tokenizer_t"})
+
+
+@pytest.mark.parametrize("header", ["ntk.h", "ntransformer.h"])
+def test_library_exports_every_declared_symbol(header):
+    L = _lib.lib()
+    names = declared_functions(header)
+    assert len(names) > 15
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_abi_basics_without_gpu():
+    L = _lib.lib()
+    assert L.ntk_abi_version() == 1
+    # nt::DType numeric contract (reference src/core/types.h:24-35) through ntk_row_bytes (types.h:37-88)
+    assert L.ntk_row_bytes(G.DT_Q8_0, 4096) == 4352
+    assert L.ntk_row_bytes(G.DT_Q4_0, 1024) == 576          # reference tests/test_tensor.cpp:131-134
+    assert L.ntk_row_bytes(G.DT_Q4_K, 4096) == 2304
+    assert L.ntk_row_bytes(G.DT_Q5_K, 4096) == 2816
+    assert L.ntk_row_bytes(G.DT_Q6_K, 4096) == 3360
+    assert L.ntk_row_bytes(G.DT_F16, 10) == 20 and L.ntk_row_bytes(G.DT_F32, 10) == 40
+    assert L.ntk_row_bytes(G.DT_Q8_0, 100) == 0
+    assert L.ntk_status_string(-1) == b"unsupported dtype"
+
+
+def test_null_engine_is_tolerated():
+    L = _lib.lib()
+    L.nt_engine_vocab_size.argtypes = [C.c_void_p]
+    L.nt_engine_generate.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_float, C.c_int, C.c_float]
+    L.nt_engine_generate.restype = C.c_void_p
+    assert L.nt_engine_vocab_size(None) == -1
+    assert L.nt_engine_generate(None, b"x", 4, 0.0, 1, 1.0) is None
+    L.nt_engine_create.restype = C.c_void_p
+    L.nt_engine_destroy.argtypes = [C.c_void_p]
+    e = L.nt_engine_create()
+    assert e
+    assert L.nt_engine_vocab_size(e) == -1          # nothing loaded
+    L.nt_engine_load.argtypes = [C.c_void_p, C.c_char_p]
+    assert L.nt_engine_load(e, b"/nonexistent.gguf") != 0
+    L.nt_engine_destroy(e)
+
+
+def describe(path):
+    L = _lib.lib()
+    buf = C.create_string_buffer(4 << 20)
+    n = L.nt_gguf_describe(path.encode(), buf, len(buf))
+    assert n > 0, n
+    return json.loads(buf.value.decode())
+
+
+@pytest.mark.parametrize("name", ["tiny_q8_0", "tiny_q4_k_m", "tiny_mixed"])
+def test_cpp_gguf_reader_matches_python_reader(name):
+    path = os.path.join(GOLDEN, name + ".gguf")
+    d = describe(path)
+    f = G.read_gguf(path)
+    assert d["data_offset"] == f.data_offset and d["version"] == 3
+    assert (d["hidden_size"], d["intermediate_size"], d["n_layers"], d["n_heads"], d["n_kv_heads"]) == (256, 512, 2, 4, 2)
+    assert d["head_dim"] == 64 and d["vocab_size"] == 512 and d["bos"] == 256 and d["eos"] == 257
+    assert abs(d["rope_theta"] - 500000.0) < 1e-3 and abs(d["norm_eps"] - 1e-5) < 1e-10
+    assert len(d["tensors"]) == len(f.tensors)
+    for t in d["tensors"]:
+        ti = f.tensors[t["name"]]
+        assert tuple(t["dims"]) == ti.dims and t["ggml_type"] == ti.ggml_type
+        assert t["offset"] == ti.offset and t["nbytes"] == ti.nbytes and t["dtype"] == G.GGML_TO_DT[ti.ggml_type]
+
+
+def test_gguf_reader_rejects_garbage(tmp_path):
+    L = _lib.lib()
+    p = tmp_path / "bad.gguf"
+    p.write_bytes(b"NOPE" + b"\0" * 64)
+    assert L.nt_gguf_describe(str(p).encode(), None, 0) == -9          # NTK_E_FORMAT
+    good = open(os.path.join(GOLDEN, "tiny_q8_0.gguf"), "rb").read()
+    p.write_bytes(good[:5000])                                          # truncated inside the metadata
+    assert L.nt_gguf_describe(str(p).encode(), None, 0) == -9
+    p.write_bytes(good[:200000])                                        # tensors run past the end of the file
+    assert L.nt_gguf_describe(str(p).encode(), None, 0) == -9
+    assert L.nt_gguf_describe(b"/nonexistent", None, 0) == -8           # NTK_E_IO
+
+
+HOST = json.load(open(os.path.join(GOLDEN, "host_logic.json")))
+
+
+@pytest.mark.parametrize("vocab", sorted(HOST["tokenizer"]))
+def test_tokenizer_matches_reference(vocab):
+    L = _lib.lib()
+    L.nt_tokenizer_open.restype = C.c_void_p
+    L.nt_tokenizer_open.argtypes = [C.c_char_p]
+    L.nt_tokenizer_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+    L.nt_tokenizer_decode.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
+    L.nt_tokenizer_close.argtypes = [C.c_void_p]
+    L.nt_tokenizer_is_gpt2.argtypes = [C.c_void_p]
+    t = L.nt_tokenizer_open(os.path.join(GOLDEN, vocab).encode())
+    assert t
+    assert L.nt_tokenizer_is_gpt2(t) == (0 if "spm" in vocab else 1)
+    for case in HOST["tokenizer"][vocab]:
+        raw = case["text"].encode("utf-8")
+        out = (C.c_int * 256)()
+        n = L.nt_tokenizer_encode(t, raw, len(raw), 1, out, 256)
+        assert list(out[:n]) == case["ids"], case["text"]
+        buf = C.create_string_buffer(1024)
+        m = L.nt_tokenizer_decode(t, out, n, buf, 1024)
+        assert buf.raw[:m].hex() == case["detok_hex"], case["text"]
+    L.nt_tokenizer_close(t)
+
+
+@pytest.mark.parametrize("idx", range(len(HOST["sampler"])))
+def test_sampler_matches_reference(idx):
+    L = _lib.lib()
+    case = HOST["sampler"][idx]
+    logits = np.fromfile(os.path.join(GOLDEN, "sampler_logits.f32"), np.float32)
+    c = case["cfg"]
+    p = GenParams(0, c["temperature"], c["top_k"], c["top_p"], c["repeat_penalty"], c["repeat_window"], c["seed"], 1)
+    recent = (C.c_int * len(case["recent"]))(*case["recent"])
+    out = (C.c_int * len(case["draws"]))()
+    L.nt_sampler_draw.argtypes = [C.c_void_p, C.c_int, C.POINTER(GenParams), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]
+    n = L.nt_sampler_draw(logits.ctypes.data_as(C.c_void_p), logits.size, C.byref(p), recent, len(case["recent"]), len(case["draws"]), out)
+    assert n == len(case["draws"])
+    assert list(out) == case["draws"]

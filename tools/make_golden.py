@@ -78,7 +78,67 @@ def golden_logits():
             os.remove(path)
 
 
+def spm_vocab():
+    """SentencePiece-flavoured vocabulary with scores and <0xXX> byte tokens (Llama-1/2 style)."""
+    toks = [b"<unk>", b"<s>", b"</s>"] + [b"<0x%02X>" % b for b in range(256)]
+    types = [2, 3, 3] + [6] * 256
+    sp = "\u2581".encode()
+    words = [sp, b"t", b"h", b"e", b"l", b"o", b"w", b"r", b"d", b"a", b"n", b"s", b"i", b"c", b"u", b"m", b"p", b".", b",",
+             b"he", b"th", b"the", sp + b"the", sp + b"t", b"ll", b"lo", b"llo", b"ello", b"hello", sp + b"hello", sp + b"h",
+             b"wor", b"ld", b"world", sp + b"world", sp + b"w", b"an", b"and", sp + b"and", sp + b"a", b"in", b"ing",
+             sp + sp, b"er", b"es", b"on", sp + b"s", b"st", b"ca", b"cat", sp + b"cat", b"\xc3\xa9", b"caf", sp + b"caf\xc3\xa9"]
+    toks += words
+    types += [1] * len(words)
+    scores = [0.0] * 259 + [-float(i) * 0.5 - (3.0 if len(w) == 1 else 0.0) for i, w in enumerate(words)]
+    return toks, scores, types
+
+
+TEXTS = ["hello world", "the cat and the hat", " leading space", "trailing space ", "two  spaces", "caf\u00e9 au lait",
+         "tabs\tand\nnewlines are bytes", "MiXeD CaSe 12345 !?", "\u65e5\u672c\u8a9e", "", "a", "the the the the"]
+
+
+def golden_host_logic():
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_host")
+    out = {"tokenizer": {}, "sampler": []}
+    spm = os.path.join(GOLD, "vocab_spm.gguf")
+    toks, scores, types = spm_vocab()
+    G.write_vocab_gguf(spm, toks, scores, types, bos=1, eos=2)
+    txt = "/tmp/_tok_lines.txt"
+    with open(txt, "w", encoding="utf-8") as f:
+        for t in TEXTS:
+            f.write(t.replace("\n", " ") + "\n")
+    for name, path in (("vocab_spm.gguf", spm), ("tiny_q8_0.gguf", os.path.join(GOLD, "tiny_q8_0.gguf"))):
+        r = subprocess.run([exe, "tok", path, txt], capture_output=True, check=True)
+        lines = r.stdout.decode().split("\n")[:len(TEXTS)]
+        cases = []
+        for t, l in zip(TEXTS, lines):
+            ids = [int(x) for x in l.split()]
+            d = subprocess.run([exe, "detok", path] + [str(i) for i in ids], capture_output=True, check=True).stdout
+            cases.append({"text": t.replace("\n", " "), "ids": ids, "detok_hex": d.hex()})
+        out["tokenizer"][name] = cases
+    rng = np.random.Generator(np.random.Philox(key=[SEED, 4242]))
+    logits = (rng.standard_normal(512) * 2.5).astype(np.float32)
+    logits[[7, 99]] = logits.max() + 0.5          # an exact tie for the maximum: first index must win
+    lp = os.path.join(GOLD, "sampler_logits.f32")
+    logits.tofile(lp)
+    for cfg in ({"temperature": 0.7, "top_k": 40, "top_p": 0.9, "repeat_penalty": 1.1, "repeat_window": 64, "seed": 42},
+                {"temperature": 1.0, "top_k": 0, "top_p": 1.0, "repeat_penalty": 1.0, "repeat_window": 64, "seed": 7},
+                {"temperature": 0.0, "top_k": 40, "top_p": 0.9, "repeat_penalty": 1.0, "repeat_window": 64, "seed": 1},
+                {"temperature": 0.5, "top_k": 5, "top_p": 0.5, "repeat_penalty": 1.3, "repeat_window": 4, "seed": 123456789012345}):
+        recent = [7, 99, 7, 3]
+        args = [exe, "sample", lp, "512", repr(cfg["temperature"]), str(cfg["top_k"]), repr(cfg["top_p"]),
+                repr(cfg["repeat_penalty"]), str(cfg["repeat_window"]), str(cfg["seed"]), "24"] + [str(t) for t in recent]
+        r = subprocess.run(args, capture_output=True, check=True)
+        out["sampler"].append({"cfg": cfg, "recent": recent, "draws": [int(x) for x in r.stdout.split()]})
+    with open(os.path.join(GOLD, "host_logic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("host logic:", {k: len(v) for k, v in out["tokenizer"].items()}, len(out["sampler"]), "sampler configs")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     golden_dequant()
     golden_logits()
+    golden_host_logic()
