@@ -71,6 +71,12 @@ int  nt_engine_last_stats(nt_engine_t e, nt_stats* out);
 int  nt_engine_forward(nt_engine_t e, const int* tokens, int n, int start_pos, float* logits_out);
 /* one fused decode step for `token` at position `pos` (device-resident state), logits copied to host */
 int  nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, float* logits_out);
+/* n greedy decode steps from (token, pos): exactly the timed inner loop of generate (device argmax, one host
+ * sync per token); generated ids to out[n] (may be NULL) */
+int  nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int* out);
+/* one fused token launched eagerly with a HIP event pair around each launch on the compute stream:
+ * ms3/calls3[0] quantised GEMV launches, [1] attention, [2] embedding + argmax + position */
+int  nt_engine_profile_token(nt_engine_t e, int token, int pos, float* ms3, int* calls3);
 int  nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int out_cap);   /* returns count */
 int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int out_cap);       /* returns bytes */
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */

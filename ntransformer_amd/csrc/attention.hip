@@ -27,7 +27,9 @@ __device__ __forceinline__ void unpack8(const u32x4 r, float (&f)[8]) {
 
 // rotation of one (x0, x1) pair, reference rotary.cu:46-60
 __device__ __forceinline__ void rope_pair(float& x0, float& x1, int pos, int pair_idx, int head_dim, float theta, float fscale) {
-    const float freq = 1.0f / powf(theta, (2.0f * pair_idx) / head_dim);
+    // powf evaluated in double and rounded once: reproduces a correctly-rounded powf (what IEEE libm gives the
+    // oracle); a 1-ulp slip in the frequency is a 4e-4 rad phase error at position 4095
+    const float freq = 1.0f / (float)pow((double)theta, (double)((2.0f * pair_idx) / head_dim));
     const float angle = pos * freq * fscale;
     const float c = cosf(angle), s = sinf(angle);
     const float a = x0, b = x1;

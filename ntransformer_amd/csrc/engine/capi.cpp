@@ -130,6 +130,21 @@ int nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, flo
     return m.copy_logits(logits_out);
 }
 
+int nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int* out) {
+    if (!e || !E(e)->loaded()) return NTK_E_NULL;
+    return E(e)->decode_greedy_steps(token, pos, n, out);
+}
+
+int nt_engine_profile_token(nt_engine_t e, int token, int pos, float* ms3, int* calls3) {
+    if (!e || !ms3 || !calls3 || !E(e)->loaded()) return NTK_E_NULL;
+    nt::Model& m = E(e)->model();
+    if (pos < 0 || pos >= m.config().max_seq_len) return NTK_E_SHAPE;
+    m.set_device_pos(pos);
+    const int rc = m.set_device_token(token);
+    if (rc != NTK_OK) return rc;
+    return m.profile_token(ms3, calls3);
+}
+
 int nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int cap) {
     if (!e || !text || !E(e)->loaded()) return NTK_E_NULL;
     const std::vector<int> ids = E(e)->tokenizer().encode(text, add_bos != 0);

@@ -109,6 +109,32 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
     return rc;
 }
 
+int Engine::decode_greedy_steps(int token, int pos, int n, int* out) {
+    if (!loaded_) return NTK_E_NULL;
+    if (pos < 0 || pos + n > model_.config().max_seq_len) return NTK_E_SHAPE;
+    int next = token;
+    if (opt_.fused) {
+        model_.set_device_pos(pos);
+        model_.set_device_token(next);
+        for (int i = 0; i < n; ++i) {
+            int rc = model_.decode_step_fused(true, opt_.graph);
+            if (rc == NTK_OK) rc = model_.sync();            // the host sees every token, like Engine::generate
+            if (rc != NTK_OK) return rc;
+            next = model_.host_token();
+            if (out) out[i] = next;
+        }
+        return NTK_OK;
+    }
+    std::vector<float> host(model_.config().vocab_size);
+    for (int i = 0; i < n; ++i) {
+        if (!model_.forward(&next, 1, pos + i)) return NTK_E_LAUNCH;
+        if (model_.copy_logits(host.data()) != NTK_OK) return NTK_E_LAUNCH;
+        next = Sampler::argmax(host.data(), (int)host.size());
+        if (out) out[i] = next;
+    }
+    return NTK_OK;
+}
+
 std::string Engine::generate(const std::string& prompt, const GenerateConfig& cfg, TokenCallback cb) {
     std::vector<int> tokens = tok_.encode(prompt, true);
     std::string out;

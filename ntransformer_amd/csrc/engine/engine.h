@@ -48,6 +48,8 @@ public:
     std::string generate(const std::string& prompt, const GenerateConfig& cfg, TokenCallback cb = nullptr);
     // the generate loop on token ids (no tokenizer, no printing): used by bench.py and the parity tests
     int generate_tokens(const std::vector<int>& prompt, const GenerateConfig& cfg, std::vector<int>& out, bool stop_at_eos);
+    // n greedy decode steps continuing from (token, pos): the timed inner loop of run(), nothing else.
+    int decode_greedy_steps(int token, int pos, int n, int* out);
     void chat(const GenerateConfig& cfg);
     void benchmark(const std::string& prompt, int n_tokens);
     void print_stats(const Stats& st) const;

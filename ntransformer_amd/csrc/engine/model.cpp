@@ -301,6 +301,13 @@ int Model::enqueue_token(bool greedy) {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     void* s = stream_;
+    // profiling hook: an event pair around one launch (only inside profile_token(), never while capturing)
+    auto mark = [&](int cls, bool begin) {
+        if (!prof_) return;
+        void* e = ntk_event_create();
+        ntk_event_record(e, s);
+        if (begin) prof_->push_back({cls, e, nullptr}); else prof_->back().b = e;
+    };
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
     float* q_buf = workspace_;
@@ -339,7 +346,9 @@ int Model::enqueue_token(bool greedy) {
                 segs[m++] = {ws[b]->ptr, ys[b], (int)ws[b]->out_f, ws[b]->dtype};
                 done[b] = true;
             }
+            mark(0, true);
             NT_TRY(ntk_gemv_fused(segs, m, x, (int)w.in_f, nw, cfg_.norm_eps, resid, 0, s));
+            mark(0, false);
         }
         return NTK_OK;
     };
@@ -349,7 +358,9 @@ int Model::enqueue_token(bool greedy) {
         return project(ws, ys, 1, x, norm, resid);
     };
 
+    mark(2, true);
     const int est = ntk_embed_rows(hidden_, token_embd_.ptr, d_token_, 1, H, token_embd_.dtype, s);
+    mark(2, false);
     if (est != NTK_OK && est != NTK_E_DTYPE) return est;
     for (int i = 0; i < cfg_.n_layers; ++i) {
         const LayerWeights& L = layers_[i];
@@ -360,12 +371,16 @@ int Model::enqueue_token(bool greedy) {
             float* ys[3] = {q_buf, k_buf, v_buf};
             NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
         }
+        mark(1, true);
         NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, nh, nkv, hd, cfg_.max_seq_len, scale,
                                           cfg_.rope_theta, cfg_.rope_freq_scale, s));
+        mark(1, false);
         NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
             ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
+            mark(0, true);
             NT_TRY(ntk_gemv_fused(segs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s));
+            mark(0, false);
         } else {
             const DevTensor* ws[2] = {&L.w_gate, &L.w_up};
             float* ys[2] = {gate_buf, up_buf};
@@ -375,8 +390,10 @@ int Model::enqueue_token(bool greedy) {
         NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_));
     }
     NT_TRY(project1(output_, logits_, hidden_, &output_norm_, nullptr));
+    mark(2, true);
     if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
     NT_TRY(ntk_advance_pos(d_pos_, s));
+    mark(2, false);
     return NTK_OK;
 }
 
@@ -397,6 +414,23 @@ int Model::decode_step_fused(bool greedy, bool use_graph) {
         slot = reinterpret_cast<ihipGraphExec_t*>(ex);
     }
     return hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(slot), st) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+
+int Model::profile_token(float ms[3], int calls[3]) {
+    std::vector<Timed> rec;
+    rec.reserve(1024);
+    prof_ = &rec;
+    int rc = enqueue_token(true);
+    prof_ = nullptr;
+    if (rc == NTK_OK) rc = ntk_stream_synchronize(stream_);
+    for (int c = 0; c < 3; ++c) { ms[c] = 0.0f; calls[c] = 0; }
+    for (auto& t : rec) {
+        float m = 0.0f;
+        if (t.a && t.b && ntk_event_elapsed_ms(t.a, t.b, &m) == NTK_OK) { ms[t.cls] += m; ++calls[t.cls]; }
+        if (t.a) ntk_event_destroy(t.a);
+        if (t.b) ntk_event_destroy(t.b);
+    }
+    return rc;
 }
 
 }  // namespace nt

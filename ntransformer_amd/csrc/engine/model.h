@@ -59,6 +59,9 @@ public:
     // algorithmic bytes one decode token must move at position `pos`
     uint64_t bytes_per_token(int pos) const;
     void set_fuse(bool on) { fuse_ = on; }
+    // One fused token launched eagerly with a HIP event pair around every launch on the compute stream.
+    // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos).
+    int profile_token(float ms[3], int calls[3]);
     void* stream() const { return stream_; }
 
 private:
@@ -93,6 +96,8 @@ private:
     float* argmax_scratch_ = nullptr;
     void* stream_ = nullptr;
     bool fuse_ = true;
+    struct Timed { int cls; void* a; void* b; };
+    std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs
     ihipGraphExec_t* graph_greedy_ = nullptr;
     ihipGraphExec_t* graph_logits_ = nullptr;
 };

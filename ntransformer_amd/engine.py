@@ -1,0 +1,201 @@
+"""Python view of the engine C API (include/ntransformer.h): the reference's nt_engine_* surface plus the
+extensions the tests and bench.py use.  Mirrors reference src/inference/engine.h (Engine::load / generate / Stats)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+class GenParams(C.Structure):
+    _fields_ = [("max_tokens", C.c_int), ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float),
+                ("repeat_penalty", C.c_float), ("repeat_window", C.c_int), ("seed", C.c_uint64), ("stop_at_eos", C.c_int)]
+
+
+class CStats(C.Structure):
+    _fields_ = [("prompt_tokens", C.c_int), ("gen_tokens", C.c_int), ("prefill_ms", C.c_float), ("decode_ms", C.c_float),
+                ("decode_tok_s", C.c_float)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("inter", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("kv_heads", C.c_int),
+                ("vocab", C.c_int), ("ctx", C.c_int), ("eps", C.c_float), ("theta", C.c_float), ("bos", C.c_int),
+                ("eos", C.c_int), ("mix", C.c_char_p), ("seed", C.c_uint64)]
+
+
+PRESETS = {
+    "tiny": dict(hidden=256, inter=512, layers=2, heads=4, kv_heads=2, vocab=512, ctx=256, bos=256, eos=257),
+    "small": dict(hidden=1024, inter=2048, layers=4, heads=8, kv_heads=2, vocab=2048, ctx=2048, bos=256, eos=257),
+    "8b": dict(hidden=4096, inter=14336, layers=32, heads=32, kv_heads=8, vocab=128256, ctx=131072, bos=128000, eos=128009),
+    "70b": dict(hidden=8192, inter=28672, layers=80, heads=64, kv_heads=8, vocab=128256, ctx=131072, bos=128000, eos=128009),
+}
+
+
+def synth_spec(preset: str, mix: str = "Q8_0", seed: int = 20260925, layers: Optional[int] = None) -> SynthSpec:
+    p = dict(PRESETS[preset])
+    if layers is not None:
+        p["layers"] = layers
+    return SynthSpec(p["hidden"], p["inter"], p["layers"], p["heads"], p["kv_heads"], p["vocab"], p["ctx"], 1e-5, 500000.0,
+                     p["bos"], p["eos"], mix.encode(), seed)
+
+
+def _bind():
+    L = _lib.lib()
+    if getattr(L, "_engine_bound", False):
+        return L
+    vp, i, f = C.c_void_p, C.c_int, C.c_float
+    L.nt_engine_create.restype = vp
+    L.nt_engine_destroy.argtypes = [vp]
+    L.nt_engine_load.argtypes = [vp, C.c_char_p]
+    L.nt_engine_load_ex.argtypes = [vp, C.c_char_p, i]
+    L.nt_engine_load_synthetic.argtypes = [vp, C.POINTER(SynthSpec), i]
+    L.nt_engine_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.nt_engine_last_error.argtypes = [vp]
+    L.nt_engine_last_error.restype = C.c_char_p
+    L.nt_engine_generate.argtypes = [vp, C.c_char_p, i, f, i, f]
+    L.nt_engine_generate.restype = vp
+    L.nt_free.argtypes = [vp]
+    for n in ("vocab_size", "n_layers", "hidden_size", "max_context"):
+        getattr(L, "nt_engine_" + n).argtypes = [vp]
+    L.nt_gen_params_default.argtypes = [C.POINTER(GenParams)]
+    L.nt_engine_generate_tokens.argtypes = [vp, C.POINTER(i), i, C.POINTER(GenParams), C.POINTER(i), i]
+    L.nt_engine_last_stats.argtypes = [vp, C.POINTER(CStats)]
+    L.nt_engine_forward.argtypes = [vp, C.POINTER(i), i, i, vp]
+    L.nt_engine_decode_fused.argtypes = [vp, i, i, i, vp]
+    L.nt_engine_tokenize.argtypes = [vp, C.c_char_p, i, C.POINTER(i), i]
+    L.nt_engine_detokenize.argtypes = [vp, C.POINTER(i), i, C.c_char_p, i]
+    L.nt_engine_bytes_per_token.argtypes = [vp, i]
+    L.nt_engine_bytes_per_token.restype = C.c_uint64
+    L.nt_engine_weight_bytes.argtypes = [vp]
+    L.nt_engine_weight_bytes.restype = C.c_uint64
+    L.nt_synth_write_gguf.argtypes = [C.c_char_p, C.POINTER(SynthSpec), i]
+    L.nt_synth_tensor.argtypes = [C.POINTER(SynthSpec), C.c_char_p, vp, C.c_size_t, i]
+    L.nt_synth_tensor.restype = C.c_int64
+    L.nt_engine_decode_greedy_steps.argtypes = [vp, i, i, i, C.POINTER(i)]
+    L.nt_engine_profile_token.argtypes = [vp, i, i, C.POINTER(f), C.POINTER(i)]
+    L._engine_bound = True
+    return L
+
+
+@dataclass
+class Stats:
+    prompt_tokens: int
+    gen_tokens: int
+    prefill_ms: float
+    decode_ms: float
+    decode_tok_s: float
+
+
+class Engine:
+    def __init__(self):
+        self.L = _bind()
+        self.h = self.L.nt_engine_create()
+        if not self.h:
+            raise MemoryError("nt_engine_create")
+
+    def close(self):
+        if self.h:
+            self.L.nt_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st, what):
+        if st != 0:
+            raise _lib.NtkError(st, "%s: %s" % (what, (self.L.nt_engine_last_error(self.h) or b"").decode()))
+
+    def load(self, path: str, max_context: int = 4096):
+        self._check(self.L.nt_engine_load_ex(self.h, path.encode(), max_context), "load")
+
+    def load_synthetic(self, spec: SynthSpec, max_context: int = 4096):
+        self._spec = spec
+        self._check(self.L.nt_engine_load_synthetic(self.h, C.byref(spec), max_context), "load_synthetic")
+
+    def set_option(self, key: str, value) -> None:
+        self._check(self.L.nt_engine_set_option(self.h, key.encode(), str(int(value)).encode()), "set_option " + key)
+
+    @property
+    def vocab_size(self): return self.L.nt_engine_vocab_size(self.h)
+    @property
+    def n_layers(self): return self.L.nt_engine_n_layers(self.h)
+    @property
+    def hidden_size(self): return self.L.nt_engine_hidden_size(self.h)
+
+    def forward(self, tokens: Sequence[int], start_pos: int) -> np.ndarray:
+        out = np.empty(self.vocab_size, np.float32)
+        arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
+        self._check(self.L.nt_engine_forward(self.h, arr, len(tokens), start_pos, out.ctypes.data_as(C.c_void_p)), "forward")
+        return out
+
+    def decode_fused(self, token: int, pos: int, graph: bool = False) -> np.ndarray:
+        out = np.empty(self.vocab_size, np.float32)
+        self._check(self.L.nt_engine_decode_fused(self.h, int(token), pos, int(graph), out.ctypes.data_as(C.c_void_p)), "decode_fused")
+        return out
+
+    def generate_tokens(self, prompt: Sequence[int], max_tokens: int, temperature: float = 0.0, top_k: int = 40,
+                        top_p: float = 0.9, repeat_penalty: float = 1.0, repeat_window: int = 64, seed: int = 42,
+                        stop_at_eos: bool = True) -> List[int]:
+        p = GenParams(max_tokens, temperature, top_k, top_p, repeat_penalty, repeat_window, seed, int(stop_at_eos))
+        arr = (C.c_int * len(prompt))(*[int(t) for t in prompt])
+        out = (C.c_int * max(max_tokens, 1))()
+        n = self.L.nt_engine_generate_tokens(self.h, arr, len(prompt), C.byref(p), out, max_tokens)
+        if n < 0:
+            self._check(n, "generate_tokens")
+        return list(out[:n])
+
+    def generate(self, prompt: str, max_tokens: int, temperature: float = 0.7, top_k: int = 40, top_p: float = 0.9) -> str:
+        r = self.L.nt_engine_generate(self.h, prompt.encode(), max_tokens, temperature, top_k, top_p)
+        if not r:
+            raise _lib.NtkError(-3, "generate")
+        s = C.string_at(r).decode("utf-8", "replace")
+        self.L.nt_free(r)
+        return s
+
+    def decode_greedy_steps(self, token: int, pos: int, n: int) -> List[int]:
+        out = (C.c_int * max(n, 1))()
+        self._check(self.L.nt_engine_decode_greedy_steps(self.h, int(token), pos, n, out), "decode_greedy_steps")
+        return list(out[:n])
+
+    def profile_token(self, token: int, pos: int):
+        ms, calls = (C.c_float * 3)(), (C.c_int * 3)()
+        self._check(self.L.nt_engine_profile_token(self.h, int(token), pos, ms, calls), "profile_token")
+        return list(ms), list(calls)
+
+    def stats(self) -> Stats:
+        s = CStats()
+        self.L.nt_engine_last_stats(self.h, C.byref(s))
+        return Stats(s.prompt_tokens, s.gen_tokens, s.prefill_ms, s.decode_ms, s.decode_tok_s)
+
+    def bytes_per_token(self, pos: int = 0) -> int:
+        return int(self.L.nt_engine_bytes_per_token(self.h, pos))
+
+    def weight_bytes(self) -> int:
+        return int(self.L.nt_engine_weight_bytes(self.h))
+
+    def tokenize(self, text: str, add_bos: bool = True) -> List[int]:
+        out = (C.c_int * 4096)()
+        n = self.L.nt_engine_tokenize(self.h, text.encode(), int(add_bos), out, 4096)
+        return list(out[:n])
+
+
+def synth_write_gguf(path: str, spec: SynthSpec, nthreads: int = 0) -> None:
+    check(_bind().nt_synth_write_gguf(path.encode(), C.byref(spec), nthreads), "synth_write_gguf")
+
+
+def synth_tensor(spec: SynthSpec, name: str, nthreads: int = 0) -> np.ndarray:
+    L = _bind()
+    n = L.nt_synth_tensor(C.byref(spec), name.encode(), None, 0, nthreads)
+    if n < 0:
+        raise _lib.NtkError(int(n), "synth_tensor " + name)
+    buf = np.empty(n, np.uint8)
+    L.nt_synth_tensor(C.byref(spec), name.encode(), buf.ctypes.data_as(C.c_void_p), n, nthreads)
+    return buf

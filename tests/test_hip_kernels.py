@@ -1,0 +1,399 @@
+"""GPU parity tests for the operator surface: every ntk_* launcher against the oracle (the CPU restatement of
+the reference kernel it replaces) on the same seeded inputs, through the C ABI.  Tolerances are stated per
+test; integer/byte results (F16 cache contents from F32, embedding rows, argmax) must be bit-exact.
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from kat_vectors import KATS
+from ntransformer_amd import gguf as G
+from ntransformer_amd import ops
+from ntransformer_amd.ops import DeviceBuffer as DB
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+QUANT = {"Q8_0": G.GGML_Q8_0, "Q4_0": G.GGML_Q4_0, "Q4_K": G.GGML_Q4_K, "Q5_K": G.GGML_Q5_K, "Q6_K": G.GGML_Q6_K}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    ops.init(0)
+    yield
+    ops.synchronize()
+
+
+def rng(seed):
+    return np.random.Generator(np.random.Philox(key=[20260925, seed]))
+
+
+def gemv_gpu(Wraw, x, out_f, in_f, dt, w_offset=0):
+    """ntk_gemv with W placed `w_offset` bytes into its allocation (exercises the 2-byte-aligned path)."""
+    Wd = DB(Wraw.nbytes + w_offset + 64)
+    Wd.upload(Wraw, w_offset)
+    xd = DB.from_numpy(x.astype(np.float32))
+    yd = DB.from_numpy(np.full(out_f, np.nan, np.float32))   # poisoned output
+    ops.launch_gemv(yd, Wd.at(w_offset), xd, out_f, in_f, dt)
+    ops.synchronize()
+    return yd.numpy(np.float32)
+
+
+def tol_for(y, in_f):
+    # F32 accumulation in a different association order than the oracle: error ~ eps * sqrt(in) * |terms|
+    return 4e-6 * np.sqrt(in_f) * max(1.0, float(np.abs(y).max()))
+
+
+# ------------------------------------------------------------------------------- reference KATs
+@pytest.mark.parametrize("name", sorted(KATS))
+def test_reference_kats_on_gpu(name):
+    k = KATS[name]
+    y = gemv_gpu(np.ascontiguousarray(k["W"]).view(np.uint8), k["x"], k["out"], k["in"], k["dtype"])
+    assert np.allclose(y, k["expect"], atol=k["tol"], rtol=0), (name, y)
+
+
+def test_reference_silu_rmsnorm_kats_on_gpu():
+    g = DB.from_numpy(np.array([0.0, 1.0, -1.0, 2.0], np.float32))
+    u = DB.from_numpy(np.ones(4, np.float32))
+    ops.launch_silu_mul(g, g, u, 4)                      # in place, as reference ffn.cpp:127
+    assert np.allclose(g.numpy(), [0.0, 0.731, -0.269, 1.762], atol=0.01)
+    x = DB.from_numpy(np.array([1, 2, 3, 4], np.float32))
+    w = DB.from_numpy(np.ones(4, np.float32))
+    ops.launch_rmsnorm(x, x, w, 1, 4, 1e-5)              # in place, as reference transformer.cpp:659
+    assert np.allclose(x.numpy(), np.array([1, 2, 3, 4]) / np.sqrt(7.5 + 1e-5), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------- GEMV vs oracle
+SHAPES = [  # (out, in): tiny, partial slices, every Llama-3.1 8B / 70B (out,in) class (row-trimmed where huge)
+    (3, 256), (64, 512), (257, 1024), (129, 2048), (512, 4096), (1024, 4096), (96, 8192), (515, 14336), (130, 28672),
+]
+
+
+@pytest.mark.parametrize("qname", sorted(QUANT))
+@pytest.mark.parametrize("out_f,in_f", SHAPES)
+def test_gemv_matches_oracle(qname, out_f, in_f):
+    gt = QUANT[qname]
+    r = rng(out_f * 7 + in_f + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    dt = G.GGML_TO_DT[gt]
+    ref = O.gemv(W, x, out_f, in_f, dt)
+    y = gemv_gpu(W, x, out_f, in_f, dt)
+    assert np.isfinite(y).all()
+    assert np.abs(y - ref).max() <= tol_for(ref, in_f), np.abs(y - ref).max()
+
+
+@pytest.mark.parametrize("qname", sorted(QUANT))
+@pytest.mark.parametrize("off", [2, 6, 14])
+def test_gemv_unaligned_weights(qname, off):
+    gt = QUANT[qname]
+    out_f, in_f = 37, 1024
+    r = rng(off + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    dt = G.GGML_TO_DT[gt]
+    ref = O.gemv(W, x, out_f, in_f, dt)
+    y = gemv_gpu(W, x, out_f, in_f, dt, w_offset=off)
+    assert np.abs(y - ref).max() <= tol_for(ref, in_f)
+
+
+@pytest.mark.parametrize("gt,in_f", [(G.GGML_F32, 3), (G.GGML_F32, 1000), (G.GGML_F16, 1000), (G.GGML_F16, 4096), (G.GGML_F32, 4096)])
+def test_gemv_dense(gt, in_f):
+    out_f = 45
+    r = rng(in_f + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    ref = O.gemv(W, x, out_f, in_f, G.GGML_TO_DT[gt])
+    y = gemv_gpu(W, x, out_f, in_f, G.GGML_TO_DT[gt])
+    assert np.abs(y - ref).max() <= tol_for(ref, in_f)
+
+
+def test_gemv_add_f16():
+    out_f, in_f = 300, 64          # the reference's delta "U . t" shape class
+    r = rng(5)
+    W = np.frombuffer(G.synth_tensor(r, G.GGML_F16, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    y0 = r.standard_normal(out_f).astype(np.float32)
+    ref = O.gemv_add(y0, W, x, out_f, in_f, G.DT_F16)
+    Wd, xd, yd = DB.from_numpy(W), DB.from_numpy(x), DB.from_numpy(y0)
+    ops.launch_gemv_add(yd, Wd, xd, out_f, in_f, G.DT_F16)
+    assert np.abs(yd.numpy() - ref).max() <= 1e-5
+    with pytest.raises(Exception):
+        ops.launch_gemv_add(yd, Wd, xd, out_f, in_f, G.DT_Q8_0)      # reference gemm.cu:866-868: F16 only
+
+
+def test_gemv_rejects_bad_arguments():
+    xd, yd = DB.zeros(4096 * 4), DB.zeros(64 * 4)
+    Wd = DB.zeros(1 << 16)
+    from ntransformer_amd import _lib
+    L = _lib.lib()
+    assert L.ntk_gemv(yd.ptr, Wd.ptr, xd.ptr, 4, 100, G.DT_Q8_0, None) == -2      # in not a multiple of the block
+    assert L.ntk_gemv(yd.ptr, Wd.ptr, xd.ptr, 4, 128, 7, None) == -1               # Q2_K: unsupported (gemm.cu:801-803)
+    assert L.ntk_gemv(None, Wd.ptr, xd.ptr, 4, 128, G.DT_Q8_0, None) == -5
+    assert L.ntk_gemv(yd.ptr, Wd.ptr + 1, xd.ptr, 4, 256, G.DT_Q8_0, None) == -4   # odd address
+    assert L.ntk_gemv(yd.ptr, Wd.ptr, xd.ptr, 0, 256, G.DT_Q8_0, None) == 0        # empty is fine
+
+
+def test_gemv_full_size_linearity_and_lm_head():
+    """Full 8B shapes: the LM head (128256 x 4096 Q8_0) against the oracle, and W(ax+by) = aWx + bWy on
+    the 14336-wide down projection (size-independent property, no oracle involved)."""
+    r = rng(11)
+    out_f, in_f = 128256, 4096
+    W = np.frombuffer(G.synth_tensor(r, G.GGML_Q8_0, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    y = gemv_gpu(W, x, out_f, in_f, G.DT_Q8_0)
+    ref = O.gemv(W, x, out_f, in_f, G.DT_Q8_0)
+    assert np.abs(y - ref).max() <= tol_for(ref, in_f)
+    out_f, in_f = 4096, 14336
+    W = np.frombuffer(G.synth_tensor(r, G.GGML_Q6_K, out_f, in_f), np.uint8)
+    a, b = r.standard_normal(in_f).astype(np.float32), r.standard_normal(in_f).astype(np.float32)
+    ya, yb = gemv_gpu(W, a, out_f, in_f, G.DT_Q6_K), gemv_gpu(W, b, out_f, in_f, G.DT_Q6_K)
+    yc = gemv_gpu(W, (2 * a - 3 * b).astype(np.float32), out_f, in_f, G.DT_Q6_K)
+    assert np.abs(yc - (2 * ya - 3 * yb)).max() <= 2e-4 * max(1.0, np.abs(yc).max())
+
+
+# ------------------------------------------------------------------------------- fused GEMV
+@pytest.mark.parametrize("qname", sorted(QUANT))
+@pytest.mark.parametrize("in_f,rows", [(256, (64, 32, 32)), (4096, (512, 128, 128)), (8192, (256, 64, 64))])
+def test_gemv_fused_norm_qkv(qname, in_f, rows):
+    gt, dt = QUANT[qname], G.GGML_TO_DT[QUANT[qname]]
+    r = rng(in_f + gt + 100)
+    x = (r.standard_normal(in_f) * 3).astype(np.float32)
+    nw = (1 + 0.05 * r.uniform(-1, 1, in_f)).astype(np.float32)
+    Ws = [np.frombuffer(G.synth_tensor(r, gt, n, in_f), np.uint8) for n in rows]
+    xn = O.rmsnorm(x, nw, 1e-5)
+    refs = [O.gemv(W, xn, n, in_f, dt) for W, n in zip(Ws, rows)]
+    xd, nd = DB.from_numpy(x), DB.from_numpy(nw)
+    Wd = [DB.from_numpy(W) for W in Ws]
+    yd = [DB.from_numpy(np.full(n, np.nan, np.float32)) for n in rows]
+    ops.gemv_fused([(Wd[i], yd[i], rows[i], dt) for i in range(3)], xd, in_f, norm_w=nd, eps=1e-5)
+    ops.synchronize()
+    for i in range(3):
+        assert np.abs(yd[i].numpy() - refs[i]).max() <= 2 * tol_for(refs[i], in_f)
+
+
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("in_f,out_f", [(512, 256), (4096, 4096), (14336, 4096), (28672, 1024)])
+def test_gemv_fused_residual_in_place(qname, in_f, out_f):
+    gt, dt = QUANT[qname], G.GGML_TO_DT[QUANT[qname]]
+    r = rng(in_f + out_f + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    h = r.standard_normal(out_f).astype(np.float32)
+    ref = h + O.gemv(W, x, out_f, in_f, dt)              # launch_gemv + launch_add_inplace
+    Wd, xd, hd = DB.from_numpy(W), DB.from_numpy(x), DB.from_numpy(h)
+    ops.gemv_fused([(Wd, hd, out_f, dt)], xd, in_f, resid=hd)
+    ops.synchronize()
+    assert np.abs(hd.numpy() - ref).max() <= tol_for(ref, in_f)
+
+
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q4_0"])
+@pytest.mark.parametrize("in_f,inter", [(256, 512), (4096, 1792), (8192, 515)])
+def test_gemv_fused_norm_gate_up_silu(qname, in_f, inter):
+    gt, dt = QUANT[qname], G.GGML_TO_DT[QUANT[qname]]
+    r = rng(in_f + inter + gt)
+    x = r.standard_normal(in_f).astype(np.float32)
+    nw = (1 + 0.05 * r.uniform(-1, 1, in_f)).astype(np.float32)
+    Wg = np.frombuffer(G.synth_tensor(r, gt, inter, in_f), np.uint8)
+    Wu = np.frombuffer(G.synth_tensor(r, gt, inter, in_f), np.uint8)
+    xn = O.rmsnorm(x, nw, 1e-5)
+    ref = O.silu_mul(O.gemv(Wg, xn, inter, in_f, dt), O.gemv(Wu, xn, inter, in_f, dt))
+    xd, nd, gd, ud = DB.from_numpy(x), DB.from_numpy(nw), DB.from_numpy(Wg), DB.from_numpy(Wu)
+    od, scratch = DB.from_numpy(np.full(inter, np.nan, np.float32)), DB.zeros(inter * 4)
+    ops.gemv_fused([(gd, od, inter, dt), (ud, scratch, inter, dt)], xd, in_f, norm_w=nd, eps=1e-5, silu_pair=True)
+    ops.synchronize()
+    assert np.abs(od.numpy() - ref).max() <= 4 * tol_for(ref, in_f)
+
+
+# ------------------------------------------------------------------------------- norm / rope / kv / attention
+@pytest.mark.parametrize("batch,hidden", [(1, 256), (1, 4096), (3, 8192), (5, 1000)])
+def test_rmsnorm(batch, hidden):
+    r = rng(hidden)
+    x = (r.standard_normal((batch, hidden)) * 2).astype(np.float32)
+    w = (1 + 0.1 * r.standard_normal(hidden)).astype(np.float32)
+    ref = O.rmsnorm(x, w, 1e-5)
+    xd, wd, od = DB.from_numpy(x), DB.from_numpy(w), DB.zeros(x.nbytes)
+    ops.launch_rmsnorm(od, xd, wd, batch, hidden, 1e-5)
+    assert np.abs(od.numpy().reshape(batch, hidden) - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-6
+    hd_ = DB.zeros(x.size * 2)
+    ops.launch_rmsnorm_f16(hd_, xd, wd, batch, hidden, 1e-5)
+    got = hd_.numpy(np.float16).astype(np.float32).reshape(batch, hidden)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("positions", [[0], [1], [4095], [3, 4, 5, 6, 100, 2047]])
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_rope(positions, interleaved):
+    nh, nkv, hd = 8, 2, 128
+    T = len(positions)
+    r = rng(T + 31 * interleaved + positions[0])
+    q = r.standard_normal(T * nh * hd).astype(np.float32)
+    k = r.standard_normal(T * nkv * hd).astype(np.float32)
+    rq, rk = O.rope(q, k, positions, nh, nkv, hd, 500000.0, 1.0, interleaved)
+    qd, kd, pd = DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(np.array(positions, np.int32))
+    ops.launch_rope(qd, kd, pd, 1, T, nh, nkv, hd, 500000.0, 1.0, interleaved)
+    # same F32 angle on both sides (the kernel rounds pow once, like libm); device sinf/cosf are within 2 ulp
+    assert np.abs(qd.numpy() - rq).max() <= 1e-5
+    assert np.abs(kd.numpy() - rk).max() <= 1e-5
+
+
+def test_copy_to_kv_cache_is_bit_exact():
+    nkv, hd, max_seq, T, start = 2, 128, 16, 5, 9
+    r = rng(77)
+    k = (r.standard_normal(T * nkv * hd) * 10 ** r.uniform(-6, 4, T * nkv * hd)).astype(np.float32)
+    v = r.standard_normal(T * nkv * hd).astype(np.float32)
+    k[:4] = [65504.0, 65520.0, 1e-8, -0.0]
+    kc, vc = np.zeros(max_seq * nkv * hd, np.uint16), np.zeros(max_seq * nkv * hd, np.uint16)
+    O.copy_to_kv_cache(kc, vc, k, v, T, nkv, hd, start, max_seq)
+    kcd, vcd = DB.zeros(kc.nbytes), DB.zeros(vc.nbytes)
+    ops.launch_copy_to_kv_cache(kcd, vcd, DB.from_numpy(k), DB.from_numpy(v), T, nkv, hd, start, max_seq)
+    assert np.array_equal(kcd.numpy(np.uint16), kc) and np.array_equal(vcd.numpy(np.uint16), vc)
+    # positions past max_seq are dropped, not wrapped (reference attention.cu:336)
+    ops.launch_copy_to_kv_cache(kcd, vcd, DB.from_numpy(k), DB.from_numpy(v), T, nkv, hd, max_seq - 2, max_seq)
+    O.copy_to_kv_cache(kc, vc, k, v, T, nkv, hd, max_seq - 2, max_seq)
+    assert np.array_equal(kcd.numpy(np.uint16), kc)
+
+
+def make_cache(r, seq, max_seq, nkv, hd):
+    kc = np.zeros(max_seq * nkv * hd, np.uint16)
+    vc = np.zeros(max_seq * nkv * hd, np.uint16)
+    kc[: seq * nkv * hd] = r.standard_normal(seq * nkv * hd).astype(np.float16).view(np.uint16)
+    vc[: seq * nkv * hd] = r.standard_normal(seq * nkv * hd).astype(np.float16).view(np.uint16)
+    return kc, vc
+
+
+@pytest.mark.parametrize("seq", [1, 17, 140, 1025, 4096])
+@pytest.mark.parametrize("nh,nkv,hd", [(32, 8, 128), (4, 2, 64), (6, 3, 80)])
+def test_attention_decode(seq, nh, nkv, hd):
+    if seq > 1025 and hd != 128:
+        pytest.skip("long context only at the real head size")
+    r = rng(seq + nh + hd)
+    max_seq = max(seq, 32)
+    kc, vc = make_cache(r, seq, max_seq, nkv, hd)
+    q = r.standard_normal(nh * hd).astype(np.float32)
+    scale = float(1 / np.sqrt(hd))
+    ref = O.attention_decode(q, kc, vc, seq, nh, nkv, hd, max_seq, scale)
+    od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+    ops.launch_attention_decode(od, DB.from_numpy(q), DB.from_numpy(kc), DB.from_numpy(vc), seq, nh, nkv, hd, max_seq, scale)
+    assert np.abs(od.numpy() - ref).max() <= 2e-5
+
+
+@pytest.mark.parametrize("T,start", [(5, 0), (7, 3), (2, 130)])
+def test_attention_prefill(T, start):
+    nh, nkv, hd = 8, 2, 128
+    r = rng(T + start)
+    max_seq = 256
+    kc, vc = make_cache(r, start + T, max_seq, nkv, hd)
+    Q = r.standard_normal(T * nh * hd).astype(np.float32)
+    scale = float(1 / np.sqrt(hd))
+    ref = O.attention_prefill(Q, kc, vc, T, start, nh, nkv, hd, max_seq, scale)
+    od = DB.from_numpy(np.full(T * nh * hd, np.nan, np.float32))
+    ops.launch_attention_prefill(od, DB.from_numpy(Q), DB.from_numpy(kc), DB.from_numpy(vc), T, start, nh, nkv, hd, max_seq, scale)
+    assert np.abs(od.numpy() - ref).max() <= 2e-5
+
+
+@pytest.mark.parametrize("pos", [0, 1, 63, 300])
+@pytest.mark.parametrize("nh,nkv,hd", [(32, 8, 128), (4, 2, 64)])
+def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd):
+    r = rng(pos + nh)
+    max_seq = 512
+    kc, vc = make_cache(r, pos, max_seq, nkv, hd)
+    q = r.standard_normal(nh * hd).astype(np.float32)
+    k = r.standard_normal(nkv * hd).astype(np.float32)
+    v = r.standard_normal(nkv * hd).astype(np.float32)
+    scale, theta = float(1 / np.sqrt(hd)), 500000.0
+    # the reference's three launches (attention.cpp:165-190) on the oracle
+    rq, rk = O.rope(q, k, [pos], nh, nkv, hd, theta)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    O.copy_to_kv_cache(kc_ref, vc_ref, rk, v, 1, nkv, hd, pos, max_seq)
+    ref = O.attention_decode(rq, kc_ref, vc_ref, pos + 1, nh, nkv, hd, max_seq, scale)
+    kcd, vcd = DB.from_numpy(kc), DB.from_numpy(vc)
+    od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+    ops.attention_decode_fused(od, DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v), kcd, vcd,
+                               DB.from_numpy(np.array([pos], np.int32)), nh, nkv, hd, max_seq, scale, theta)
+    assert np.abs(od.numpy() - ref).max() <= 3e-5
+    # the stored row: V bit-exact; K within one half-precision ulp (device vs glibc sin/cos)
+    assert np.array_equal(vcd.numpy(np.uint16), vc_ref)
+    got_k = kcd.numpy(np.uint16).view(np.float16).astype(np.float32)
+    want_k = kc_ref.view(np.float16).astype(np.float32)
+    assert np.abs(got_k - want_k).max() <= 2e-3 * max(1.0, np.abs(want_k).max())
+    assert np.array_equal(kcd.numpy(np.uint16)[: pos * nkv * hd], kc[: pos * nkv * hd])   # older rows untouched
+
+
+# ------------------------------------------------------------------------------- small ops
+def test_elementwise_and_reductions():
+    r = rng(3)
+    n = 10007
+    a, b = r.standard_normal(n).astype(np.float32), r.standard_normal(n).astype(np.float32)
+    ad, bd, od = DB.from_numpy(a), DB.from_numpy(b), DB.zeros(n * 4)
+    ops.launch_add(od, ad, bd, n)
+    assert np.array_equal(od.numpy(), a + b)
+    ops.launch_add_inplace(ad, bd, n)
+    assert np.array_equal(ad.numpy(), a + b)
+    ops.launch_copy(od, bd, n)
+    assert np.array_equal(od.numpy(), b)
+    ops.launch_add_bias(od, bd, n)
+    assert np.array_equal(od.numpy(), b + b)
+    res = DB.zeros(4)
+    ops.launch_cosine_similarity(res, DB.from_numpy(a), bd, n)
+    assert abs(res.numpy()[0] - O.cosine_similarity(a, b)) <= 1e-6
+    x = r.standard_normal((7, 333)).astype(np.float32)
+    e = np.exp(x - x.max(1, keepdims=True))
+    sd = DB.zeros(x.nbytes)
+    ops.launch_softmax(sd, DB.from_numpy(x), 7, 333)
+    assert np.abs(sd.numpy().reshape(7, 333) - e / e.sum(1, keepdims=True)).max() <= 1e-6
+    mask = (r.uniform(size=(7, 333)) > 0.3).astype(np.uint8)
+    mask[:, 0] = 1
+    em = e * mask
+    ops.launch_masked_softmax(sd, DB.from_numpy(x), DB.from_numpy(mask), 7, 333)
+    xm = np.where(mask > 0, x, -np.inf)
+    em = np.exp(xm - xm.max(1, keepdims=True))
+    assert np.abs(sd.numpy().reshape(7, 333) - em / em.sum(1, keepdims=True)).max() <= 1e-6
+    M, N, K = 9, 17, 33
+    A, Bm = r.standard_normal((M, K)).astype(np.float32), r.standard_normal((N, K)).astype(np.float32)
+    cd = DB.zeros(M * N * 4)
+    ops.launch_gemm_f32(cd, DB.from_numpy(A), DB.from_numpy(Bm), M, N, K)
+    assert np.abs(cd.numpy().reshape(M, N) - A @ Bm.T).max() <= 1e-4
+
+
+@pytest.mark.parametrize("gt", [G.GGML_F32, G.GGML_F16, G.GGML_Q8_0, G.GGML_Q4_0, G.GGML_Q4_K, G.GGML_Q6_K])
+def test_embed_rows_bit_exact(gt):
+    vocab, hidden = 50, 512
+    r = rng(gt + 1000)
+    table = np.frombuffer(G.synth_tensor(r, gt, vocab, hidden, sigma=20.0), np.uint8)
+    toks = np.array([0, 49, 7, 7, 23], np.int32)
+    dt = G.GGML_TO_DT[gt]
+    ref = np.stack([O.embed_row(table, int(t), hidden, dt) for t in toks])
+    od = DB.from_numpy(np.full(toks.size * hidden, np.nan, np.float32))
+    ops.embed_rows(od, DB.from_numpy(table), DB.from_numpy(toks), toks.size, hidden, dt)
+    assert np.array_equal(od.numpy().reshape(toks.size, hidden), ref)
+
+
+def test_embed_rows_q5_k_zero_fills_like_reference():
+    vocab, hidden = 8, 256
+    table = np.frombuffer(G.synth_tensor(rng(9), G.GGML_Q5_K, vocab, hidden), np.uint8)
+    od = DB.from_numpy(np.full(hidden, np.nan, np.float32))
+    st = ops.embed_rows(od, DB.from_numpy(table), DB.from_numpy(np.array([3], np.int32)), 1, hidden, G.DT_Q5_K, allow_unsupported=True)
+    assert st == -1 and not od.numpy().any()
+
+
+def test_argmax_first_maximum_and_advance_pos():
+    r = rng(1)
+    for n in (5, 512, 2048, 128256):
+        x = r.standard_normal(n).astype(np.float32)
+        a, b = sorted(r.choice(n, 2, replace=False))
+        x[[a, b]] = x.max() + 1.0                      # exact tie: the lower index wins (sampler.cpp:18-28)
+        tok, scratch = DB.zeros(64), DB.zeros(2 * 1024 * 4)
+        ops.argmax(DB.from_numpy(x), n, tok, scratch)
+        ops.synchronize()
+        assert tok.numpy(np.int32)[0] == a == int(np.argmax(x))
+    p = DB.from_numpy(np.array([41], np.int32))
+    ops.advance_pos(p)
+    ops.advance_pos(p)
+    ops.synchronize()
+    assert p.numpy(np.int32)[0] == 43
