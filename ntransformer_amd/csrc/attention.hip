@@ -250,7 +250,14 @@ static int launch_attention(float* out, const float* Q, const void* kc, const vo
     const uint16_t* k16 = static_cast<const uint16_t*>(kc);
     const uint16_t* v16 = static_cast<const uint16_t*>(vc);
     dim3 grid(nh, T), block(256);
-#define NTK_ATT(LPR_) hipLaunchKernelGGL(attention_kernel<LPR_>, grid, block, lds, st, out, Q, k16, v16, n_keys_base, causal, nh, nkv, hd, scale)
+    // more than 64 KiB of dynamic LDS (contexts beyond ~15K keys) must be opted into per kernel
+#define NTK_ATT(LPR_)                                                                                                   \
+    do {                                                                                                                \
+        if (lds > 64 * 1024)                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<LPR_>),                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL(attention_kernel<LPR_>, grid, block, lds, st, out, Q, k16, v16, n_keys_base, causal, nh, nkv, hd, scale); \
+    } while (0)
     if (aligned && hd == 128) NTK_ATT(16);
     else if (aligned && hd == 64) NTK_ATT(8);
     else if (aligned && hd == 256) NTK_ATT(32);
@@ -313,7 +320,14 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
     const bool aligned = (reinterpret_cast<uintptr_t>(k_cache) & 15) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 15) == 0;
     uint16_t* k16 = static_cast<uint16_t*>(k_cache);
     uint16_t* v16 = static_cast<uint16_t*>(v_cache);
-#define NTK_ATTF(LPR_) hipLaunchKernelGGL(ntk::attention_decode_fused_kernel<LPR_>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, k16, v16, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
+#define NTK_ATTF(LPR_)                                                                                                  \
+    do {                                                                                                                \
+        if (lds > 64 * 1024)                                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntk::attention_decode_fused_kernel<LPR_>),          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL(ntk::attention_decode_fused_kernel<LPR_>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, \
+                           k16, v16, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale);     \
+    } while (0)
     if (aligned && head_dim == 128) NTK_ATTF(16);
     else if (aligned && head_dim == 64) NTK_ATTF(8);
     else if (aligned && head_dim == 256) NTK_ATTF(32);
