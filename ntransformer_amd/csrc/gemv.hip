@@ -29,6 +29,13 @@ namespace ntk {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// 16-byte global load the compiler does not see in its s_waitcnt bookkeeping (base: uniform pointer, off: bytes)
+__device__ __forceinline__ u32x4 asm_load16(const void* base, unsigned off) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    return v;
+}
+
 constexpr int RB = 4;            // rows (items) per batch between cross-wave combines
 constexpr int XPITCH = 68;       // floats per 64-column lane row in the prologue LDS image (conflict-free b128)
 constexpr int MAX_SEG = 3;
@@ -66,6 +73,7 @@ struct GemvParams {
     const float* resid;
     int silu_pair;
     unsigned row_bytes;
+    int ablate;         // tuning ablations (env NTK_GEMV_ABLATE): 1 = skip the x prologue, 2 = skip the decode, 4 = skip LDS staging
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +248,7 @@ template <> struct Dot<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (bl
 //   [0, A)   prologue x (+ norm weight) image, afterwards nwaves * STAGE wave-private byte images
 //   [A, ..)  partial sums [2][rw][ns][RB] + 16 floats reduction scratch
 // ------------------------------------------------------------------------------------------------
-template <int DT>
+template <int DT, bool NORM, bool XFAST>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
@@ -253,11 +261,12 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     const int nwaves = p.ns * p.rw;
     const int s = wave % p.ns;        // column slice of this wave
     const int g = wave / p.ns;        // row group of this wave
-    const bool norm = p.norm_w != nullptr;
+    constexpr bool norm = NORM;   // compile-time: the norm-weight loads/stores must not sit behind a runtime branch
 
-    const size_t regionA = (size_t)std::max(nwaves * STAGE, (norm ? 2 : 1) * 64 * XPITCH * 4);
+    const size_t regionA = (size_t)std::max(nwaves * STAGE, p.ns * 64 * XPITCH * 4);
     float* part = reinterpret_cast<float*>(smem + regionA);
     float* red = part + 2 * p.rw * p.ns * RB;
+    const size_t lds_floats_total = regionA / 4 + (size_t)(2 * p.rw * p.ns * RB + 16 + 16);   // ... + red[16] + 16 spare
 
     // ---- item bookkeeping + first prefetch (issued before the prologue so HBM latency overlaps it) ----
     uint8_t* stage = smem + (size_t)wave * STAGE;
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     u32x4 pf[NL];
     auto issue = [&](int q) {
         int seg, row;
-        locate(q, seg, row);
+        if (n_my > 0) locate(q, seg, row); else { seg = 0; row = 0; }
         const size_t rel = (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + slice_byte0;
         const unsigned nbytes = (unsigned)(rel & 15) + slice_bytes;
         const unsigned last = (nbytes - 1u) & ~15u;
@@ -293,66 +302,106 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
             pf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + off));
         }
     };
-    if (n_my > 0 && slice_bytes > 0) issue(0);
 
     // ---- prologue: this lane's 64 activations into registers (through a padded LDS image: coalesced
     //      global reads, conflict-free ds_read_b128), optional RMSNorm (reference rmsnorm.cu:16-70) ----
     float xr[64];
     {
+        // The activations reach registers through a padded LDS image holding ALL slices: image row (sp*64 + l)
+        // = the 64 columns lane l of slice sp owns (pitch 68 floats: conflict-free ds_read_b128).
+        //   * x (and the norm weights) are requested BEFORE the first weight prefetch: a CU serves its memory
+        //     requests roughly in order, and x queued behind 80 KB of weight loads cost 3 us per launch;
+        //   * those loads are inline asm so that hipcc does not count them: the wait can then say exactly
+        //     "everything older than the NL prefetch loads has landed" (s_waitcnt vmcnt(NL)) -- left to the
+        //     compiler the image stores wait with vmcnt(0), i.e. for the first weight row from HBM;
+        //   * RMSNorm is applied by the thread that loaded the element (x * rms_inv * w, rmsnorm.cu:68) and the
+        //     image holds normalised values: the transposing read needs no second image and no extra registers
+        //     (a weight image made hipcc spill the in-flight prefetch registers to scratch).
         float* ximg = reinterpret_cast<float*>(smem);
-        float* wimg = ximg + 64 * XPITCH;
-        // pass 1 (NORM only): sum of squares over the whole row, every thread a strided share
-        float rms_inv = 1.0f;
-        if (norm) {
-            float ssq = 0.0f;
-            if (p.x_vec && (p.in & 3) == 0) {
-                for (int c = tid * 4; c < p.in; c += blockDim.x * 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(p.x + c);
-                    ssq = fmaf(v.x, v.x, ssq); ssq = fmaf(v.y, v.y, ssq);
-                    ssq = fmaf(v.z, v.z, ssq); ssq = fmaf(v.w, v.w, ssq);
-                }
-            } else {
-                for (int c = tid; c < p.in; c += blockDim.x) ssq = fmaf(p.x[c], p.x[c], ssq);
-            }
-            const float tot = block_sum(ssq, red);
-            rms_inv = 1.0f / sqrtf(tot / (float)p.in + p.eps);
-        }
-        // pass 2: slice by slice through the padded image; the owning waves pull their 64 columns
-        const int ncols_l = ncols;
-        for (int sp = 0; sp < p.ns; ++sp) {
-            const int c0 = sp * p.slice_cols;
-            const int len = min(p.slice_cols, p.in - c0);
-            __syncthreads();
-            if (p.x_vec && (len & 3) == 0) {
-                for (int c = tid * 4; c < len; c += blockDim.x * 4) {
-                    *reinterpret_cast<float4*>(ximg + (c >> 6) * XPITCH + (c & 63)) =
-                        *reinterpret_cast<const float4*>(p.x + c0 + c);
-                    if (norm)
-                        *reinterpret_cast<float4*>(wimg + (c >> 6) * XPITCH + (c & 63)) =
-                            *reinterpret_cast<const float4*>(p.norm_w + c0 + c);
-                }
-            } else {
-                for (int c = tid; c < len; c += blockDim.x) {
-                    ximg[(c >> 6) * XPITCH + (c & 63)] = p.x[c0 + c];
-                    if (norm) wimg[(c >> 6) * XPITCH + (c & 63)] = p.norm_w[c0 + c];
-                }
-            }
-            __syncthreads();
-            if (s == sp) {
+        auto img_index = [&](int c) {
+            const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
+            return (sp * 64 + (cc >> 6)) * XPITCH + (cc & 63);
+        };
+        constexpr int XIT = 8, WIT = 4;
+        const int step = (int)blockDim.x * 4;
+        const int dummy = (int)(lds_floats_total - 16);   // 16 spare floats at the end of the allocation
+        if constexpr (XFAST) {   // host guarantees: x (and norm_w) 16-byte aligned, in % 4 == 0, (!NORM || in <= WIT * step)
+            u32x4 xv[XIT], wv[WIT];
 #pragma unroll
-                for (int j = 0; j < 64; j += 4) {
-                    float4 v = *reinterpret_cast<const float4*>(ximg + lane * XPITCH + j);
-                    if (norm) {   // x * rms_inv * w, the reference's association (rmsnorm.cu:68)
-                        const float4 w = *reinterpret_cast<const float4*>(wimg + lane * XPITCH + j);
-                        v.x = v.x * rms_inv * w.x; v.y = v.y * rms_inv * w.y;
-                        v.z = v.z * rms_inv * w.z; v.w = v.w * rms_inv * w.w;
-                    }
-                    xr[j] = (j < ncols_l) ? v.x : 0.0f;
-                    xr[j + 1] = (j + 1 < ncols_l) ? v.y : 0.0f;
-                    xr[j + 2] = (j + 2 < ncols_l) ? v.z : 0.0f;
-                    xr[j + 3] = (j + 3 < ncols_l) ? v.w : 0.0f;
-                }
+            for (int i = 0; i < XIT; ++i) xv[i] = asm_load16(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
+            if constexpr (NORM) {
+#pragma unroll
+                for (int i = 0; i < WIT; ++i) wv[i] = asm_load16(p.norm_w, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
             }
+            issue(0);   // unconditional (a wave without rows re-reads row 0): keeps this block free of branches
+            asm volatile("s_waitcnt vmcnt(%c8)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]) : "i"(NL));
+            if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));   // older than the wait above: landed too
+            __builtin_amdgcn_sched_barrier(0);
+            float rms_inv = 1.0f;
+            if constexpr (NORM) {   // sum x^2 over the row: every column is loaded by exactly one thread (i < WIT covers the row)
+                float ssq = 0.0f;
+#pragma unroll
+                for (int i = 0; i < WIT; ++i) {
+                    const float m = (tid * 4 + i * step < p.in) ? 1.0f : 0.0f;
+                    const float x0 = __uint_as_float(xv[i].x), x1 = __uint_as_float(xv[i].y), x2 = __uint_as_float(xv[i].z), x3 = __uint_as_float(xv[i].w);
+                    ssq = fmaf(x0 * m, x0, ssq); ssq = fmaf(x1 * m, x1, ssq); ssq = fmaf(x2 * m, x2, ssq); ssq = fmaf(x3 * m, x3, ssq);
+                }
+                ssq = wave_sum(ssq);
+                if (lane == 0) red[wave] = ssq;
+                __syncthreads();
+                float tot = 0.0f;
+                for (int w = 0; w < nwaves; ++w) tot += red[w];
+                rms_inv = 1.0f / sqrtf(tot / (float)p.in + p.eps);   // rsqrtf(mean + eps), rmsnorm.cu:60-61
+            }
+#pragma unroll
+            for (int i = 0; i < XIT; ++i) {
+                const int c = tid * 4 + i * step;
+                float4 v = make_float4(__uint_as_float(xv[i].x), __uint_as_float(xv[i].y), __uint_as_float(xv[i].z), __uint_as_float(xv[i].w));
+                if constexpr (NORM) {
+                    if (i < WIT) {
+                        v.x = v.x * rms_inv * __uint_as_float(wv[i].x); v.y = v.y * rms_inv * __uint_as_float(wv[i].y);
+                        v.z = v.z * rms_inv * __uint_as_float(wv[i].z); v.w = v.w * rms_inv * __uint_as_float(wv[i].w);
+                    }
+                }
+                *reinterpret_cast<float4*>(ximg + (c < p.in ? img_index(c) : dummy)) = v;
+            }
+            if constexpr (!NORM) {   // columns beyond 8 * 4 * blockDim (28672-wide rows): the weights are already in flight
+                for (int c = XIT * step + tid * 4; c < p.in; c += step)
+                    *reinterpret_cast<float4*>(ximg + img_index(c)) = *reinterpret_cast<const float4*>(p.x + c);
+            }
+        } else {   // unaligned / odd sizes (and the NTK_GEMV_ABLATE=1 experiment): plain loops
+            if (n_my > 0) issue(0);
+            float rms_inv = 1.0f;
+            if (NORM && !(p.ablate & 1)) {
+                float ssq = 0.0f;
+                for (int c = tid; c < p.in; c += blockDim.x) ssq = fmaf(p.x[c], p.x[c], ssq);
+                ssq = wave_sum(ssq);
+                if (lane == 0) red[wave] = ssq;
+                __syncthreads();
+                float tot = 0.0f;
+                for (int w = 0; w < nwaves; ++w) tot += red[w];
+                rms_inv = 1.0f / sqrtf(tot / (float)p.in + p.eps);
+            }
+            if (!(p.ablate & 1)) {
+                for (int c = tid; c < p.in; c += blockDim.x)
+                    ximg[img_index(c)] = NORM ? p.x[c] * rms_inv * p.norm_w[c] : p.x[c];
+            }
+        }
+        __syncthreads();
+        const bool have_lo = ncols > 0, have_hi = ncols > 32;   // ncols is 0, 32 or 64: two masks, not 64 compares
+        const float* xrow = ximg + (s * 64 + lane) * XPITCH;
+#pragma unroll
+        for (int j = 0; j < 64; j += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xrow + j);
+            const bool have = j < 32 ? have_lo : have_hi;
+            xr[j] = have ? v.x : 0.0f;
+            xr[j + 1] = have ? v.y : 0.0f;
+            xr[j + 2] = have ? v.z : 0.0f;
+            xr[j + 3] = have ? v.w : 0.0f;
+        }
+        if (p.ablate & 1) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) xr[j] = 1.0f;
         }
         __syncthreads();   // LDS region A becomes the staging area
     }
@@ -400,10 +449,13 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
         const size_t rel = (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + slice_byte0;
         const int shift = (int)(rel & 15);
 #pragma unroll
-        for (int j = 0; j < NL; ++j) *reinterpret_cast<u32x4*>(stage + 16 * (lane + 64 * j)) = pf[j];
+        for (int j = 0; j < NL; ++j) {
+            if (p.ablate & 4) { asm volatile("" ::"v"(pf[j])); continue; }
+            *reinterpret_cast<u32x4*>(stage + 16 * (lane + 64 * j)) = pf[j];
+        }
         __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
         if (q + 1 < n_my) issue(q + 1);    // next row's bytes fly while this one is decoded
-        const float acc = Dot<DT>::run(stage, shift, lane, ncols, xr, sx16, sx32);
+        const float acc = (p.ablate & 2) ? xr[0] + (float)q : Dot<DT>::run(stage, shift, lane, ncols, xr, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
         const float tot = wave_sum(acc);
 
@@ -523,7 +575,10 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     p.slice_cols = ((in + p.ns - 1) / p.ns + align - 1) / align * align;
     if (p.ns > 8 || (long)(p.ns - 1) * p.slice_cols >= in) return NTK_E_SHAPE;   // in_features > 32768 not supported
     // waves per workgroup = ns * rw ~ 8: one x prologue feeds eight row streams
-    p.rw = p.ns == 1 ? 8 : (p.ns == 2 ? 4 : (p.ns <= 4 ? 2 : 1));
+    static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
+    static const int env_ablate = [] { const char* e = getenv("NTK_GEMV_ABLATE"); return e ? atoi(e) : 0; }();
+    p.rw = std::max(1, env_waves / p.ns);
+    p.ablate = env_ablate;
     const int nwaves = p.ns * p.rw;
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? 1 : 0;
@@ -541,9 +596,25 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     const long rows_per_group = (total + ngroups - 1) / ngroups;
     p.nbatch = (int)((rows_per_group * mats + RB - 1) / RB);
     constexpr int STAGE = F::NL * 1024 + 64;
-    const size_t regionA = (size_t)std::max(nwaves * STAGE, (norm_w ? 2 : 1) * 64 * XPITCH * 4);
-    const size_t lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16) * sizeof(float);
-    hipLaunchKernelGGL(gemv_quant_kernel<DT>, dim3(grid), dim3(64 * nwaves), lds, st, p);
+    const size_t regionA = (size_t)std::max(nwaves * STAGE, p.ns * 64 * XPITCH * 4);
+    const size_t lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
+    if (lds > 64 * 1024) {   // 28672-wide rows: the activation image alone is 119 KiB
+        static bool once = [] {
+            bool ok = true;
+            for (const void* f : {(const void*)gemv_quant_kernel<DT, false, false>, (const void*)gemv_quant_kernel<DT, false, true>,
+                                  (const void*)gemv_quant_kernel<DT, true, false>, (const void*)gemv_quant_kernel<DT, true, true>})
+                ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            return ok;
+        }();
+        if (!once || lds > 160 * 1024) return NTK_E_SHAPE;
+    }
+    // fast prologue: aligned x / norm weights, whole float4s, norm weights fit the 4 register slots per thread
+    const bool xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(p.ablate & 1) && (!norm_w || in <= 4 * 4 * 64 * nwaves);
+    const dim3 g(grid), b(64 * nwaves);
+    if (norm_w && xfast) hipLaunchKernelGGL((gemv_quant_kernel<DT, true, true>), g, b, lds, st, p);
+    else if (norm_w) hipLaunchKernelGGL((gemv_quant_kernel<DT, true, false>), g, b, lds, st, p);
+    else if (xfast) hipLaunchKernelGGL((gemv_quant_kernel<DT, false, true>), g, b, lds, st, p);
+    else hipLaunchKernelGGL((gemv_quant_kernel<DT, false, false>), g, b, lds, st, p);
     return last_launch_status();
 }
 

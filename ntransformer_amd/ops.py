@@ -45,6 +45,9 @@ class DeviceBuffer:
         dt = np.dtype(dtype)
         n = (self.nbytes - offset) // dt.itemsize if count is None else count
         out = np.empty(n, dt)
+        # the blocking copy runs on the NULL stream, which does not order against the library's non-blocking
+        # compute stream (same as the reference: cudaMemcpy vs cudaStreamNonBlocking) -> drain it first
+        check(_lib.lib().ntk_stream_synchronize(None), "stream sync")
         if n:
             _lib.lib().nt_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.ptr + offset, out.nbytes)
         return out

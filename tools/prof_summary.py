@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace run of bench.py (rocpd sqlite database or kernel_trace CSV) per kernel
+for the DECODE window only: dispatches after the last prefill attention launch.  bench.py's `roofline` numbers are
+measured over decode tokens, so this is the slice of the trace they must agree with.
+usage: python tools/prof_summary.py <results.db> [--bytes-per-token N] > profiles/<name>.txt"""
+import argparse
+import collections
+import sqlite3
+import sys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--gemv-bytes-per-token", type=float, default=7_973_699_584.0, help="bytes the GEMV launches of one token stream")
+    a = ap.parse_args()
+    db = sqlite3.connect(a.db)
+    rows = db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count, lds_size from kernels order by start").fetchall()
+    last_prefill = max((i for i, r in enumerate(rows) if "attention_kernel<" in r[0]), default=-1)
+    dec = rows[last_prefill + 1:]
+    # drop everything up to the end of prefill's token (final norm + LM head + first argmax): start at first fused attention
+    first = next((i for i, r in enumerate(dec) if "attention_decode_fused" in r[0]), 0)
+    first_embed = max((i for i in range(first) if "embed_rows" in dec[i][0]), default=0)
+    dec = dec[first_embed:]
+    n_tokens = sum(1 for r in dec if "embed_rows" in r[0])
+    stats = collections.OrderedDict()
+    for name, s, e, gx, wx, vg, lds in dec:
+        short = name.split("(")[0].replace("void ", "")
+        st = stats.setdefault(short, [0, 0.0, set()])
+        st[0] += 1
+        st[1] += (e - s) / 1e3
+        st[2].add((gx // max(wx, 1), wx, vg, lds))
+    span_us = (dec[-1][2] - dec[0][1]) / 1e3 if dec else 0.0
+    busy = sum(v[1] for v in stats.values())
+    print("decode window: %d kernel dispatches, %d tokens, span %.1f us (%.1f us/token), kernel-busy %.1f us (%.1f%%)"
+          % (len(dec), n_tokens, span_us, span_us / max(n_tokens, 1), busy, 100 * busy / max(span_us, 1e-9)))
+    print("%-48s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "share"))
+    for k, (c, t, shapes) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
+        print("%-48s %8d %12.1f %10.2f %6.1f%%" % (k, c, t, t / c, 100 * t / busy))
+    g = [v for k, v in stats.items() if "gemv_quant_kernel" in k]
+    if g and n_tokens:
+        c, t = sum(v[0] for v in g), sum(v[1] for v in g)
+        per_launch = a.gemv_bytes_per_token * n_tokens / c
+        print("\ngemv_quant_kernel pooled: %.1f launches/token, avg %.2f us, algorithmic %.1f MB/launch -> %.1f GB/s = %.1f%% of 8 TB/s"
+              % (c / n_tokens, t / c, per_launch / 1e6, per_launch / (t / c * 1e-6) / 1e9, per_launch / (t / c * 1e-6) / 8e12 * 100))
+    # per launch geometry of the GEMV (grid in workgroups, block, vgprs, lds): one line per distinct shape
+    byshape = collections.defaultdict(lambda: [0, 0.0])
+    for name, s, e, gx, wx, vg, lds in dec:
+        if "gemv_quant_kernel" in name:
+            k = (gx // max(wx, 1), wx, vg, lds)
+            byshape[k][0] += 1
+            byshape[k][1] += (e - s) / 1e3
+    print("\ngemv launches by geometry (workgroups, threads, vgprs, lds bytes): calls, avg us")
+    for k, (c, t) in sorted(byshape.items(), key=lambda kv: -kv[1][1]):
+        print("  %-28s %6d %9.2f" % (k, c, t / c))
+
+
+if __name__ == "__main__":
+    main()
