@@ -53,6 +53,8 @@ def cpu_baseline(args, spec_full, prompt):
     import numpy as np
     from ntransformer_amd import engine as E
     from oracle import oracle as O
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+    threads = O.pick_threads()      # what this host really schedules, not what it advertises
     sample_layers = 2 if args.model in ("8b", "70b") else E.PRESETS[args.model]["layers"]
     spec = E.synth_spec(args.model, args.mix, layers=sample_layers)
     path = "/dev/shm/_bench_cpu_sample.gguf" if os.path.isdir("/dev/shm") else "/tmp/_bench_cpu_sample.gguf"
@@ -80,7 +82,7 @@ def cpu_baseline(args, spec_full, prompt):
         t_layer = max((t_full - t_one) / max(sample_layers - 1, 1), 1e-9)
         t_head = max(t_one - t_layer, 0.0)
         tok_s = 1.0 / (t_head + full_layers * t_layer)
-        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        cores = threads
         return {"value": round(tok_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
                 "sample": "%d of %d layers + full LM head of the same %s %s model, %d decode steps on the CPU oracle "
                           "(%.3f s/layer, %.3f s head+embed); layers scaled to full depth"
@@ -112,12 +114,9 @@ def main():
         print("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
     os.environ["NTK_DEVICE"] = str(local_rank)
 
-    dist = torch = None
-    if world > 1:   # torch only as the rendezvous / barrier / max-reduce plumbing over RCCL
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=torch.device("cuda", local_rank))
+    from ntransformer_amd import replica
+    backend = "nccl" if world > 1 else None      # torch only as rendezvous / barrier / max-reduce plumbing over RCCL
+    dist = replica.init_distributed("nccl", local_rank) if world > 1 else None
 
     import numpy as np
     from ntransformer_amd import _lib
@@ -143,21 +142,8 @@ def main():
         tok = warm[-1]
     pos += args.warmup
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-        _lib.check(L.ntk_device_synchronize(), "device sync")
-
-    barrier()
-    t0 = time.perf_counter()
-    out = eng.decode_greedy_steps(tok, pos, args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, _, out = replica.timed_steps(lambda k: eng.decode_greedy_steps(tok, pos, k), args.steps,
+                                          lambda: _lib.check(L.ntk_device_synchronize(), "device sync"), dist, backend)
     pos_end = pos + args.steps
 
     if rank == 0:

@@ -12,7 +12,7 @@ of those kernels for the resident path:
   buffers / KV layout       reference src/model/transformer.cpp:330-391
 
 `OracleModel` is pinned bit-for-bit against the reference's own unmodified host code linked with the same
-kernels (oracle/_ref/ref_logits; tests/test_oracle_model.py), so either can be the golden side.
+kernels (oracle/_ref/ref_logits; tests/test_oracle_golden.py), so either can be the golden side.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """
@@ -145,6 +145,37 @@ def embed_row(table: np.ndarray, token: int, hidden: int, dtype: int) -> np.ndar
     o = np.empty(hidden, np.float32)
     lib().oracle_embed_row(_p(o), _p(table), C.c_int(token), C.c_int(hidden), C.c_int(dtype))
     return o
+
+
+def set_threads(n: int) -> None:
+    lib().oracle_set_threads(C.c_int(n))
+
+
+def max_threads() -> int:
+    return int(lib().oracle_get_max_threads())
+
+
+def pick_threads(candidates=(1, 2, 4, 8, 16, 32, 64, 128)) -> int:
+    """Thread count this host actually sustains (containers often expose more CPUs than they schedule):
+    time one 2048x4096 Q8_0 GEMV per candidate, keep the fastest."""
+    import time
+    rng = np.random.default_rng(0)
+    W = rng.integers(0, 255, 2048 * 4352, dtype=np.uint8)
+    x = rng.standard_normal(4096).astype(np.float32)
+    best, best_t = 1, float("inf")
+    limit = os.cpu_count() or 1
+    for n in candidates:
+        if n > limit:
+            break
+        set_threads(n)
+        gemv(W, x, 2048, 4096, 2)
+        t0 = time.perf_counter()
+        gemv(W, x, 2048, 4096, 2)
+        dt = time.perf_counter() - t0
+        if dt < best_t * 0.95:
+            best, best_t = n, dt
+    set_threads(best)
+    return best
 
 
 def h2f(h: int) -> float:

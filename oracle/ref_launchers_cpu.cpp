@@ -34,9 +34,9 @@
 //
 // PARITY PIN.  Pinned against: the known-answer vectors in the reference's tests/test_gemm.cpp
 // (tests/test_oracle_kat.py), the independent numpy dequantisers in the reference's
-// tools/decompose_gguf.py (tests/golden/dequant_*.npz, made by tools/make_golden_dequant.py), and
+// tools/decompose_gguf.py (tests/golden/dequant_*.npz, made by tools/make_golden.py), and
 // end-to-end through the reference's own unmodified host code linked against this file
-// (oracle/_ref/ref_logits, tests/golden/tiny_*_logits.npy).  The device arithmetic itself
+// (oracle/_ref/ref_logits -> tests/golden/*_logits.npz, checked by tests/test_oracle_golden.py).  The device arithmetic itself
 // (src/cuda/*.cu) cannot be executed here (no nvcc, no NVIDIA GPU): for Q8_0/Q4_K/Q5_K GEMV,
 // RoPE, KV store and attention the reference has no tests of its own, so those rows are
 // "pinned by restatement + independent dequant only" (see DESIGN.md, section Oracle).
@@ -47,6 +47,9 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifdef ORACLE_WITH_REFERENCE_HEADERS
 #include "core/types.h"      // nt::DType from the reference (only when linking with its host TUs)
@@ -702,5 +705,21 @@ int oracle_embed_row(float* out, const void* table, int token, int hidden, int d
 }
 
 int oracle_abi_version(void) { return 1; }
+
+// thread control for the timed CPU baseline (bench.py probes which thread count this host actually sustains)
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+int oracle_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 }  // extern "C"
