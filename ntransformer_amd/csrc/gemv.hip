@@ -84,8 +84,20 @@ struct GemvParams {
 // ------------------------------------------------------------------------------------------------
 template <int DT> struct Dot;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two FMAs per instruction (v_pk_fma_f32): the dot products are VALU-issue bound for the 4/5/6-bit formats
+__device__ __forceinline__ f32x2 pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// hide a value from the optimiser so that (x & 0x0F0F0F0F) stays ONE v_and and each byte converts with
+// v_cvt_f32_ubyteN (otherwise hipcc re-derives every nibble with its own v_bfe_u32 + v_cvt_f32_ubyte0)
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ f32x2 ub01(uint32_t w) { return f32x2{ub2f(w, 0), ub2f(w, 1)}; }
+__device__ __forceinline__ f32x2 ub23(uint32_t w) { return f32x2{ub2f(w, 2), ub2f(w, 3)}; }
+__device__ __forceinline__ float hsum(f32x2 a, f32x2 b) { return (a.x + a.y) + (b.x + b.y); }
+
+// x2[i] = (x[2i], x[2i+1]) of the lane's 64 columns
+
 template <> struct Dot<NTK_DT_Q8_0> {   // reference gemm.cu:129-141: sum += d * sum_j q_j x_j
-    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&)[2]) {
         float acc = 0.0f;
         const int o = shift + 68 * lane;
@@ -96,13 +108,13 @@ template <> struct Dot<NTK_DT_Q8_0> {   // reference gemm.cu:129-141: sum += d *
                 const float d = h2f(lds_u16_at(st, ob));
                 uint32_t q[8];
                 lds_read_dwords<8>(q, st, ob + 2);
-                float bs = 0.0f;
+                f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) bs = fmaf(sb2f(q[i], k), xr[32 * h + 4 * i + k], bs);
+                    a0 = pkfma(f32x2{sb2f(q[i], 0), sb2f(q[i], 1)}, x2[16 * h + 2 * i], a0);
+                    a1 = pkfma(f32x2{sb2f(q[i], 2), sb2f(q[i], 3)}, x2[16 * h + 2 * i + 1], a1);
                 }
-                acc = fmaf(d, bs, acc);
+                acc = fmaf(d, hsum(a0, a1), acc);
             }
         }
         return acc;
@@ -110,7 +122,7 @@ template <> struct Dot<NTK_DT_Q8_0> {   // reference gemm.cu:129-141: sum += d *
 };
 
 template <> struct Dot<NTK_DT_Q4_0> {   // reference gemm.cu:60-75: w_j = d (lo-8), w_{j+16} = d (hi-8)
-    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {
         float acc = 0.0f;
         const int o = shift + 36 * lane;
@@ -121,36 +133,47 @@ template <> struct Dot<NTK_DT_Q4_0> {   // reference gemm.cu:60-75: w_j = d (lo-
                 const float d = h2f(lds_u16_at(st, ob));
                 uint32_t q[4];
                 lds_read_dwords<4>(q, st, ob + 2);
-                float bs = 0.0f;
+                f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = q[i] & 0x0F0F0F0Fu, hi = (q[i] >> 4) & 0x0F0F0F0Fu;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        bs = fmaf(ub2f(lo, k), xr[32 * h + 4 * i + k], bs);
-                        bs = fmaf(ub2f(hi, k), xr[32 * h + 16 + 4 * i + k], bs);
-                    }
+                    const uint32_t lo = opaque(q[i] & 0x0F0F0F0Fu), hi = opaque((q[i] >> 4) & 0x0F0F0F0Fu);
+                    a0 = pkfma(ub01(lo), x2[16 * h + 2 * i], a0);
+                    a1 = pkfma(ub23(lo), x2[16 * h + 2 * i + 1], a1);
+                    a0 = pkfma(ub01(hi), x2[16 * h + 8 + 2 * i], a0);
+                    a1 = pkfma(ub23(hi), x2[16 * h + 8 + 2 * i + 1], a1);
                 }
-                acc = fmaf(d, fmaf(-8.0f, sx32[h], bs), acc);   // sum (n-8) x = sum n x - 8 sum x
+                acc = fmaf(d, fmaf(-8.0f, sx32[h], hsum(a0, a1)), acc);   // sum (n-8) x = sum n x - 8 sum x
             }
         }
         return acc;
     }
 };
 
-// K-quant header: d, dmin and the (scale, min) pairs of sub-blocks 2c, 2c+1
+// K-quant header: d, dmin and the 6-bit (scale, min) pairs of sub-blocks 2c, 2c+1 (types.h:112-117, gemm.cu:206-222).
+// Branch-free in the lane-constant c: bytes 0-3 / 4-7 / 8-11 of the 12 packed bytes are the dwords s0 / s1 / s2.
 __device__ __forceinline__ void kq_header(const uint8_t* st, int ob, int c, float& d1, float& m1, float& d2, float& m2) {
     uint32_t hd[4];
     lds_read_dwords<4>(hd, st, ob);
     const float d = h2f((uint16_t)(hd[0] & 0xFFFFu)), dmin = h2f((uint16_t)(hd[0] >> 16));
-    float s_lo, n_lo, s_hi, n_hi;
-    kq_scale_min(hd[1], hd[2], hd[3], 2 * c, s_lo, n_lo);
-    kq_scale_min(hd[1], hd[2], hd[3], 2 * c + 1, s_hi, n_hi);
-    d1 = d * s_lo; m1 = dmin * n_lo; d2 = d * s_hi; m2 = dmin * n_hi;
+    const uint32_t s0 = hd[1], s1 = hd[2], s2 = hd[3];
+    const bool upper = c >= 2;                       // sub-blocks 4..7 keep their top 2 bits in bytes 0..7
+    const int sh = 16 * (c & 1);                     // byte (2c & 3) of a dword, then byte + 1
+    uint32_t sc[2], mn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int b = sh + 8 * t;
+        const uint32_t lo_s = (s0 >> b) & 63u, lo_m = (s1 >> b) & 63u;
+        const uint32_t hi_s = ((s2 >> b) & 0xFu) | (((s0 >> (b + 6)) & 3u) << 4);
+        const uint32_t hi_m = ((s2 >> (b + 4)) & 0xFu) | (((s1 >> (b + 6)) & 3u) << 4);
+        sc[t] = upper ? hi_s : lo_s;
+        mn[t] = upper ? hi_m : lo_m;
+    }
+    d1 = d * (float)sc[0]; m1 = dmin * (float)mn[0];
+    d2 = d * (float)sc[1]; m2 = dmin * (float)mn[1];
 }
 
 template <> struct Dot<NTK_DT_Q4_K> {   // reference gemm.cu:190-244
-    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {
         if (ncols <= 0) return 0.0f;
         const int c = lane & 3, ob = shift + 144 * (lane >> 2);
@@ -158,32 +181,31 @@ template <> struct Dot<NTK_DT_Q4_K> {   // reference gemm.cu:190-244
         kq_header(st, ob, c, d1, m1, d2, m2);
         uint32_t q[8];
         lds_read_dwords<8>(q, st, ob + 16 + 32 * c);
-        float s_lo = 0.0f, s_hi = 0.0f;
+        f32x2 l0 = {0.0f, 0.0f}, l1 = {0.0f, 0.0f}, h0 = {0.0f, 0.0f}, h1 = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const uint32_t lo = q[i] & 0x0F0F0F0Fu, hi = (q[i] >> 4) & 0x0F0F0F0Fu;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s_lo = fmaf(ub2f(lo, k), xr[4 * i + k], s_lo);
-                s_hi = fmaf(ub2f(hi, k), xr[32 + 4 * i + k], s_hi);
-            }
+            const uint32_t lo = opaque(q[i] & 0x0F0F0F0Fu), hi = opaque((q[i] >> 4) & 0x0F0F0F0Fu);
+            l0 = pkfma(ub01(lo), x2[2 * i], l0);
+            l1 = pkfma(ub23(lo), x2[2 * i + 1], l1);
+            h0 = pkfma(ub01(hi), x2[16 + 2 * i], h0);
+            h1 = pkfma(ub23(hi), x2[16 + 2 * i + 1], h1);
         }
-        float t = d1 * s_lo;
+        float t = d1 * hsum(l0, l1);
         t = fmaf(-m1, sx32[0], t);
-        t = fmaf(d2, s_hi, t);
+        t = fmaf(d2, hsum(h0, h1), t);
         t = fmaf(-m2, sx32[1], t);
         return t;
     }
 };
 
 template <> struct Dot<NTK_DT_Q5_K> {   // reference gemm.cu:297-354
-    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {
         if (ncols <= 0) return 0.0f;
         const int c = lane & 3, ob = shift + 176 * (lane >> 2);
         float d1, m1, d2, m2;
         kq_header(st, ob, c, d1, m1, d2, m2);
-        float s_lo = 0.0f, s_hi = 0.0f;
+        f32x2 l0 = {0.0f, 0.0f}, l1 = {0.0f, 0.0f}, h0 = {0.0f, 0.0f}, h1 = {0.0f, 0.0f};
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {   // two 16-byte halves: keeps the live dword count low
             uint32_t qh[4], ql[4];
@@ -191,54 +213,54 @@ template <> struct Dot<NTK_DT_Q5_K> {   // reference gemm.cu:297-354
             lds_read_dwords<4>(ql, st, ob + 48 + 32 * c + 16 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t lo = (ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c)) & 0x01010101u) << 4);
-                const uint32_t hi = ((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c + 1)) & 0x01010101u) << 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s_lo = fmaf(ub2f(lo, k), xr[16 * hh + 4 * i + k], s_lo);
-                    s_hi = fmaf(ub2f(hi, k), xr[32 + 16 * hh + 4 * i + k], s_hi);
-                }
+                const uint32_t lo = opaque((ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c)) & 0x01010101u) << 4));
+                const uint32_t hi = opaque(((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c + 1)) & 0x01010101u) << 4));
+                l0 = pkfma(ub01(lo), x2[8 * hh + 2 * i], l0);
+                l1 = pkfma(ub23(lo), x2[8 * hh + 2 * i + 1], l1);
+                h0 = pkfma(ub01(hi), x2[16 + 8 * hh + 2 * i], h0);
+                h1 = pkfma(ub23(hi), x2[16 + 8 * hh + 2 * i + 1], h1);
             }
         }
-        float t = d1 * s_lo;
+        float t = d1 * hsum(l0, l1);
         t = fmaf(-m1, sx32[0], t);
-        t = fmaf(d2, s_hi, t);
+        t = fmaf(d2, hsum(h0, h1), t);
         t = fmaf(-m2, sx32[1], t);
         return t;
     }
 };
 
 template <> struct Dot<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (block, half, t): groups g = 2t, 2t+1
-    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const float (&xr)[64],
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&sx16)[4], const float (&)[2]) {
         if (ncols <= 0) return 0.0f;
         const int t = lane & 1, hf = (lane >> 1) & 1, ob = shift + 210 * (lane >> 2);
         const uint32_t scw = lds_u32_at(st, ob + 192 + 8 * hf + 4 * t);   // sc[is + 2gg], bytes: (gg0,is0)(gg0,is1)(gg1,is0)(gg1,is1)
         const float d = h2f(lds_u16_at(st, ob + 208));
-        float Sa[2] = {0.0f, 0.0f}, Sb[2] = {0.0f, 0.0f};
+        float S[4];   // [gg*2 + is]
 #pragma unroll
         for (int is = 0; is < 2; ++is) {   // the two 16-column runs of each group (sub-scale index is)
             uint32_t A[4], B[4], H[4];
             lds_read_dwords<4>(A, st, ob + 64 * hf + 16 * is);
             lds_read_dwords<4>(B, st, ob + 64 * hf + 32 + 16 * is);
             lds_read_dwords<4>(H, st, ob + 128 + 32 * hf + 16 * is);
+            f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, b0 = {0.0f, 0.0f}, b1 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t qa = ((A[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t)) & 0x03030303u) << 4);
-                const uint32_t qb = ((B[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t + 2)) & 0x03030303u) << 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    Sa[is] = fmaf(ub2f(qa, k), xr[16 * is + 4 * i + k], Sa[is]);
-                    Sb[is] = fmaf(ub2f(qb, k), xr[32 + 16 * is + 4 * i + k], Sb[is]);
-                }
+                const uint32_t qa = opaque(((A[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t)) & 0x03030303u) << 4));
+                const uint32_t qb = opaque(((B[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t + 2)) & 0x03030303u) << 4));
+                a0 = pkfma(ub01(qa), x2[8 * is + 2 * i], a0);
+                a1 = pkfma(ub23(qa), x2[8 * is + 2 * i + 1], a1);
+                b0 = pkfma(ub01(qb), x2[16 + 8 * is + 2 * i], b0);
+                b1 = pkfma(ub23(qb), x2[16 + 8 * is + 2 * i + 1], b1);
             }
+            S[is] = hsum(a0, a1);
+            S[2 + is] = hsum(b0, b1);
         }
-        const float Sa0 = Sa[0], Sa1 = Sa[1], Sb0 = Sb[0], Sb1 = Sb[1];
         // sum (q-32) x = sum q x - 32 sum x, per 16-column run, times the run's int8 sub-scale
-        float bs = sb2f(scw, 0) * fmaf(-32.0f, sx16[0], Sa0);
-        bs = fmaf(sb2f(scw, 1), fmaf(-32.0f, sx16[1], Sa1), bs);
-        bs = fmaf(sb2f(scw, 2), fmaf(-32.0f, sx16[2], Sb0), bs);
-        bs = fmaf(sb2f(scw, 3), fmaf(-32.0f, sx16[3], Sb1), bs);
+        float bs = sb2f(scw, 0) * fmaf(-32.0f, sx16[0], S[0]);
+        bs = fmaf(sb2f(scw, 1), fmaf(-32.0f, sx16[1], S[1]), bs);
+        bs = fmaf(sb2f(scw, 2), fmaf(-32.0f, sx16[2], S[2]), bs);
+        bs = fmaf(sb2f(scw, 3), fmaf(-32.0f, sx16[3], S[3]), bs);
         return d * bs;
     }
 };
@@ -263,7 +285,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     const int g = wave / p.ns;        // row group of this wave
     constexpr bool norm = NORM;   // compile-time: the norm-weight loads/stores must not sit behind a runtime branch
 
-    const size_t regionA = (size_t)std::max(nwaves * STAGE, p.ns * 64 * XPITCH * 4);
+    const size_t regionA = (size_t)std::max(nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
     float* part = reinterpret_cast<float*>(smem + regionA);
     float* red = part + 2 * p.rw * p.ns * RB;
     const size_t lds_floats_total = regionA / 4 + (size_t)(2 * p.rw * p.ns * RB + 16 + 16);   // ... + red[16] + 16 spare
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 
     // ---- prologue: this lane's 64 activations into registers (through a padded LDS image: coalesced
     //      global reads, conflict-free ds_read_b128), optional RMSNorm (reference rmsnorm.cu:16-70) ----
-    float xr[64];
+    f32x2 x2[32];   // the lane's 64 activations as 32 (even, odd) pairs
     {
         // The activations reach registers through a padded LDS image holding ALL slices: image row (sp*64 + l)
         // = the 64 columns lane l of slice sp owns (pitch 68 floats: conflict-free ds_read_b128).
@@ -318,13 +340,25 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
         //     image holds normalised values: the transposing read needs no second image and no extra registers
         //     (a weight image made hipcc spill the in-flight prefetch registers to scratch).
         float* ximg = reinterpret_cast<float*>(smem);
-        auto img_index = [&](int c) {
+        constexpr int GS = 4;   // slices per image pass: 28672-wide rows (7 slices) take two passes, keeping LDS at 68 KB
+        auto img_index = [&](int c, int g0) {
             const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
-            return (sp * 64 + (cc >> 6)) * XPITCH + (cc & 63);
+            return ((sp - g0) * 64 + (cc >> 6)) * XPITCH + (cc & 63);
         };
         constexpr int XIT = 8, WIT = 4;
         const int step = (int)blockDim.x * 4;
         const int dummy = (int)(lds_floats_total - 16);   // 16 spare floats at the end of the allocation
+        const bool have_lo = ncols > 0, have_hi = ncols > 32;   // ncols is 0, 32 or 64: two masks, not 64 compares
+        auto read_own_row = [&](int g0) {
+            const float* xrow = ximg + ((s - g0) * 64 + lane) * XPITCH;
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(xrow + j);
+                const bool have = j < 32 ? have_lo : have_hi;
+                x2[j / 2] = f32x2{have ? v.x : 0.0f, have ? v.y : 0.0f};
+                x2[j / 2 + 1] = f32x2{have ? v.z : 0.0f, have ? v.w : 0.0f};
+            }
+        };
         if constexpr (XFAST) {   // host guarantees: x (and norm_w) 16-byte aligned, in % 4 == 0, (!NORM || in <= WIT * step)
             u32x4 xv[XIT], wv[WIT];
 #pragma unroll
@@ -343,8 +377,8 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 #pragma unroll
                 for (int i = 0; i < WIT; ++i) {
                     const float m = (tid * 4 + i * step < p.in) ? 1.0f : 0.0f;
-                    const float x0 = __uint_as_float(xv[i].x), x1 = __uint_as_float(xv[i].y), x2 = __uint_as_float(xv[i].z), x3 = __uint_as_float(xv[i].w);
-                    ssq = fmaf(x0 * m, x0, ssq); ssq = fmaf(x1 * m, x1, ssq); ssq = fmaf(x2 * m, x2, ssq); ssq = fmaf(x3 * m, x3, ssq);
+                    const float x0 = __uint_as_float(xv[i].x), x1 = __uint_as_float(xv[i].y), x2_ = __uint_as_float(xv[i].z), x3 = __uint_as_float(xv[i].w);
+                    ssq = fmaf(x0 * m, x0, ssq); ssq = fmaf(x1 * m, x1, ssq); ssq = fmaf(x2_ * m, x2_, ssq); ssq = fmaf(x3 * m, x3, ssq);
                 }
                 ssq = wave_sum(ssq);
                 if (lane == 0) red[wave] = ssq;
@@ -352,22 +386,33 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
                 float tot = 0.0f;
                 for (int w = 0; w < nwaves; ++w) tot += red[w];
                 rms_inv = 1.0f / sqrtf(tot / (float)p.in + p.eps);   // rsqrtf(mean + eps), rmsnorm.cu:60-61
-            }
 #pragma unroll
-            for (int i = 0; i < XIT; ++i) {
-                const int c = tid * 4 + i * step;
-                float4 v = make_float4(__uint_as_float(xv[i].x), __uint_as_float(xv[i].y), __uint_as_float(xv[i].z), __uint_as_float(xv[i].w));
-                if constexpr (NORM) {
-                    if (i < WIT) {
-                        v.x = v.x * rms_inv * __uint_as_float(wv[i].x); v.y = v.y * rms_inv * __uint_as_float(wv[i].y);
-                        v.z = v.z * rms_inv * __uint_as_float(wv[i].z); v.w = v.w * rms_inv * __uint_as_float(wv[i].w);
-                    }
+                for (int i = 0; i < WIT; ++i) {   // x * rms_inv * w, the reference's association (rmsnorm.cu:68)
+                    xv[i].x = __float_as_uint(__uint_as_float(xv[i].x) * rms_inv * __uint_as_float(wv[i].x));
+                    xv[i].y = __float_as_uint(__uint_as_float(xv[i].y) * rms_inv * __uint_as_float(wv[i].y));
+                    xv[i].z = __float_as_uint(__uint_as_float(xv[i].z) * rms_inv * __uint_as_float(wv[i].z));
+                    xv[i].w = __float_as_uint(__uint_as_float(xv[i].w) * rms_inv * __uint_as_float(wv[i].w));
                 }
-                *reinterpret_cast<float4*>(ximg + (c < p.in ? img_index(c) : dummy)) = v;
             }
-            if constexpr (!NORM) {   // columns beyond 8 * 4 * blockDim (28672-wide rows): the weights are already in flight
-                for (int c = XIT * step + tid * 4; c < p.in; c += step)
-                    *reinterpret_cast<float4*>(ximg + img_index(c)) = *reinterpret_cast<const float4*>(p.x + c);
+            {   // pass 0 (the only one up to 16384 columns): straight-line, the registers die here
+                const int cend = min(p.in, GS * p.slice_cols);
+#pragma unroll
+                for (int i = 0; i < XIT; ++i) {
+                    const int c = tid * 4 + i * step;
+                    *reinterpret_cast<u32x4*>(ximg + (c < cend ? img_index(c, 0) : dummy)) = xv[i];
+                }
+                for (int c = XIT * step + tid * 4; c < cend; c += step)   // columns the registers do not cover
+                    *reinterpret_cast<float4*>(ximg + img_index(c, 0)) = *reinterpret_cast<const float4*>(p.x + c);
+                __syncthreads();
+                if (s < GS) read_own_row(0);
+            }
+            for (int g0 = GS; g0 < p.ns; g0 += GS) {   // 28672-wide rows: slices 4..6 in a second pass (weights already in flight)
+                const int cbeg = g0 * p.slice_cols, cend = min(p.in, (g0 + GS) * p.slice_cols);
+                __syncthreads();   // the previous pass has been read
+                for (int c = cbeg + tid * 4; c < cend; c += step)
+                    *reinterpret_cast<float4*>(ximg + img_index(c, g0)) = *reinterpret_cast<const float4*>(p.x + c);
+                __syncthreads();
+                if (s >= g0 && s < g0 + GS) read_own_row(g0);
             }
         } else {   // unaligned / odd sizes (and the NTK_GEMV_ABLATE=1 experiment): plain loops
             if (n_my > 0) issue(0);
@@ -382,26 +427,20 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
                 for (int w = 0; w < nwaves; ++w) tot += red[w];
                 rms_inv = 1.0f / sqrtf(tot / (float)p.in + p.eps);
             }
-            if (!(p.ablate & 1)) {
-                for (int c = tid; c < p.in; c += blockDim.x)
-                    ximg[img_index(c)] = NORM ? p.x[c] * rms_inv * p.norm_w[c] : p.x[c];
+            for (int g0 = 0; g0 < p.ns; g0 += GS) {
+                const int cbeg = g0 * p.slice_cols, cend = min(p.in, (g0 + GS) * p.slice_cols);
+                if (g0 > 0) __syncthreads();
+                if (!(p.ablate & 1)) {
+                    for (int c = cbeg + tid; c < cend; c += blockDim.x)
+                        ximg[img_index(c, g0)] = NORM ? p.x[c] * rms_inv * p.norm_w[c] : p.x[c];
+                }
+                __syncthreads();
+                if (s >= g0 && s < g0 + GS) read_own_row(g0);
             }
-        }
-        __syncthreads();
-        const bool have_lo = ncols > 0, have_hi = ncols > 32;   // ncols is 0, 32 or 64: two masks, not 64 compares
-        const float* xrow = ximg + (s * 64 + lane) * XPITCH;
-#pragma unroll
-        for (int j = 0; j < 64; j += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(xrow + j);
-            const bool have = j < 32 ? have_lo : have_hi;
-            xr[j] = have ? v.x : 0.0f;
-            xr[j + 1] = have ? v.y : 0.0f;
-            xr[j + 2] = have ? v.z : 0.0f;
-            xr[j + 3] = have ? v.w : 0.0f;
         }
         if (p.ablate & 1) {
 #pragma unroll
-            for (int j = 0; j < 64; ++j) xr[j] = 1.0f;
+            for (int j = 0; j < 32; ++j) x2[j] = f32x2{1.0f, 1.0f};
         }
         __syncthreads();   // LDS region A becomes the staging area
     }
@@ -410,7 +449,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     for (int r = 0; r < 4; ++r) {
         float t = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t += xr[16 * r + j];
+        for (int j = 0; j < 8; ++j) t += x2[8 * r + j].x + x2[8 * r + j].y;
         sx16[r] = t;
     }
     sx32[0] = sx16[0] + sx16[1];
@@ -455,7 +494,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
         }
         __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
         if (q + 1 < n_my) issue(q + 1);    // next row's bytes fly while this one is decoded
-        const float acc = (p.ablate & 2) ? xr[0] + (float)q : Dot<DT>::run(stage, shift, lane, ncols, xr, sx16, sx32);
+        const float acc = (p.ablate & 2) ? x2[0].x + (float)q : Dot<DT>::run(stage, shift, lane, ncols, x2, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
         const float tot = wave_sum(acc);
 
@@ -596,7 +635,7 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     const long rows_per_group = (total + ngroups - 1) / ngroups;
     p.nbatch = (int)((rows_per_group * mats + RB - 1) / RB);
     constexpr int STAGE = F::NL * 1024 + 64;
-    const size_t regionA = (size_t)std::max(nwaves * STAGE, p.ns * 64 * XPITCH * 4);
+    const size_t regionA = (size_t)std::max(nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
     const size_t lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
     if (lds > 64 * 1024) {   // 28672-wide rows: the activation image alone is 119 KiB
         static bool once = [] {
