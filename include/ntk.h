@@ -14,7 +14,7 @@
  *   - in-place aliasing the reference relies on is supported: rmsnorm(out==in), silu_mul(out==gate),
  *     add_inplace, gemv never aliases y with x;
  *   - returns NTK_OK or a negative NTK_E_* code.  Where the reference only prints (unsupported dtype,
- *     reference src/cuda/gemm.cu:801-803) the C++ wrappers in include/nt_kernels.hpp print and continue.
+ *     reference src/cuda/gemm.cu:801-803) the C++ wrappers in integration/nt_cuda_launchers.cpp print and continue.
  */
 #ifndef NTK_H
 #define NTK_H
@@ -153,10 +153,12 @@ int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_fe
 
 /* RoPE(q,k at *d_pos) + KV store + GQA decode attention over keys 0..*d_pos, one launch
  * (launch_rope + launch_copy_to_kv_cache + launch_attention_decode; attention.cpp:165-190).
- * q [nh*hd], k,v [nkv*hd] are the raw projections (left untouched); d_pos is a DEVICE int. */
+ * q [nh*hd], k,v [nkv*hd] are the raw projections (left untouched); d_pos is a DEVICE int.
+ * inv_freq: optional DEVICE table [hd/2] of 1/powf(theta, 2i/hd) (NULL = computed in the kernel). */
 int ntk_attention_decode_fused(float* output, const float* q, const float* k, const float* v, void* k_cache,
-                               void* v_cache, const int* d_pos, int n_heads, int n_kv_heads, int head_dim,
-                               int max_seq, float scale, float theta_base, float freq_scale, void* stream);
+                               void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,
+                               int head_dim, int max_seq, float scale, float theta_base, float freq_scale,
+                               void* stream);
 
 /* Dequantise rows of a (quantised) embedding table on the device: out[t,:] = table[tokens[t],:].
  * Same arithmetic as the host loop in reference src/model/transformer.cpp:419-599; Q5_K is zero-filled

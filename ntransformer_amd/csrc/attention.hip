@@ -206,6 +206,115 @@ __global__ __launch_bounds__(256) void attention_decode_fused_kernel(
     attend<LPR>(output + (size_t)head * hd, qs, kc, vc, pos, kx, vx, kv_head, n_kv_heads, hd, scale, sc, part, red);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode attention, single pass (engine path).  The reference kernel (attention.cu:108-202) and `attend` above make
+// three passes over LDS scores with ~8 workgroup barriers; at decode lengths the launch is pure latency, so here
+// every (wave, 16-lane group) streams its own positions with an online softmax (running max m, sum l, 8 output
+// dims per lane), K/V of the next position in flight while the current one is reduced, and the 16 partial states
+// merge once through LDS: two barriers in total.  Same F32 math on the same half-rounded K/V; the summation order
+// differs (|d out| ~1e-6).  The token being decoded comes from LDS (kx/vx), not from the cache row another
+// workgroup is writing.
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void attention_decode_fused_v2_kernel(
+    float* __restrict__ output, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
+    int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale) {
+    constexpr int PPW = 64 / LPR, NW = 4, G = NW * PPW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int head = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int group = n_heads / n_kv_heads, kv_head = head / group;
+    const int pos = *d_pos;
+    float* qs = lds;              // [hd] post-RoPE query
+    float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
+    float* vx = kx + hd;          // [hd] value of this token, rounded through half
+    float* ms = vx + hd;          // [G] running maxima
+    float* ls = ms + G;           // [G] running sums
+    float* accs = ls + G;         // [G][hd]
+    const int half_dim = hd / 2;
+    const size_t stride = (size_t)n_kv_heads * hd;
+    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
+    const bool writer = (head % group == 0) && pos < max_seq;
+    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
+    const uint16_t* kbase = kc + (size_t)kv_head * hd + 8 * part_i;
+    const uint16_t* vbase = vc + (size_t)kv_head * hd + 8 * part_i;
+
+    // first cache rows in flight before the RoPE math
+    int p = g;
+    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
+    if (p < pos) {
+        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
+        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
+    }
+    for (int i = tid; i < half_dim; i += blockDim.x) {
+        float a = q[(size_t)head * hd + i], b = q[(size_t)head * hd + i + half_dim];
+        float ka = k[(size_t)kv_head * hd + i], kb = k[(size_t)kv_head * hd + i + half_dim];
+        // reference rotary.cu:46-60; inv_freq (engine) holds 1/powf(theta, 2i/hd) computed once on the host
+        const float freq = inv_freq ? inv_freq[i] : 1.0f / (float)pow((double)theta, (double)((2.0f * i) / hd));
+        const float angle = pos * freq * fscale;
+        const float c = cosf(angle), sn = sinf(angle);
+        qs[i] = a * c - b * sn; qs[i + half_dim] = b * c + a * sn;
+        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
+        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
+        if (writer) { kc[cache_row + i] = ha; kc[cache_row + i + half_dim] = hb; }
+    }
+    for (int i = tid; i < hd; i += blockDim.x) {
+        const uint16_t hv = f2h(v[(size_t)kv_head * hd + i]);
+        vx[i] = h2f(hv);
+        if (writer) vc[cache_row + i] = hv;
+    }
+    __syncthreads();
+
+    float qreg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
+    float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (; p <= pos; p += G) {
+        float kf[8], vf[8];
+        if (p < pos) {
+            unpack8(kraw, kf);
+            unpack8(vraw, vf);
+        } else {   // the token being decoded
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
+        }
+        const int pn = p + G;
+        if (pn < pos) {   // next position's rows fly during the reduction below
+            kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
+            vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
+        }
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) sc += __shfl_xor(sc, off, 64);
+        sc *= scale;
+        const float mn = fmaxf(m, sc);
+        const float a = expf(m - mn), pw = expf(sc - mn);
+        l = fmaf(l, a, pw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, pw * vf[j]);
+        m = mn;
+    }
+    if (part_i == 0) { ms[g] = m; ls[g] = l; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accs[g * hd + 8 * part_i + j] = acc[j];
+    __syncthreads();
+    for (int d = tid; d < hd; d += blockDim.x) {
+        float M = ms[0];
+        for (int i = 1; i < G; ++i) M = fmaxf(M, ms[i]);
+        float L = 0.0f, o = 0.0f;
+        for (int i = 0; i < G; ++i) {
+            const float w = expf(ms[i] - M);   // exp(-inf) = 0 for groups that saw no position
+            L = fmaf(w, ls[i], L);
+            o = fmaf(w, accs[i * hd + d], o);
+        }
+        output[(size_t)head * hd + d] = o / L;
+    }
+}
+
 __global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, const int* __restrict__ positions, int seq_len,
                             int n_heads, int n_kv_heads, int head_dim, float theta, float fscale, int interleaved) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,30 +418,33 @@ int ntk_attention_prefill(float* output, const float* Q, const void* k_cache, co
 }
 
 int ntk_attention_decode_fused(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
-                               const int* d_pos, int n_heads, int n_kv_heads, int head_dim, int max_seq, float scale,
-                               float theta_base, float freq_scale, void* stream) {
+                               const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                               float scale, float theta_base, float freq_scale, void* stream) {
     if (!output || !q || !k || !v || !k_cache || !v_cache || !d_pos) return NTK_E_NULL;
     if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || head_dim <= 0 || (head_dim & 1) || max_seq <= 0)
         return NTK_E_SHAPE;
-    const size_t lds = ntk::attn_lds(head_dim, max_seq, 3);
-    if (lds > 160 * 1024) return NTK_E_SHAPE;
     hipStream_t st = ntk::resolve_stream(stream);
     const bool aligned = (reinterpret_cast<uintptr_t>(k_cache) & 15) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 15) == 0;
     uint16_t* k16 = static_cast<uint16_t*>(k_cache);
     uint16_t* v16 = static_cast<uint16_t*>(v_cache);
-#define NTK_ATTF(LPR_)                                                                                                  \
-    do {                                                                                                                \
-        if (lds > 64 * 1024)                                                                                            \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntk::attention_decode_fused_kernel<LPR_>),          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL(ntk::attention_decode_fused_kernel<LPR_>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, \
-                           k16, v16, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale);     \
-    } while (0)
-    if (aligned && head_dim == 128) NTK_ATTF(16);
-    else if (aligned && head_dim == 64) NTK_ATTF(8);
-    else if (aligned && head_dim == 256) NTK_ATTF(32);
-    else NTK_ATTF(0);
-#undef NTK_ATTF
+    if (aligned && (head_dim == 128 || head_dim == 64 || head_dim == 256)) {   // single-pass kernel
+        const int G = 4 * (64 / (head_dim / 8));
+        const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
+#define NTK_ATTV2(LPR_) hipLaunchKernelGGL(ntk::attention_decode_fused_v2_kernel<LPR_>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, \
+                                           k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
+        if (head_dim == 128) NTK_ATTV2(16);
+        else if (head_dim == 64) NTK_ATTV2(8);
+        else NTK_ATTV2(32);
+#undef NTK_ATTV2
+        return ntk::last_launch_status();
+    }
+    const size_t lds = ntk::attn_lds(head_dim, max_seq, 3);
+    if (lds > 160 * 1024) return NTK_E_SHAPE;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ntk::attention_decode_fused_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ntk::attention_decode_fused_kernel<0>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, k16, v16, d_pos,
+                       n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale);
     return ntk::last_launch_status();
 }
 

@@ -184,6 +184,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_pos_ = (int*)dev(64, true);
     d_token_ = (int*)dev(64, true);
     argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
+    rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
     h_token_ = (int*)nt_hip_malloc_host(64);
     if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
         !d_pos_ || !d_token_ || !argmax_scratch_ || !h_token_) {
@@ -191,6 +192,11 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
         return NTK_E_NOMEM;
     }
     *h_token_ = 0;
+    if (rope_inv_freq_) {
+        std::vector<float> f((size_t)cfg_.head_dim / 2);
+        for (int i = 0; i < cfg_.head_dim / 2; ++i) f[i] = 1.0f / powf(cfg_.rope_theta, (2.0f * i) / cfg_.head_dim);
+        nt_hip_memcpy_h2d(rope_inv_freq_, f.data(), f.size() * 4);
+    }
     return NTK_OK;
 }
 
@@ -372,8 +378,8 @@ int Model::enqueue_token(bool greedy) {
             NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
         }
         mark(1, true);
-        NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, nh, nkv, hd, cfg_.max_seq_len, scale,
-                                          cfg_.rope_theta, cfg_.rope_freq_scale, s));
+        NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
+                                          cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale, s));
         mark(1, false);
         NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {

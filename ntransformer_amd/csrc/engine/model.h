@@ -94,6 +94,7 @@ private:
     int* d_token_ = nullptr;        // device scalar: id of the token being decoded
     int* h_token_ = nullptr;        // pinned mirror of the argmax result
     float* argmax_scratch_ = nullptr;
+    float* rope_inv_freq_ = nullptr; // [hd/2] 1/powf(theta, 2i/hd), computed once on the host (rotary.cu:47)
     void* stream_ = nullptr;
     bool fuse_ = true;
     struct Timed { int cls; void* a; void* b; };

@@ -167,10 +167,10 @@ def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resi
 
 
 def attention_decode_fused(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale,
-                           theta_base, freq_scale=1.0, stream=None):
+                           theta_base, freq_scale=1.0, inv_freq=None, stream=None):
     check(_lib.lib().ntk_attention_decode_fused(_p(output), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(d_pos),
-                                                n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale,
-                                                stream), "attention_decode_fused")
+                                                _p(inv_freq), n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base,
+                                                freq_scale, stream), "attention_decode_fused")
 
 
 def embed_rows(out, table, tokens, n_tokens, hidden, dtype, stream=None, allow_unsupported=False):

@@ -297,11 +297,11 @@ def test_attention_prefill(T, start):
     assert np.abs(od.numpy() - ref).max() <= 2e-5
 
 
-@pytest.mark.parametrize("pos", [0, 1, 63, 300])
-@pytest.mark.parametrize("nh,nkv,hd", [(32, 8, 128), (4, 2, 64)])
-def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd):
+@pytest.mark.parametrize("pos", [0, 1, 15, 16, 63, 300, 2047])
+@pytest.mark.parametrize("nh,nkv,hd,table", [(32, 8, 128, True), (32, 8, 128, False), (4, 2, 64, True), (64, 8, 128, True), (6, 3, 80, False)])
+def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd, table):
     r = rng(pos + nh)
-    max_seq = 512
+    max_seq = 2048 if pos >= 512 else 512
     kc, vc = make_cache(r, pos, max_seq, nkv, hd)
     q = r.standard_normal(nh * hd).astype(np.float32)
     k = r.standard_normal(nkv * hd).astype(np.float32)
@@ -314,8 +314,12 @@ def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd):
     ref = O.attention_decode(rq, kc_ref, vc_ref, pos + 1, nh, nkv, hd, max_seq, scale)
     kcd, vcd = DB.from_numpy(kc), DB.from_numpy(vc)
     od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+    inv = None
+    if table:   # the engine's host-computed table: 1/powf(theta, 2i/hd) in float32 (reference rotary.cu:47)
+        i = np.arange(hd // 2, dtype=np.float32)
+        inv = DB.from_numpy((np.float32(1.0) / np.power(np.float32(theta), (np.float32(2.0) * i) / np.float32(hd))).astype(np.float32))
     ops.attention_decode_fused(od, DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v), kcd, vcd,
-                               DB.from_numpy(np.array([pos], np.int32)), nh, nkv, hd, max_seq, scale, theta)
+                               DB.from_numpy(np.array([pos], np.int32)), nh, nkv, hd, max_seq, scale, theta, inv_freq=inv)
     assert np.abs(od.numpy() - ref).max() <= 3e-5
     # the stored row: V bit-exact; K within one half-precision ulp (device vs glibc sin/cos)
     assert np.array_equal(vcd.numpy(np.uint16), vc_ref)
