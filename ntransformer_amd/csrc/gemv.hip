@@ -616,9 +616,7 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     // waves per workgroup = ns * rw ~ 8: one x prologue feeds eight row streams
     static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
     static const int env_ablate = [] { const char* e = getenv("NTK_GEMV_ABLATE"); return e ? atoi(e) : 0; }();
-    // 3-waves-per-SIMD formats (12 waves per CU): 6-wave workgroups so that two fit; the others 8-wave
-    const int waves = std::min(env_waves, F::MINW == 3 ? 6 : 8);
-    p.rw = std::max(1, waves / p.ns);
+    p.rw = std::max(1, env_waves / p.ns);   // (6-wave workgroups for the 3-waves/SIMD formats measured 30 % slower)
     p.ablate = env_ablate;
     const int nwaves = p.ns * p.rw;
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
