@@ -75,8 +75,9 @@ int  nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, fl
  * sync per token); generated ids to out[n] (may be NULL) */
 int  nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int* out);
 /* one fused token launched eagerly with a HIP event pair around each launch on the compute stream:
- * ms3/calls3[0] quantised GEMV launches, [1] attention, [2] embedding + argmax + position */
-int  nt_engine_profile_token(nt_engine_t e, int token, int pos, float* ms3, int* calls3);
+ * ms4/calls4[0] quantised GEMV launches, [1] attention, [2] embedding + argmax + position, [3] mean duration of an
+ * empty event pair (measurement overhead to subtract per launch) */
+int  nt_engine_profile_token(nt_engine_t e, int token, int pos, float* ms4, int* calls4);
 int  nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int out_cap);   /* returns count */
 int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int out_cap);       /* returns bytes */
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */

@@ -422,7 +422,25 @@ int Model::decode_step_fused(bool greedy, bool use_graph) {
     return hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(slot), st) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
 }
 
-int Model::profile_token(float ms[3], int calls[3]) {
+int Model::profile_token(float ms[4], int calls[4]) {
+    // calibration: back-to-back event pairs with nothing in between measure the cost of the measurement itself
+    {
+        float tot = 0.0f;
+        int n = 0;
+        for (int i = 0; i < 16; ++i) {
+            void* a = ntk_event_create();
+            void* b = ntk_event_create();
+            ntk_event_record(a, stream_);
+            ntk_event_record(b, stream_);
+            ntk_event_synchronize(b);
+            float m = 0.0f;
+            if (ntk_event_elapsed_ms(a, b, &m) == NTK_OK && i >= 4) { tot += m; ++n; }
+            ntk_event_destroy(a);
+            ntk_event_destroy(b);
+        }
+        ms[3] = n ? tot / n : 0.0f;
+        calls[3] = n;
+    }
     std::vector<Timed> rec;
     rec.reserve(1024);
     prof_ = &rec;

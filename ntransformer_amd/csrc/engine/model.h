@@ -60,8 +60,9 @@ public:
     uint64_t bytes_per_token(int pos) const;
     void set_fuse(bool on) { fuse_ = on; }
     // One fused token launched eagerly with a HIP event pair around every launch on the compute stream.
-    // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos).
-    int profile_token(float ms[3], int calls[3]);
+    // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos);
+    // ms[3] = mean duration of an EMPTY event pair (the cost of the measurement itself), calls[3] = pairs averaged.
+    int profile_token(float ms[4], int calls[4]);
     void* stream() const { return stream_; }
 
 private:

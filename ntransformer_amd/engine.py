@@ -166,7 +166,7 @@ class Engine:
         return list(out[:n])
 
     def profile_token(self, token: int, pos: int):
-        ms, calls = (C.c_float * 3)(), (C.c_int * 3)()
+        ms, calls = (C.c_float * 4)(), (C.c_int * 4)()
         self._check(self.L.nt_engine_profile_token(self.h, int(token), pos, ms, calls), "profile_token")
         return list(ms), list(calls)
 
