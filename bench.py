@@ -149,18 +149,24 @@ def main():
     if rank == 0:
         tok_s = world * args.steps / elapsed
         b_tok = eng.bytes_per_token(pos + args.steps // 2)
-        # ---- roofline of the dominant kernel: event pairs around every launch of a few eagerly launched tokens
-        ms, calls = [0.0, 0.0, 0.0, 0.0], [0, 0, 0, 0]
-        n_prof = 4
-        for i in range(n_prof):
-            m_, c_ = eng.profile_token(out[-1] if out else tok, min(pos_end + i, args.ctx - 1))
-            ms = [a + b for a, b in zip(ms, m_)]
-            calls = [a + b for a, b in zip(calls, c_)]
+        # ---- roofline of the dominant kernel, measured live with HIP events on the compute stream over a few eagerly
+        # launched tokens.  `coarse`: one event per run of GEMV launches (o, gate|up, down, next qkv between two attention
+        # launches), so the events' own cost (~2 us each) is paid once per 4 launches; `fine` (an event pair per launch,
+        # reads ~2 us high per launch) is reported beside it.  rocprofv3's kernel trace of this command is in profiles/.
+        def prof(coarse, n_prof=4):
+            ms, calls = [0.0] * 4, [0] * 4
+            for i in range(n_prof):
+                m_, c_ = eng.profile_token(out[-1] if out else tok, min(pos_end + i, args.ctx - 1), coarse)
+                ms = [a + b for a, b in zip(ms, m_)]
+                calls = [a + b for a, b in zip(calls, c_)]
+            return [m / n_prof for m in ms], [c / n_prof for c in calls]
+        ms, calls = prof(True)
+        ms_fine, calls_fine = prof(False)
         gemv_bytes_tok = _gemv_bytes_per_token(eng, spec, args.mix)
-        launches_tok = calls[0] / n_prof
-        pair_overhead_ms = ms[3] / n_prof          # an empty event pair: the cost of the measurement itself
-        avg_launch_ms = max(ms[0] / max(calls[0], 1) - pair_overhead_ms, 1e-6)
+        launches_tok = calls[0]
+        avg_launch_ms = ms[0] / max(calls[0], 1)
         achieved = (gemv_bytes_tok / max(launches_tok, 1)) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic, traffic_src = _pmc_traffic(args)
         line = {
             "metric": "decode tokens/sec (Llama-3.1-8B Q8_0 class, resident weights, greedy, batch 1)" if (args.model, args.mix) == ("8b", "Q8_0")
                       else "decode tokens/sec (%s %s, resident weights, greedy, batch 1)" % (args.model, args.mix),
@@ -177,12 +183,12 @@ def main():
             "hbm_fraction_of_8TBs_end_to_end": round(b_tok * tok_s / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": {"bound": "hbm", "kernel": "gemv_quant_kernel<%s> (all projection launches of a token pooled)" % args.mix,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": int(gemv_bytes_tok / max(launches_tok, 1)), "launches_per_token": launches_tok,
-                         "avg_launch_us": round(avg_launch_ms * 1e3, 2), "avg_launch_us_raw_event_pair": round(ms[0] / max(calls[0], 1) * 1e3, 2),
-                         "event_pair_overhead_us": round(pair_overhead_ms * 1e3, 2),
-                         "token_ms_by_class_eager": {"gemv": round(ms[0] / n_prof, 4), "attention": round(ms[1] / n_prof, 4),
-                                                     "other": round(ms[2] / n_prof, 4)}},
+                         "avg_launch_us": round(avg_launch_ms * 1e3, 2),
+                         "avg_launch_us_event_pair_per_launch": round(ms_fine[0] / max(calls_fine[0], 1) * 1e3, 2),
+                         "timed_runs_per_token": calls[3],
+                         "token_ms_by_class_eager": {"gemv": round(ms[0], 4), "attention": round(ms[1], 4), "other": round(ms[2], 4)}},
         }
         if not args.no_cpu_baseline:
             try:
@@ -194,6 +200,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pmc_traffic(args):
+    """HBM bytes per GEMV launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs of this
+    command, decode window, gfx950 x2 correction on FETCH_SIZE: tools/pmc_summary.py -> profiles/pmc_traffic.json).
+    PMC collection needs rocprofv3 around the process, so the number is read back, not measured in this run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    key = "%s_%s" % (args.model, args.mix.lower())
+    try:
+        g = json.load(open(path))[key]["ntk::gemv_quant_kernel"]
+        return int(g["fetch_bytes_per_launch"] + g["write_bytes_per_launch_raw"]), "profiles/pmc_traffic.json[%s]" % key
+    except Exception:
+        return None, None
 
 
 def _gemv_bytes_per_token(eng, spec, mix):

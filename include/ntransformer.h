@@ -74,10 +74,11 @@ int  nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, fl
 /* n greedy decode steps from (token, pos): exactly the timed inner loop of generate (device argmax, one host
  * sync per token); generated ids to out[n] (may be NULL) */
 int  nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int* out);
-/* one fused token launched eagerly with a HIP event pair around each launch on the compute stream:
- * ms4/calls4[0] quantised GEMV launches, [1] attention, [2] embedding + argmax + position, [3] mean duration of an
- * empty event pair (measurement overhead to subtract per launch) */
-int  nt_engine_profile_token(nt_engine_t e, int token, int pos, float* ms4, int* calls4);
+/* one fused token launched eagerly and timed with HIP events on the compute stream:
+ * ms4/calls4[0] quantised GEMV launches, [1] attention, [2] embedding + argmax + position; calls4[3] = timed intervals.
+ * coarse = 0: an event pair around every launch; coarse = 1: one event per change of launch class (a run of GEMV
+ * launches is timed as a whole: event cost paid once per run, the boundaries inside a run included) */
+int  nt_engine_profile_token(nt_engine_t e, int token, int pos, int coarse, float* ms4, int* calls4);
 int  nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int out_cap);   /* returns count */
 int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int out_cap);       /* returns bytes */
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */

@@ -72,8 +72,7 @@ __device__ void attend(float* out, const float* qs, const uint16_t* kc, const ui
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s = fmaf(qreg[j], kf[j], s);
             }
-#pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            s = group_sum<LPR>(s);
             if (part_i == 0 && pos < n_cache) sc[pos] = s * scale;
         }
     } else {
@@ -288,8 +287,7 @@ __global__ __launch_bounds__(256) void attention_decode_fused_v2_kernel(
         float sc = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
-#pragma unroll
-        for (int off = LPR / 2; off > 0; off >>= 1) sc += __shfl_xor(sc, off, 64);
+        sc = group_sum<LPR>(sc);
         sc *= scale;
         const float mn = fmaxf(m, sc);
         const float a = expf(m - mn), pw = expf(sc - mn);

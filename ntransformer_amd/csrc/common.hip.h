@@ -30,15 +30,54 @@ __device__ __forceinline__ uint16_t f2h(float f) {
     return bits;
 }
 
-// ---- wave64 reductions: every lane ends with the full result ---------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// ---- wave64 reductions on the DPP path (no LDS traffic, ~6 dependent VALU ops instead of six ds_bpermute round
+//      trips): quad swaps, half-row and row mirrors leave every lane of a 16-lane row with the row total;
+//      row_bcast:15 / row_bcast:31 then chain the four rows, so the wave total lands in lanes 48..63. ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v) {   // lanes outside ROW_MASK (or without a source lane) read 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_self(float v) {   // ... read their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+constexpr int DPP_QUAD_1032 = 0xB1, DPP_QUAD_2301 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140,
+              DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+// total in lane 63 only (cheapest form: the caller stores from lane 63)
+__device__ __forceinline__ float wave_sum_lane63(float v) {
+    v += dpp_or_zero<DPP_QUAD_1032, 0xF>(v);
+    v += dpp_or_zero<DPP_QUAD_2301, 0xF>(v);
+    v += dpp_or_zero<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    v += dpp_or_zero<DPP_ROW_MIRROR, 0xF>(v);
+    v += dpp_or_zero<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_or_zero<DPP_ROW_BCAST31, 0xC>(v);
     return v;
 }
+// every lane ends with the full result (v_readlane_b32 of lane 63)
+__device__ __forceinline__ float wave_sum(float v) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_lane63(v)), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    v = fmaxf(v, dpp_or_self<DPP_QUAD_1032, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<DPP_QUAD_2301, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<DPP_ROW_HALF_MIRROR, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<DPP_ROW_MIRROR, 0xF>(v));
+    v = fmaxf(v, dpp_or_self<DPP_ROW_BCAST15, 0xA>(v));
+    v = fmaxf(v, dpp_or_self<DPP_ROW_BCAST31, 0xC>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// sum over aligned groups of N consecutive lanes (N = 2..32), result in every lane of the group; DPP up to a
+// 16-lane row, one ds_bpermute for the 32-lane step
+template <int N>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32, "group size");
+    if constexpr (N >= 2) v += dpp_or_zero<DPP_QUAD_1032, 0xF>(v);
+    if constexpr (N >= 4) v += dpp_or_zero<DPP_QUAD_2301, 0xF>(v);
+    if constexpr (N >= 8) v += dpp_or_zero<DPP_ROW_HALF_MIRROR, 0xF>(v);
+    if constexpr (N >= 16) v += dpp_or_zero<DPP_ROW_MIRROR, 0xF>(v);
+    if constexpr (N >= 32) v += __shfl_xor(v, 16, 64);
     return v;
 }
 

@@ -135,14 +135,14 @@ int nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int*
     return E(e)->decode_greedy_steps(token, pos, n, out);
 }
 
-int nt_engine_profile_token(nt_engine_t e, int token, int pos, float* ms4, int* calls4) {
+int nt_engine_profile_token(nt_engine_t e, int token, int pos, int coarse, float* ms4, int* calls4) {
     if (!e || !ms4 || !calls4 || !E(e)->loaded()) return NTK_E_NULL;
     nt::Model& m = E(e)->model();
     if (pos < 0 || pos >= m.config().max_seq_len) return NTK_E_SHAPE;
     m.set_device_pos(pos);
     const int rc = m.set_device_token(token);
     if (rc != NTK_OK) return rc;
-    return m.profile_token(ms4, calls4);
+    return m.profile_token(ms4, calls4, coarse != 0);
 }
 
 int nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int cap) {

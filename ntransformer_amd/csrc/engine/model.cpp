@@ -307,12 +307,24 @@ int Model::enqueue_token(bool greedy) {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     void* s = stream_;
-    // profiling hook: an event pair around one launch (only inside profile_token(), never while capturing)
+    // profiling hook (only inside profile_token(), never while capturing).  Fine mode: an event pair around every
+    // launch.  Coarse mode: ONE event where the launch class changes -- a run of same-class launches is timed as a
+    // whole (its kernels and the boundaries between them), so the cost of the events is paid once per run.
     auto mark = [&](int cls, bool begin) {
         if (!prof_) return;
+        if (prof_coarse_) {
+            if (!begin) return;
+            if (!prof_->empty() && prof_->back().cls == cls) { ++prof_->back().n; return; }
+            void* e = ntk_event_create();
+            ntk_event_record(e, s);
+            const bool shared = !prof_->empty();
+            if (shared) prof_->back().b = e;
+            prof_->push_back({cls, e, nullptr, 1, shared});
+            return;
+        }
         void* e = ntk_event_create();
         ntk_event_record(e, s);
-        if (begin) prof_->push_back({cls, e, nullptr}); else prof_->back().b = e;
+        if (begin) prof_->push_back({cls, e, nullptr, 1, false}); else prof_->back().b = e;
     };
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
@@ -422,36 +434,28 @@ int Model::decode_step_fused(bool greedy, bool use_graph) {
     return hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(slot), st) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
 }
 
-int Model::profile_token(float ms[4], int calls[4]) {
-    // calibration: back-to-back event pairs with nothing in between measure the cost of the measurement itself
-    {
-        float tot = 0.0f;
-        int n = 0;
-        for (int i = 0; i < 16; ++i) {
-            void* a = ntk_event_create();
-            void* b = ntk_event_create();
-            ntk_event_record(a, stream_);
-            ntk_event_record(b, stream_);
-            ntk_event_synchronize(b);
-            float m = 0.0f;
-            if (ntk_event_elapsed_ms(a, b, &m) == NTK_OK && i >= 4) { tot += m; ++n; }
-            ntk_event_destroy(a);
-            ntk_event_destroy(b);
-        }
-        ms[3] = n ? tot / n : 0.0f;
-        calls[3] = n;
-    }
+int Model::profile_token(float ms[4], int calls[4], bool coarse) {
     std::vector<Timed> rec;
     rec.reserve(1024);
     prof_ = &rec;
+    prof_coarse_ = coarse;
     int rc = enqueue_token(true);
+    if (coarse && !rec.empty()) {   // close the last run
+        void* e = ntk_event_create();
+        ntk_event_record(e, stream_);
+        rec.back().b = e;
+    }
     prof_ = nullptr;
+    prof_coarse_ = false;
     if (rc == NTK_OK) rc = ntk_stream_synchronize(stream_);
-    for (int c = 0; c < 3; ++c) { ms[c] = 0.0f; calls[c] = 0; }
+    for (int c = 0; c < 4; ++c) { ms[c] = 0.0f; calls[c] = 0; }
     for (auto& t : rec) {
         float m = 0.0f;
-        if (t.a && t.b && ntk_event_elapsed_ms(t.a, t.b, &m) == NTK_OK) { ms[t.cls] += m; ++calls[t.cls]; }
-        if (t.a) ntk_event_destroy(t.a);
+        if (t.a && t.b && ntk_event_elapsed_ms(t.a, t.b, &m) == NTK_OK) { ms[t.cls] += m; calls[t.cls] += t.n; }
+        ++calls[3];   // timed intervals
+    }
+    for (auto& t : rec) {   // coarse: record i's `b` is record i+1's `a` -- destroy every event once
+        if (t.a && !t.shared_a) ntk_event_destroy(t.a);
         if (t.b) ntk_event_destroy(t.b);
     }
     return rc;

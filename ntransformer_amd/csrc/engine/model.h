@@ -59,10 +59,11 @@ public:
     // algorithmic bytes one decode token must move at position `pos`
     uint64_t bytes_per_token(int pos) const;
     void set_fuse(bool on) { fuse_ = on; }
-    // One fused token launched eagerly with a HIP event pair around every launch on the compute stream.
-    // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos);
-    // ms[3] = mean duration of an EMPTY event pair (the cost of the measurement itself), calls[3] = pairs averaged.
-    int profile_token(float ms[4], int calls[4]);
+    // One fused token launched eagerly and timed with HIP events on the compute stream.
+    // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos); calls[3] = timed
+    // intervals.  fine (coarse = false): an event pair around every launch.  coarse: one event per change of class, so
+    // a run of GEMV launches is timed as a whole (kernels + the boundaries between them) and the event cost is per run.
+    int profile_token(float ms[4], int calls[4], bool coarse);
     void* stream() const { return stream_; }
 
 private:
@@ -98,7 +99,8 @@ private:
     float* rope_inv_freq_ = nullptr; // [hd/2] 1/powf(theta, 2i/hd), computed once on the host (rotary.cu:47)
     void* stream_ = nullptr;
     bool fuse_ = true;
-    struct Timed { int cls; void* a; void* b; };
+    struct Timed { int cls; void* a; void* b; int n; bool shared_a; };   // n launches between events a and b
+    bool prof_coarse_ = false;
     std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs
     ihipGraphExec_t* graph_greedy_ = nullptr;
     ihipGraphExec_t* graph_logits_ = nullptr;

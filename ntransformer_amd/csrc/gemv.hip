@@ -39,6 +39,12 @@ __device__ __forceinline__ u32x4 asm_load16(const void* base, unsigned off) {
 constexpr int RB = 4;            // rows (items) per batch between cross-wave combines
 constexpr int XPITCH = 68;       // floats per 64-column lane row in the prologue LDS image (conflict-free b128)
 constexpr int MAX_SEG = 3;
+// tuning ablations, compile-time only (make HIPFLAGS+=-DNTK_GEMV_ABLATE=n; profiles/r01_gemv_ablation.txt):
+// 1 = skip the x prologue, 2 = skip the decode, 4 = skip LDS staging.  0 in the product.
+#ifndef NTK_GEMV_ABLATE
+#define NTK_GEMV_ABLATE 0
+#endif
+constexpr int kAblate = NTK_GEMV_ABLATE;
 
 template <int DT> struct Fmt;
 // BW/BB: weights / bytes per GGUF block; NL: 1 KiB chunks per <=4096-column slice (+15 alignment bytes);
@@ -49,6 +55,9 @@ template <> struct Fmt<NTK_DT_Q4_0> { static constexpr int BW = 32, BB = 18, NL 
 template <> struct Fmt<NTK_DT_Q4_K> { static constexpr int BW = 256, BB = 144, NL = 3, MINW = 4; };
 template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, NL = 3, MINW = 3; };
 template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 3; };
+
+// formats that have a 16-byte-aligned fast decoder (others instantiate only the general one)
+template <int DT> constexpr bool A16_OK = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
 
 struct GemvSeg {
     const uint8_t* W;   // 16-byte-aligned-down base of the segment
@@ -73,7 +82,6 @@ struct GemvParams {
     const float* resid;
     int silu_pair;
     unsigned row_bytes;
-    int ablate;         // tuning ablations (env NTK_GEMV_ABLATE): 1 = skip the x prologue, 2 = skip the decode, 4 = skip LDS staging
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -82,7 +90,8 @@ struct GemvParams {
 //   ncols : how many of the lane's 64 columns exist (0, 32 or 64)
 //   xr    : the lane's activations, sx16/sx32 their run sums
 // ------------------------------------------------------------------------------------------------
-template <int DT> struct Dot;
+// A16: every LDS offset the decoder touches is 16-byte aligned (K-quant rows whose bytes start 16-byte aligned)
+template <int DT, bool A16> struct Dot;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // two FMAs per instruction (v_pk_fma_f32): the dot products are VALU-issue bound for the 4/5/6-bit formats
@@ -96,7 +105,7 @@ __device__ __forceinline__ float hsum(f32x2 a, f32x2 b) { return (a.x + a.y) + (
 
 // x2[i] = (x[2i], x[2i+1]) of the lane's 64 columns
 
-template <> struct Dot<NTK_DT_Q8_0> {   // reference gemm.cu:129-141: sum += d * sum_j q_j x_j
+template <bool A16> struct Dot<NTK_DT_Q8_0, A16> {   // reference gemm.cu:129-141: sum += d * sum_j q_j x_j
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&)[2]) {
         float acc = 0.0f;
@@ -121,7 +130,7 @@ template <> struct Dot<NTK_DT_Q8_0> {   // reference gemm.cu:129-141: sum += d *
     }
 };
 
-template <> struct Dot<NTK_DT_Q4_0> {   // reference gemm.cu:60-75: w_j = d (lo-8), w_{j+16} = d (hi-8)
+template <bool A16> struct Dot<NTK_DT_Q4_0, A16> {   // reference gemm.cu:60-75: w_j = d (lo-8), w_{j+16} = d (hi-8)
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {
         float acc = 0.0f;
@@ -136,7 +145,7 @@ template <> struct Dot<NTK_DT_Q4_0> {   // reference gemm.cu:60-75: w_j = d (lo-
                 f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t lo = opaque(q[i] & 0x0F0F0F0Fu), hi = opaque((q[i] >> 4) & 0x0F0F0F0Fu);
+                    const uint32_t lo = opaque(q[i] & 0x0F0F0F0Fu), hi = opaque(q[i] & 0xF0F0F0F0u);   // hi bytes = 16 n, x pre-scaled
                     a0 = pkfma(ub01(lo), x2[16 * h + 2 * i], a0);
                     a1 = pkfma(ub23(lo), x2[16 * h + 2 * i + 1], a1);
                     a0 = pkfma(ub01(hi), x2[16 * h + 8 + 2 * i], a0);
@@ -150,41 +159,58 @@ template <> struct Dot<NTK_DT_Q4_0> {   // reference gemm.cu:60-75: w_j = d (lo-
 };
 
 // K-quant header: d, dmin and the 6-bit (scale, min) pairs of sub-blocks 2c, 2c+1 (types.h:112-117, gemm.cu:206-222).
-// Branch-free in the lane-constant c: bytes 0-3 / 4-7 / 8-11 of the 12 packed bytes are the dwords s0 / s1 / s2.
+// Branch-free in the lane-constant c.  The 12 packed bytes are the dwords s0 / s1 / s2; all eight scales (mins) are
+// first laid out as the bytes of two dwords each -- sub-blocks 0..3: s0 & 0x3F (s1 & 0x3F); sub-blocks 4..7:
+// (s2 & 0x0F) | ((s0 >> 6) << 4)   ((s2 >> 4) | ((s1 >> 6) << 4)) -- then one select and one shift pick the pair.
+template <bool A16>
 __device__ __forceinline__ void kq_header(const uint8_t* st, int ob, int c, float& d1, float& m1, float& d2, float& m2) {
     uint32_t hd[4];
-    lds_read_dwords<4>(hd, st, ob);
+    if constexpr (A16) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(st + ob);
+        hd[0] = v.x; hd[1] = v.y; hd[2] = v.z; hd[3] = v.w;
+    } else {
+        lds_read_dwords<4>(hd, st, ob);
+    }
     const float d = h2f((uint16_t)(hd[0] & 0xFFFFu)), dmin = h2f((uint16_t)(hd[0] >> 16));
     const uint32_t s0 = hd[1], s1 = hd[2], s2 = hd[3];
-    const bool upper = c >= 2;                       // sub-blocks 4..7 keep their top 2 bits in bytes 0..7
-    const int sh = 16 * (c & 1);                     // byte (2c & 3) of a dword, then byte + 1
-    uint32_t sc[2], mn[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int b = sh + 8 * t;
-        const uint32_t lo_s = (s0 >> b) & 63u, lo_m = (s1 >> b) & 63u;
-        const uint32_t hi_s = ((s2 >> b) & 0xFu) | (((s0 >> (b + 6)) & 3u) << 4);
-        const uint32_t hi_m = ((s2 >> (b + 4)) & 0xFu) | (((s1 >> (b + 6)) & 3u) << 4);
-        sc[t] = upper ? hi_s : lo_s;
-        mn[t] = upper ? hi_m : lo_m;
-    }
-    d1 = d * (float)sc[0]; m1 = dmin * (float)mn[0];
-    d2 = d * (float)sc[1]; m2 = dmin * (float)mn[1];
+    const uint32_t sc_lo = s0 & 0x3F3F3F3Fu, mn_lo = s1 & 0x3F3F3F3Fu;
+    const uint32_t sc_hi = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
+    const uint32_t mn_hi = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
+    const bool upper = c >= 2;
+    const int sh = 16 * (c & 1);
+    const uint32_t sc = (upper ? sc_hi : sc_lo) >> sh, mn = (upper ? mn_hi : mn_lo) >> sh;
+    d1 = d * ub2f(sc, 0); m1 = dmin * ub2f(mn, 0);
+    d2 = d * ub2f(sc, 1); m2 = dmin * ub2f(mn, 1);
 }
 
-template <> struct Dot<NTK_DT_Q4_K> {   // reference gemm.cu:190-244
+// N dwords at a 16-byte aligned LDS offset (A16) or at any even offset
+template <int N, bool A16>
+__device__ __forceinline__ void lds_read_q(uint32_t (&dst)[N], const uint8_t* st, int off) {
+    if constexpr (A16) {
+        static_assert(N % 4 == 0, "b128 reads");
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(st + off + 16 * i);
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else {
+        lds_read_dwords<N>(dst, st, off);
+    }
+}
+
+template <bool A16> struct Dot<NTK_DT_Q4_K, A16> {   // reference gemm.cu:190-244
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {
         if (ncols <= 0) return 0.0f;
         const int c = lane & 3, ob = shift + 144 * (lane >> 2);
         float d1, m1, d2, m2;
-        kq_header(st, ob, c, d1, m1, d2, m2);
+        kq_header<A16>(st, ob, c, d1, m1, d2, m2);
         uint32_t q[8];
-        lds_read_dwords<8>(q, st, ob + 16 + 32 * c);
+        lds_read_q<8, A16>(q, st, ob + 16 + 32 * c);
         f32x2 l0 = {0.0f, 0.0f}, l1 = {0.0f, 0.0f}, h0 = {0.0f, 0.0f}, h1 = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const uint32_t lo = opaque(q[i] & 0x0F0F0F0Fu), hi = opaque((q[i] >> 4) & 0x0F0F0F0Fu);
+            const uint32_t lo = opaque(q[i] & 0x0F0F0F0Fu), hi = opaque(q[i] & 0xF0F0F0F0u);   // hi bytes = 16 n, x pre-scaled
             l0 = pkfma(ub01(lo), x2[2 * i], l0);
             l1 = pkfma(ub23(lo), x2[2 * i + 1], l1);
             h0 = pkfma(ub01(hi), x2[16 + 2 * i], h0);
@@ -198,19 +224,19 @@ template <> struct Dot<NTK_DT_Q4_K> {   // reference gemm.cu:190-244
     }
 };
 
-template <> struct Dot<NTK_DT_Q5_K> {   // reference gemm.cu:297-354
+template <bool A16> struct Dot<NTK_DT_Q5_K, A16> {   // reference gemm.cu:297-354
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {
         if (ncols <= 0) return 0.0f;
         const int c = lane & 3, ob = shift + 176 * (lane >> 2);
         float d1, m1, d2, m2;
-        kq_header(st, ob, c, d1, m1, d2, m2);
+        kq_header<A16>(st, ob, c, d1, m1, d2, m2);
         f32x2 l0 = {0.0f, 0.0f}, l1 = {0.0f, 0.0f}, h0 = {0.0f, 0.0f}, h1 = {0.0f, 0.0f};
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {   // two 16-byte halves: keeps the live dword count low
             uint32_t qh[4], ql[4];
-            lds_read_dwords<4>(qh, st, ob + 16 + 16 * hh);
-            lds_read_dwords<4>(ql, st, ob + 48 + 32 * c + 16 * hh);
+            lds_read_q<4, A16>(qh, st, ob + 16 + 16 * hh);
+            lds_read_q<4, A16>(ql, st, ob + 48 + 32 * c + 16 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const uint32_t lo = opaque((ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c)) & 0x01010101u) << 4));
@@ -229,7 +255,7 @@ template <> struct Dot<NTK_DT_Q5_K> {   // reference gemm.cu:297-354
     }
 };
 
-template <> struct Dot<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (block, half, t): groups g = 2t, 2t+1
+template <bool A16> struct Dot<NTK_DT_Q6_K, A16> {   // reference gemm.cu:421-459; lane = (block, half, t): groups g = 2t, 2t+1
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&sx16)[4], const float (&)[2]) {
         if (ncols <= 0) return 0.0f;
@@ -270,7 +296,7 @@ template <> struct Dot<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (bl
 //   [0, A)   prologue x (+ norm weight) image, afterwards nwaves * STAGE wave-private byte images
 //   [A, ..)  partial sums [2][rw][ns][RB] + 16 floats reduction scratch
 // ------------------------------------------------------------------------------------------------
-template <int DT, bool NORM, bool XFAST>
+template <int DT, bool NORM, bool XFAST, bool A16>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     const int mats = p.silu_pair ? 2 : 1;
     const int n_my = (p.total_rows > group) ? ((p.total_rows - 1 - group) / ngroups + 1) * mats : 0;
 
-    // item q of this wave -> (segment, row inside the segment); q < n_my
+    // item q of this wave -> (segment, row inside the segment); q < n_my  (per-lane form, used by the combine step)
     auto locate = [&](int q, int& seg, int& row) {
         int r = group + (q / mats) * ngroups;
         if (p.silu_pair) { seg = q & 1; row = r; return; }
@@ -309,21 +335,38 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
         while (seg + 1 < p.nseg && r >= p.seg[seg].rows) { r -= p.seg[seg].rows; ++seg; }
         row = r;
     };
+    // The wave walks its items in order, so the location is kept as a cursor (scalar registers) and advanced
+    // incrementally: one add and one compare per row instead of a search through the segment table.
+    int cu_seg = 0, cu_row = group, cu_rows = p.silu_pair ? 0x7fffffff : p.seg[0].rows;   // cursor = next item to issue
+    auto cursor_normalise = [&]() {
+        while (cu_seg + 1 < p.nseg && cu_row >= cu_rows) { cu_row -= cu_rows; ++cu_seg; cu_rows = p.seg[cu_seg].rows; }
+    };
+    if (!p.silu_pair) cursor_normalise();
+    auto cursor_advance = [&]() {
+        if (p.silu_pair) {
+            if (cu_seg == 0) { cu_seg = 1; } else { cu_seg = 0; cu_row += ngroups; }
+        } else {
+            cu_row += ngroups;
+            cursor_normalise();
+        }
+    };
 
     u32x4 pf[NL];
-    auto issue = [&](int q) {
-        int seg, row;
-        if (n_my > 0) locate(q, seg, row); else { seg = 0; row = 0; }
-        const size_t rel = (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + slice_byte0;
-        const unsigned nbytes = (unsigned)(rel & 15) + slice_bytes;
+    int pf_seg = 0, pf_row = 0, pf_shift = 0;   // what the bytes in pf[] belong to
+    auto issue = [&]() {   // prefetch the item under the cursor (rows * row_bytes < 4 GiB: checked on the host)
+        pf_seg = cu_seg; pf_row = cu_row;
+        const unsigned rel = (unsigned)p.seg[cu_seg].delta + (unsigned)cu_row * p.row_bytes + slice_byte0;
+        pf_shift = (int)(rel & 15u);
+        const unsigned nbytes = (rel & 15u) + slice_bytes;
         const unsigned last = (nbytes - 1u) & ~15u;
-        const uint8_t* a = p.seg[seg].W + (rel & ~(size_t)15);
+        const uint8_t* a = p.seg[cu_seg].W + (rel & ~15u);
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const unsigned off = min(16u * (unsigned)(lane + 64 * j), last);
             pf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + off));
         }
     };
+    if (n_my <= 0) { cu_seg = 0; cu_row = 0; }   // a wave without rows still prefetches (row 0): keeps the prologue branch-free
 
     // ---- prologue: this lane's 64 activations into registers (through a padded LDS image: coalesced
     //      global reads, conflict-free ds_read_b128), optional RMSNorm (reference rmsnorm.cu:16-70) ----
@@ -367,7 +410,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 #pragma unroll
                 for (int i = 0; i < WIT; ++i) wv[i] = asm_load16(p.norm_w, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
             }
-            issue(0);   // unconditional (a wave without rows re-reads row 0): keeps this block free of branches
+            issue();   // unconditional (a wave without rows re-reads row 0): keeps this block free of branches
             asm volatile("s_waitcnt vmcnt(%c8)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]) : "i"(NL));
             if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));   // older than the wait above: landed too
             __builtin_amdgcn_sched_barrier(0);
@@ -415,9 +458,9 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
                 if (s >= g0 && s < g0 + GS) read_own_row(g0);
             }
         } else {   // unaligned / odd sizes (and the NTK_GEMV_ABLATE=1 experiment): plain loops
-            if (n_my > 0) issue(0);
+            issue();
             float rms_inv = 1.0f;
-            if (NORM && !(p.ablate & 1)) {
+            if (NORM && !(kAblate & 1)) {
                 float ssq = 0.0f;
                 for (int c = tid; c < p.in; c += blockDim.x) ssq = fmaf(p.x[c], p.x[c], ssq);
                 ssq = wave_sum(ssq);
@@ -430,7 +473,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
             for (int g0 = 0; g0 < p.ns; g0 += GS) {
                 const int cbeg = g0 * p.slice_cols, cend = min(p.in, (g0 + GS) * p.slice_cols);
                 if (g0 > 0) __syncthreads();
-                if (!(p.ablate & 1)) {
+                if (!(kAblate & 1)) {
                     for (int c = cbeg + tid; c < cend; c += blockDim.x)
                         ximg[img_index(c, g0)] = NORM ? p.x[c] * rms_inv * p.norm_w[c] : p.x[c];
                 }
@@ -438,7 +481,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
                 if (s >= g0 && s < g0 + GS) read_own_row(g0);
             }
         }
-        if (p.ablate & 1) {
+        if (kAblate & 1) {
 #pragma unroll
             for (int j = 0; j < 32; ++j) x2[j] = f32x2{1.0f, 1.0f};
         }
@@ -454,6 +497,16 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     }
     sx32[0] = sx16[0] + sx16[1];
     sx32[1] = sx16[2] + sx16[3];
+    // 4-bit formats: the high nibbles are used in place (byte value 16 n, one v_and instead of shift + and), so the
+    // activations of those columns carry the factor 1/16 -- a power of two: every product and sum is unchanged
+    if constexpr (DT == NTK_DT_Q4_K) {
+#pragma unroll
+        for (int j = 16; j < 32; ++j) x2[j] *= 0.0625f;
+    }
+    if constexpr (DT == NTK_DT_Q4_0) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if ((j & 8) != 0) x2[j] *= 0.0625f;   // pairs 8..15 of each 16: columns 16..31 of a block
+    }
     float gate_carry = 0.0f;
 
     // cross-slice combine of one batch (ns > 1): wave s == 0 of each row group sums the ns partials of
@@ -483,23 +536,20 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     // All loads / LDS writes are unpredicated (lanes past the slice end re-read its last chunk) so the loop
     // body is straight-line code: hipcc then waits for the prefetch exactly once, right before the ds_writes.
     for (int q = 0; q < n_my; ++q) {
-        int seg, row;
-        locate(q, seg, row);
-        const size_t rel = (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + slice_byte0;
-        const int shift = (int)(rel & 15);
+        const int seg = pf_seg, row = pf_row, shift = A16 ? 0 : pf_shift;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            if (p.ablate & 4) { asm volatile("" ::"v"(pf[j])); continue; }
+            if (kAblate & 4) { asm volatile("" ::"v"(pf[j])); continue; }
             *reinterpret_cast<u32x4*>(stage + 16 * (lane + 64 * j)) = pf[j];
         }
         __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
-        if (q + 1 < n_my) issue(q + 1);    // next row's bytes fly while this one is decoded
-        const float acc = (p.ablate & 2) ? x2[0].x + (float)q : Dot<DT>::run(stage, shift, lane, ncols, x2, sx16, sx32);
+        if (q + 1 < n_my) { cursor_advance(); issue(); }   // next row's bytes fly while this one is decoded
+        const float acc = (kAblate & 2) ? x2[0].x + (float)q : Dot<DT, A16>::run(stage, shift, lane, ncols, x2, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
-        const float tot = wave_sum(acc);
+        const float tot = wave_sum_lane63(acc);   // valid in lane 63
 
         if (p.ns == 1) {
-            if (lane == 0) {
+            if (lane == 63) {
                 if (p.silu_pair) {
                     if ((q & 1) == 0) gate_carry = tot;
                     else p.seg[0].y[row] = gate_carry / (1.0f + expf(-gate_carry)) * tot;   // reference gemm.cu:719-724
@@ -511,7 +561,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
             }
         } else {
             const int b = q / RB, i = q % RB;
-            if (lane == 0) part[(size_t)(b & 1) * p.rw * p.ns * RB + (size_t)(g * p.ns + s) * RB + i] = tot;
+            if (lane == 63) part[(size_t)(b & 1) * p.rw * p.ns * RB + (size_t)(g * p.ns + s) * RB + i] = tot;
             if (i == RB - 1) {
                 __syncthreads();
                 combine(b, RB);
@@ -615,9 +665,7 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     if (p.ns > 8 || (long)(p.ns - 1) * p.slice_cols >= in) return NTK_E_SHAPE;   // in_features > 32768 not supported
     // waves per workgroup = ns * rw ~ 8: one x prologue feeds eight row streams
     static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
-    static const int env_ablate = [] { const char* e = getenv("NTK_GEMV_ABLATE"); return e ? atoi(e) : 0; }();
     p.rw = std::max(1, env_waves / p.ns);   // (6-wave workgroups for the 3-waves/SIMD formats measured 30 % slower)
-    p.ablate = env_ablate;
     const int nwaves = p.ns * p.rw;
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? 1 : 0;
@@ -637,23 +685,32 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     constexpr int STAGE = F::NL * 1024 + 64;
     const size_t regionA = (size_t)std::max(nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
     const size_t lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
+    // fast prologue: aligned x / norm weights, whole float4s, norm weights fit the 4 register slots per thread
+    const bool xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(kAblate & 1) && (!norm_w || in <= 4 * 4 * 64 * nwaves);
+    // A16 (K-quants whose blocks are multiples of 16 bytes): every row slice starts 16-byte aligned -> b128 LDS reads,
+    // no v_alignbyte.  True for every GGUF tensor (data offsets are 32-byte aligned); the general form covers the rest.
+    bool a16 = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
+    for (int i = 0; i < nseg; ++i) a16 = a16 && p.seg[i].delta == 0;
+    using KernelFn = void (*)(const GemvParams);
+    static const KernelFn table[2][2][2] = {
+        {{gemv_quant_kernel<DT, false, false, false>, gemv_quant_kernel<DT, false, false, A16_OK<DT>>},
+         {gemv_quant_kernel<DT, false, true, false>, gemv_quant_kernel<DT, false, true, A16_OK<DT>>}},
+        {{gemv_quant_kernel<DT, true, false, false>, gemv_quant_kernel<DT, true, false, A16_OK<DT>>},
+         {gemv_quant_kernel<DT, true, true, false>, gemv_quant_kernel<DT, true, true, A16_OK<DT>>}}};
     if (lds > 64 * 1024) {   // 28672-wide rows: the activation image alone is 119 KiB
         static bool once = [] {
             bool ok = true;
-            for (const void* f : {(const void*)gemv_quant_kernel<DT, false, false>, (const void*)gemv_quant_kernel<DT, false, true>,
-                                  (const void*)gemv_quant_kernel<DT, true, false>, (const void*)gemv_quant_kernel<DT, true, true>})
-                ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b)
+                    for (int c = 0; c < 2; ++c)
+                        ok = ok && hipFuncSetAttribute((const void*)table[a][b][c], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       160 * 1024) == hipSuccess;
             return ok;
         }();
         if (!once || lds > 160 * 1024) return NTK_E_SHAPE;
     }
-    // fast prologue: aligned x / norm weights, whole float4s, norm weights fit the 4 register slots per thread
-    const bool xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(p.ablate & 1) && (!norm_w || in <= 4 * 4 * 64 * nwaves);
     const dim3 g(grid), b(64 * nwaves);
-    if (norm_w && xfast) hipLaunchKernelGGL((gemv_quant_kernel<DT, true, true>), g, b, lds, st, p);
-    else if (norm_w) hipLaunchKernelGGL((gemv_quant_kernel<DT, true, false>), g, b, lds, st, p);
-    else if (xfast) hipLaunchKernelGGL((gemv_quant_kernel<DT, false, true>), g, b, lds, st, p);
-    else hipLaunchKernelGGL((gemv_quant_kernel<DT, false, false>), g, b, lds, st, p);
+    hipLaunchKernelGGL(table[norm_w ? 1 : 0][xfast ? 1 : 0][a16 ? 1 : 0], g, b, lds, st, p);
     return last_launch_status();
 }
 

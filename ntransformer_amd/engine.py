@@ -77,7 +77,7 @@ def _bind():
     L.nt_synth_tensor.argtypes = [C.POINTER(SynthSpec), C.c_char_p, vp, C.c_size_t, i]
     L.nt_synth_tensor.restype = C.c_int64
     L.nt_engine_decode_greedy_steps.argtypes = [vp, i, i, i, C.POINTER(i)]
-    L.nt_engine_profile_token.argtypes = [vp, i, i, C.POINTER(f), C.POINTER(i)]
+    L.nt_engine_profile_token.argtypes = [vp, i, i, i, C.POINTER(f), C.POINTER(i)]
     L._engine_bound = True
     return L
 
@@ -165,9 +165,11 @@ class Engine:
         self._check(self.L.nt_engine_decode_greedy_steps(self.h, int(token), pos, n, out), "decode_greedy_steps")
         return list(out[:n])
 
-    def profile_token(self, token: int, pos: int):
+    def profile_token(self, token: int, pos: int, coarse: bool = True):
+        """One eager fused token timed with HIP events; see nt_engine_profile_token (coarse: one event per run of
+        same-class launches)."""
         ms, calls = (C.c_float * 4)(), (C.c_int * 4)()
-        self._check(self.L.nt_engine_profile_token(self.h, int(token), pos, ms, calls), "profile_token")
+        self._check(self.L.nt_engine_profile_token(self.h, int(token), pos, 1 if coarse else 0, ms, calls), "profile_token")
         return list(ms), list(calls)
 
     def stats(self) -> Stats:
