@@ -104,6 +104,9 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // ---- byte-granular LDS reads: the staged weight stream keeps GGUF's 2-byte alignment -----------------
+// gfx950 does execute ds_read_b32/b128 at any byte address (hipcc emits them for a 2-byte-aligned pointer), but
+// measured on MI355X the misaligned wide reads are slower than aligned dwords + v_alignbyte_b32 (Q8_0 GEMVs lost
+// 10-14 %), so a block's dwords are assembled from aligned reads.
 // 4 bytes at any even offset: two aligned dwords + v_alignbyte_b32
 __device__ __forceinline__ uint32_t lds_u32_at(const uint8_t* base, int off) {
     const int a = off & ~3;

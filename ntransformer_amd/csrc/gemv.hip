@@ -53,8 +53,8 @@ template <int DT> struct Fmt;
 template <> struct Fmt<NTK_DT_Q8_0> { static constexpr int BW = 32, BB = 34, NL = 5, MINW = 4; };
 template <> struct Fmt<NTK_DT_Q4_0> { static constexpr int BW = 32, BB = 18, NL = 3, MINW = 4; };
 template <> struct Fmt<NTK_DT_Q4_K> { static constexpr int BW = 256, BB = 144, NL = 3, MINW = 4; };
-template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, NL = 3, MINW = 3; };
-template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 3; };
+template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, NL = 3, MINW = 4; };
+template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 4; };
 
 // formats that have a 16-byte-aligned fast decoder (others instantiate only the general one)
 template <int DT> constexpr bool A16_OK = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
@@ -239,8 +239,11 @@ template <bool A16> struct Dot<NTK_DT_Q5_K, A16> {   // reference gemm.cu:297-35
             lds_read_q<4, A16>(ql, st, ob + 48 + 32 * c + 16 * hh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t lo = opaque((ql[i] & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c)) & 0x01010101u) << 4));
-                const uint32_t hi = opaque(((ql[i] >> 4) & 0x0F0F0F0Fu) | (((qh[i] >> (2 * c + 1)) & 0x01010101u) << 4));
+                // rotate right by 2c - 4: bit 2c of every qh byte lands on bit 4, bit 2c + 1 on bit 5 (what wraps in from the
+                // neighbouring byte falls outside the masks)
+                const uint32_t r = __builtin_amdgcn_alignbit(qh[i], qh[i], (uint32_t)((2 * c + 28) & 31));
+                const uint32_t lo = opaque((ql[i] & 0x0F0F0F0Fu) | (r & 0x10101010u));
+                const uint32_t hi = opaque(((ql[i] >> 4) & 0x0F0F0F0Fu) | ((r >> 1) & 0x10101010u));
                 l0 = pkfma(ub01(lo), x2[8 * hh + 2 * i], l0);
                 l1 = pkfma(ub23(lo), x2[8 * hh + 2 * i + 1], l1);
                 h0 = pkfma(ub01(hi), x2[16 + 8 * hh + 2 * i], h0);
@@ -255,25 +258,34 @@ template <bool A16> struct Dot<NTK_DT_Q5_K, A16> {   // reference gemm.cu:297-35
     }
 };
 
-template <bool A16> struct Dot<NTK_DT_Q6_K, A16> {   // reference gemm.cu:421-459; lane = (block, half, t): groups g = 2t, 2t+1
+// Q6_K (reference gemm.cu:421-459).  lane = (block, half hf, t).  Within a half the 128 weights are
+//   q1: ql[l] & 15 | (qh[l] & 3) << 4 -> column l          q3: ql[l] >> 4 | ((qh[l] >> 4) & 3) << 4 -> column 64 + l
+//   q2: ql[32+l] & 15 | ((qh[l] >> 2) & 3) << 4 -> 32 + l   q4: ql[32+l] >> 4 | ((qh[l] >> 6) & 3) << 4 -> 96 + l
+// so lane t takes the 32 bytes ql[32t .. 32t+31] whole: their LOW nibbles are columns 32t + l (q1 / q2), their HIGH
+// nibbles columns 64 + 32t + l (q3 / q4), with the 2-bit tops at bits 2t and 4 + 2t of qh[l].  The lane's activations
+// are loaded to match (kernel: read_own_row): x2[0..15] = columns 128hf + 32t + [0,32), x2[16..31] = the same + 64.
+// Seven VALU ops turn one ql dword + one qh dword into 8 weights; sub-scale index = l/16 + {2t, 4 + 2t}.
+template <bool A16> struct Dot<NTK_DT_Q6_K, A16> {
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&sx16)[4], const float (&)[2]) {
         if (ncols <= 0) return 0.0f;
         const int t = lane & 1, hf = (lane >> 1) & 1, ob = shift + 210 * (lane >> 2);
-        const uint32_t scw = lds_u32_at(st, ob + 192 + 8 * hf + 4 * t);   // sc[is + 2gg], bytes: (gg0,is0)(gg0,is1)(gg1,is0)(gg1,is1)
+        uint32_t scd[2];
+        lds_read_dwords<2>(scd, st, ob + 192 + 8 * hf);                    // the half's 8 int8 sub-scales
+        const uint32_t sc_lo = scd[0] >> (16 * t), sc_hi = scd[1] >> (16 * t);   // bytes 0,1: is = 0,1
         const float d = h2f(lds_u16_at(st, ob + 208));
-        float S[4];   // [gg*2 + is]
+        float S[4];   // [type * 2 + is]
 #pragma unroll
-        for (int is = 0; is < 2; ++is) {   // the two 16-column runs of each group (sub-scale index is)
-            uint32_t A[4], B[4], H[4];
-            lds_read_dwords<4>(A, st, ob + 64 * hf + 16 * is);
-            lds_read_dwords<4>(B, st, ob + 64 * hf + 32 + 16 * is);
+        for (int is = 0; is < 2; ++is) {   // the two 16-column runs of each type (sub-scale index is)
+            uint32_t A[4], H[4];
+            lds_read_dwords<4>(A, st, ob + 64 * hf + 32 * t + 16 * is);
             lds_read_dwords<4>(H, st, ob + 128 + 32 * hf + 16 * is);
             f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f}, b0 = {0.0f, 0.0f}, b1 = {0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const uint32_t qa = opaque(((A[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t)) & 0x03030303u) << 4));
-                const uint32_t qb = opaque(((B[i] >> (4 * t)) & 0x0F0F0F0Fu) | (((H[i] >> (4 * t + 2)) & 0x03030303u) << 4));
+                const uint32_t hs = H[i] >> (2 * t);
+                const uint32_t qa = opaque((A[i] & 0x0F0F0F0Fu) | ((hs & 0x03030303u) << 4));
+                const uint32_t qb = opaque(((A[i] >> 4) & 0x0F0F0F0Fu) | (hs & 0x30303030u));
                 a0 = pkfma(ub01(qa), x2[8 * is + 2 * i], a0);
                 a1 = pkfma(ub23(qa), x2[8 * is + 2 * i + 1], a1);
                 b0 = pkfma(ub01(qb), x2[16 + 8 * is + 2 * i], b0);
@@ -283,10 +295,10 @@ template <bool A16> struct Dot<NTK_DT_Q6_K, A16> {   // reference gemm.cu:421-45
             S[2 + is] = hsum(b0, b1);
         }
         // sum (q-32) x = sum q x - 32 sum x, per 16-column run, times the run's int8 sub-scale
-        float bs = sb2f(scw, 0) * fmaf(-32.0f, sx16[0], S[0]);
-        bs = fmaf(sb2f(scw, 1), fmaf(-32.0f, sx16[1], S[1]), bs);
-        bs = fmaf(sb2f(scw, 2), fmaf(-32.0f, sx16[2], S[2]), bs);
-        bs = fmaf(sb2f(scw, 3), fmaf(-32.0f, sx16[3], S[3]), bs);
+        float bs = sb2f(sc_lo, 0) * fmaf(-32.0f, sx16[0], S[0]);
+        bs = fmaf(sb2f(sc_lo, 1), fmaf(-32.0f, sx16[1], S[1]), bs);
+        bs = fmaf(sb2f(sc_hi, 0), fmaf(-32.0f, sx16[2], S[2]), bs);
+        bs = fmaf(sb2f(sc_hi, 1), fmaf(-32.0f, sx16[3], S[3]), bs);
         return d * bs;
     }
 };
@@ -393,10 +405,17 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
         const int dummy = (int)(lds_floats_total - 16);   // 16 spare floats at the end of the allocation
         const bool have_lo = ncols > 0, have_hi = ncols > 32;   // ncols is 0, 32 or 64: two masks, not 64 compares
         auto read_own_row = [&](int g0) {
+            // image row r = the 64 columns [64r, 64r+64) of the slice.  A lane owns row `lane`, except for Q6_K where it
+            // owns columns 32t + [0,32) of rows (lane & ~1) and (lane | 1) (see Dot<Q6_K>)
             const float* xrow = ximg + ((s - g0) * 64 + lane) * XPITCH;
+            const float* xr0 = xrow, *xr1 = xrow + 32;
+            if constexpr (DT == NTK_DT_Q6_K) {
+                xr0 = ximg + ((s - g0) * 64 + (lane & ~1)) * XPITCH + 32 * (lane & 1);
+                xr1 = xr0 + XPITCH;
+            }
 #pragma unroll
             for (int j = 0; j < 64; j += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(xrow + j);
+                const float4 v = *reinterpret_cast<const float4*>((j < 32 ? xr0 : xr1 - 32) + j);
                 const bool have = j < 32 ? have_lo : have_hi;
                 x2[j / 2] = f32x2{have ? v.x : 0.0f, have ? v.y : 0.0f};
                 x2[j / 2 + 1] = f32x2{have ? v.z : 0.0f, have ? v.w : 0.0f};
