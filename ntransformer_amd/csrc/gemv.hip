@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 
     // item q of this wave -> (segment, row inside the segment); q < n_my  (per-lane form, used by the combine step)
     auto locate = [&](int q, int& seg, int& row) {
-        int r = group + (q / mats) * ngroups;
+        int r = group + (q >> (mats - 1)) * ngroups;   // mats is 1 or 2
         if (p.silu_pair) { seg = q & 1; row = r; return; }
         seg = 0;
         while (seg + 1 < p.nseg && r >= p.seg[seg].rows) { r -= p.seg[seg].rows; ++seg; }
@@ -365,8 +365,14 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 
     u32x4 pf[NL];
     int pf_seg = 0, pf_row = 0, pf_shift = 0;   // what the bytes in pf[] belong to
+    float pf_res = 0.0f;                         // residual of that row (ns == 1): fetched a row ahead, not in the epilogue
     auto issue = [&]() {   // prefetch the item under the cursor (rows * row_bytes < 4 GiB: checked on the host)
         pf_seg = cu_seg; pf_row = cu_row;
+        if (p.resid != nullptr && p.ns == 1) {
+            int idx = cu_row;
+            asm volatile("" : "+v"(idx));   // a vector load: a scalar one would sit in lgkmcnt in front of the LDS reads
+            pf_res = p.resid[idx];
+        }
         const unsigned rel = (unsigned)p.seg[cu_seg].delta + (unsigned)cu_row * p.row_bytes + slice_byte0;
         pf_shift = (int)(rel & 15u);
         const unsigned nbytes = (rel & 15u) + slice_bytes;
@@ -530,6 +536,14 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 
     // cross-slice combine of one batch (ns > 1): wave s == 0 of each row group sums the ns partials of
     // item i in slice order and applies the epilogue; `cnt` items of batch b are valid
+    float res_pf = 0.0f;
+    auto prefetch_resid = [&](int b) {   // ns > 1: the combining wave fetches batch b's residuals one batch ahead
+        if (p.resid == nullptr || s != 0 || lane >= RB || b * RB + lane >= n_my) return;
+        int seg, row;
+        locate(b * RB + lane, seg, row);
+        res_pf = p.resid[row];
+    };
+    if (p.ns > 1) prefetch_resid(0);
     auto combine = [&](int b, int cnt) {
         if (s != 0) return;
         const float* pg = part + (size_t)(b & 1) * p.rw * p.ns * RB + (size_t)(g * p.ns) * RB;
@@ -544,10 +558,11 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
                 if ((lane & 1) == 0) p.seg[0].y[row] = t / (1.0f + expf(-t)) * nxt;
             } else {
                 float v = t;
-                if (p.resid != nullptr && seg == 0) v = p.resid[row] + v;
+                if (p.resid != nullptr && seg == 0) v = res_pf + v;
                 p.seg[seg].y[row] = v;
             }
         }
+        prefetch_resid(b + 1);
     };
 
     // ---- row streaming ---------------------------------------------------------------------------
@@ -556,6 +571,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     // body is straight-line code: hipcc then waits for the prefetch exactly once, right before the ds_writes.
     for (int q = 0; q < n_my; ++q) {
         const int seg = pf_seg, row = pf_row, shift = A16 ? 0 : pf_shift;
+        const float res = pf_res;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             if (kAblate & 4) { asm volatile("" ::"v"(pf[j])); continue; }
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
                     else p.seg[0].y[row] = gate_carry / (1.0f + expf(-gate_carry)) * tot;   // reference gemm.cu:719-724
                 } else {
                     float v = tot;
-                    if (p.resid != nullptr && seg == 0) v = p.resid[row] + v;             // reference elementwise.cu:23-32
+                    if (p.resid != nullptr && seg == 0) v = res + v;                      // reference elementwise.cu:23-32
                     p.seg[seg].y[row] = v;
                 }
             }
