@@ -160,6 +160,13 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale,
                                void* stream);
 
+/* Batched prompt projection on the matrix cores (replaces the per-token launch_gemv loops of
+ * attention.cpp:144-162,200-210 and ffn.cpp:96-133):  Y[t,:] = W . X[t,:] (+ resid[t,:]) for t < n_tokens.
+ * X [n_tokens][in] and Y/resid [n_tokens][out] are F32, token-major; W raw GGUF blocks [out][in] (quantised dtypes
+ * only); X 16-byte aligned.  W is streamed once per 16 tokens; F32 activations, F32 MFMA accumulate.  resid may == Y. */
+int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features,
+                   int weight_dtype, const float* resid, void* stream);
+
 /* Dequantise rows of a (quantised) embedding table on the device: out[t,:] = table[tokens[t],:].
  * Same arithmetic as the host loop in reference src/model/transformer.cpp:419-599; Q5_K is zero-filled
  * exactly as the reference does (:595-598).  tokens is a DEVICE int array. */

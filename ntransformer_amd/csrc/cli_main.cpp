@@ -25,6 +25,7 @@ static void usage(const char* prog) {
             "  -v, --verbose            Verbose output\n"
             "  -h, --help               Show this help\n"
             "  --no-fuse / --no-graph   Use the 15-launch/layer sequence / launch eagerly\n"
+            "  --no-batched-prefill     Prompt tokens one by one (the reference's GEMV loops) instead of 16 per weight pass\n"
             "  --synthetic <shape:mix>  8b|70b|tiny : Q8_0|Q4_K_M|Q6_K|...  seeded synthetic weights, no file\n"
             "Accepted for CLI compatibility, no effect (weights are always resident in 288 GB HBM):\n"
             "  --streaming --draft-model <p> --draft-k <n> --self-spec --early-exit <f> --skip-threshold <f>\n"
@@ -56,7 +57,8 @@ int main(int argc, char** argv) {
         else if (a == "--benchmark") benchmark = true;
         else if (a == "--chat") chat = true;
         else if (a == "-v" || a == "--verbose") cfg.verbose = true;
-        else if (a == "--no-fuse") engine.options().fused = false;
+        else if (a == "--no-fuse") { engine.options().fused = false; engine.options().batched_prefill = false; }
+        else if (a == "--no-batched-prefill") engine.options().batched_prefill = false;
         else if (a == "--no-graph") engine.options().graph = false;
         else if (a == "--synthetic") { if (auto v = val()) synthetic = v; }
         else if (a == "--streaming" || a == "--self-spec" || a == "--requant-q4k") noop(a.c_str());

@@ -51,6 +51,7 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
     if (cfg.verbose) fprintf(stderr, "Prompt tokens: %d\n", stats_.prompt_tokens);
 
     auto t0 = Clock::now();
+    model_.set_batched_prefill(opt_.batched_prefill);
     float* logits = model_.forward(tokens.data(), (int)tokens.size(), 0);
     stats_.prefill_ms = ms_since(t0);
     if (!logits) { err_ = model_.error(); return NTK_E_LAUNCH; }

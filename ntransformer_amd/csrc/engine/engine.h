@@ -37,6 +37,7 @@ using TokenCallback = std::function<bool(const std::string& piece, int token_id)
 struct EngineOptions {
     bool fused = true;            // fused 5-launch/layer decode path (false: the reference's 15-launch sequence)
     bool graph = true;            // replay the fused token from a hipGraph
+    bool batched_prefill = true;  // prompts: one pass over each weight matrix per 16 tokens (false: per-token GEMV loops)
     bool device_sampling = true;  // greedy argmax on the device when temperature <= 0 and repeat_penalty <= 1
     int synth_threads = 0;        // 0 = hardware concurrency
 };

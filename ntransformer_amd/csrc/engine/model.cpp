@@ -246,34 +246,43 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         if (st == NTK_E_DTYPE) fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dtype_name(w.dtype));   // gemm.cu:801-803
         else ok(st);
     };
+    // Y[t] = W . X[t] for the T tokens: one pass over W per 16 tokens on the matrix cores, or the reference's loop
+    const bool batched = batched_prefill_ && T > 1;
+    auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
+        if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
+            ok(ntk_gemm_quant(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s));
+            return;
+        }
+        for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, X + (size_t)t * xstride);
+    };
+    // hidden += W . X (attention.cpp:207 + transformer.cpp:645, ffn.cpp:130 + transformer.cpp:652): the batched
+    // projection adds the residual in its epilogue, the reference sequence goes through residual_ and launch_add_inplace
+    auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
+        if (batched && is_quant(w.dtype) && (size_t)w.out_f == (size_t)H && xstride == (size_t)w.in_f) {
+            ok(ntk_gemm_quant(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s));
+            return;
+        }
+        project(residual_, w, X, H, xstride);
+        ok(ntk_add_inplace(hidden_, residual_, T * H, s));
+    };
     for (int i = 0; i < cfg_.n_layers; ++i) {
         const LayerWeights& L = layers_[i];
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
         ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.attn_norm.ptr, T, H, cfg_.norm_eps, s));
-        for (int t = 0; t < T; ++t) {
-            const float* x = residual_ + (size_t)t * H;
-            gemv(q_buf + (size_t)t * qd, L.wq, x);
-            gemv(k_buf + (size_t)t * kvd, L.wk, x);
-            gemv(v_buf + (size_t)t * kvd, L.wv, x);
-        }
+        project(q_buf, L.wq, residual_, qd, H);
+        project(k_buf, L.wk, residual_, kvd, H);
+        project(v_buf, L.wv, residual_, kvd, H);
         ok(ntk_rope(q_buf, k_buf, positions_, 1, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, s));
         ok(ntk_copy_to_kv_cache(kc, vc, k_buf, v_buf, T, nkv, hd, start_pos, cfg_.max_seq_len, s));
         if (T == 1) ok(ntk_attention_decode(attn_out, q_buf, kc, vc, start_pos + T, nh, nkv, hd, cfg_.max_seq_len, scale, s));
         else ok(ntk_attention_prefill(attn_out, q_buf, kc, vc, T, start_pos, nh, nkv, hd, cfg_.max_seq_len, scale, s));
-        for (int t = 0; t < T; ++t) gemv(residual_ + (size_t)t * H, L.wo, attn_out + (size_t)t * qd);
-        ok(ntk_add_inplace(hidden_, residual_, T * H, s));
+        project_add(L.wo, attn_out, qd);
         ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.ffn_norm.ptr, T, H, cfg_.norm_eps, s));
-        for (int t = 0; t < T; ++t) {
-            const float* x = residual_ + (size_t)t * H;
-            float* g = gate_buf + (size_t)t * I;
-            float* u = up_buf + (size_t)t * I;
-            gemv(g, L.w_gate, x);
-            gemv(u, L.w_up, x);
-            ok(ntk_silu_mul(g, g, u, I, s));
-            gemv(residual_ + (size_t)t * H, L.w_down, g);
-        }
-        ok(ntk_add_inplace(hidden_, residual_, T * H, s));
+        project(gate_buf, L.w_gate, residual_, I, H);
+        project(up_buf, L.w_up, residual_, I, H);
+        ok(ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s));   // per token in the reference (ffn.cpp:127): same elementwise op
+        project_add(L.w_down, gate_buf, I);
         if (rc != NTK_OK) break;
     }
     float* last = hidden_ + (size_t)(T - 1) * H;

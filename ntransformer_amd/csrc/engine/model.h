@@ -58,7 +58,9 @@ public:
     uint64_t weight_bytes() const { return weight_bytes_; }
     // algorithmic bytes one decode token must move at position `pos`
     uint64_t bytes_per_token(int pos) const;
-    void set_fuse(bool on) { fuse_ = on; }
+    // Prompts (seq_len > 1) project all tokens of a chunk with one pass over each weight matrix (ntk_gemm_quant) instead
+    // of the reference's per-token GEMV loops; off = the reference's exact launch sequence.
+    void set_batched_prefill(bool on) { batched_prefill_ = on; }
     // One fused token launched eagerly and timed with HIP events on the compute stream.
     // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos); calls[3] = timed
     // intervals.  fine (coarse = false): an event pair around every launch.  coarse: one event per change of class, so
@@ -98,7 +100,7 @@ private:
     float* argmax_scratch_ = nullptr;
     float* rope_inv_freq_ = nullptr; // [hd/2] 1/powf(theta, 2i/hd), computed once on the host (rotary.cu:47)
     void* stream_ = nullptr;
-    bool fuse_ = true;
+    bool batched_prefill_ = true;
     struct Timed { int cls; void* a; void* b; int n; bool shared_a; };   // n launches between events a and b
     bool prof_coarse_ = false;
     std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs

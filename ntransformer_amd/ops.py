@@ -166,6 +166,12 @@ def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resi
                                     stream), "gemv_fused")
 
 
+def gemm_quant(Y, W, X, n_tokens, out_features, in_features, dtype, resid=None, stream=None):
+    """Y[t,:] = W . X[t,:] (+ resid[t,:]) for a chunk of prompt tokens: one pass over W per 16 tokens (ntk_gemm_quant)."""
+    check(_lib.lib().ntk_gemm_quant(_p(Y), _p(W), _p(X), n_tokens, out_features, in_features, int(dtype), _p(resid),
+                                    stream), "gemm_quant")
+
+
 def attention_decode_fused(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale,
                            theta_base, freq_scale=1.0, inv_freq=None, stream=None):
     check(_lib.lib().ntk_attention_decode_fused(_p(output), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(d_pos),

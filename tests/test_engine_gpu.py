@@ -18,7 +18,7 @@ TOL = 1e-3
 
 def teacher_forced(eng, z, fused, graph):
     prompt, forced = [int(t) for t in z["prompt"]], [int(t) for t in z["forced"]]
-    outs = [eng.forward(prompt, 0)]                       # prefill is always the per-token GEMV loop
+    outs = [eng.forward(prompt, 0)]                       # prefill: batched MFMA GEMM unless batched_prefill=0
     pos = len(prompt)
     fed = forced + [int(t) for t in z["fed"][1 + len(forced):]]   # golden greedy continuation, fed verbatim
     for t in fed:
@@ -28,12 +28,15 @@ def teacher_forced(eng, z, fused, graph):
 
 
 @pytest.mark.parametrize("name,shape,mix", CASES)
-@pytest.mark.parametrize("mode", ["launchers", "fused", "graph"])
+@pytest.mark.parametrize("mode", ["reference", "launchers", "fused", "graph"])
 def test_logits_match_reference_host_code(name, shape, mix, mode, tmp_path):
+    """reference: the reference's exact launch sequence (per-token prompt loop, 15 launches per layer);
+    launchers: batched prompt + 1:1 decode launchers; fused / graph: batched prompt + fused decode."""
     path, z = golden_model(name, shape, mix, tmp_path)
     eng = E.Engine()
     eng.load(path, int(z["ctx"]))
-    got = teacher_forced(eng, z, fused=mode != "launchers", graph=mode == "graph")
+    eng.set_option("batched_prefill", mode != "reference")
+    got = teacher_forced(eng, z, fused=mode in ("fused", "graph"), graph=mode == "graph")
     want = z["logits"]
     assert got.shape == want.shape and np.isfinite(got).all()
     err = np.abs(got - want).max()
@@ -135,3 +138,29 @@ def test_reference_test_gemm_runs_on_the_hip_library():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "SKIP" not in r.stderr and "FAIL" not in r.stderr, r.stderr[-2000:]
     assert r.stderr.count("PASS") == 6, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mix", ["Q8_0", "Q4_K_M", "MIXED"])
+def test_batched_prefill_fills_the_same_kv_cache(mix, tmp_path):
+    """A 37-token prompt (three 16-token chunks, the last ragged) through the batched MFMA projections and through the
+    reference's per-token loops: the logits after the prompt and after eight more teacher-forced tokens (which read the
+    whole KV cache the prompt wrote) agree within the north-star tolerance."""
+    name = "tiny_" + mix.lower()
+    path, z = golden_model(name, G.TINY, mix, tmp_path)
+    r = np.random.Generator(np.random.Philox(key=[20260925, 4242]))
+    prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, 36)]
+    cont = [int(t) for t in r.integers(0, 256, 8)]
+    outs = {}
+    for batched in (0, 1):
+        eng = E.Engine()
+        eng.load(path, int(z["ctx"]))
+        eng.set_option("batched_prefill", batched)
+        lg = [eng.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in cont:
+            lg.append(eng.decode_fused(t, pos, False))
+            pos += 1
+        outs[batched] = np.stack(lg)
+        eng.close()
+    assert np.isfinite(outs[1]).all()
+    assert np.abs(outs[1] - outs[0]).max() <= TOL, np.abs(outs[1] - outs[0]).max()

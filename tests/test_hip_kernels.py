@@ -102,6 +102,77 @@ def test_gemv_unaligned_weights(qname, off):
     assert np.abs(y - ref).max() <= tol_for(ref, in_f)
 
 
+# ------------------------------------------------------------------------------- batched prompt GEMM (MFMA) vs oracle
+def gemm_gpu(Wraw, X, out_f, in_f, dt, w_offset=0, resid=None):
+    T = X.shape[0]
+    Wd = DB(Wraw.nbytes + w_offset + 64)
+    Wd.upload(Wraw, w_offset)
+    Xd = DB.from_numpy(np.ascontiguousarray(X, np.float32))
+    Yd = DB.from_numpy(np.full((T, out_f), np.nan, np.float32) if resid is None else resid.astype(np.float32))
+    ops.gemm_quant(Yd, Wd.at(w_offset), Xd, T, out_f, in_f, dt, resid=Yd if resid is not None else None)
+    ops.synchronize()
+    return Yd.numpy(np.float32).reshape(T, out_f)
+
+
+@pytest.mark.parametrize("qname", sorted(QUANT))
+@pytest.mark.parametrize("T,out_f,in_f", [(1, 3, 256), (2, 64, 512), (5, 257, 1024), (16, 512, 4096), (17, 129, 2048),
+                                          (33, 96, 8192), (7, 40, 14336), (16, 130, 28672)])
+def test_gemm_quant_matches_per_token_oracle(qname, T, out_f, in_f):
+    """ntk_gemm_quant (one pass over W per 16 tokens, F32 MFMA) against the oracle's GEMV applied token by token --
+    what the reference's prefill loop computes (attention.cpp:144-162, ffn.cpp:96-133)."""
+    gt = QUANT[qname]
+    r = rng(T * 1000 + out_f * 7 + in_f + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    dt = G.GGML_TO_DT[gt]
+    ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
+    Y = gemm_gpu(W, X, out_f, in_f, dt)
+    assert np.isfinite(Y).all()
+    assert np.abs(Y - ref).max() <= tol_for(ref, in_f), np.abs(Y - ref).max()
+
+
+@pytest.mark.parametrize("qname", sorted(QUANT))
+@pytest.mark.parametrize("off", [2, 6, 14])
+def test_gemm_quant_unaligned_weights_and_residual(qname, off):
+    gt = QUANT[qname]
+    T, out_f, in_f = 9, 37, 1024
+    r = rng(off + gt + 77)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    R = r.standard_normal((T, out_f)).astype(np.float32)
+    dt = G.GGML_TO_DT[gt]
+    ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
+    assert np.abs(gemm_gpu(W, X, out_f, in_f, dt, w_offset=off) - ref).max() <= tol_for(ref, in_f)
+    assert np.abs(gemm_gpu(W, X, out_f, in_f, dt, w_offset=off, resid=R) - (R + ref)).max() <= tol_for(ref, in_f)   # in place
+
+
+def test_gemm_quant_equals_gemv_kernel_at_full_width():
+    """Same weights, same activations: the MFMA prompt path and the decode GEMV agree to summation-order error at the
+    8B shapes (16 tokens x 4096 -> 1024 rows of Q8_0 and Q4_K)."""
+    for qname in ("Q8_0", "Q4_K", "Q6_K"):
+        gt = QUANT[qname]
+        T, out_f, in_f = 16, 1024, 4096
+        r = rng(5 + gt)
+        W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+        X = r.standard_normal((T, in_f)).astype(np.float32)
+        dt = G.GGML_TO_DT[gt]
+        Y = gemm_gpu(W, X, out_f, in_f, dt)
+        for t in (0, 7, 15):
+            y = gemv_gpu(W, X[t], out_f, in_f, dt)
+            assert np.abs(Y[t] - y).max() <= tol_for(y, in_f)
+
+
+def test_gemm_quant_rejects_bad_arguments():
+    W, X, Y = DB.zeros(1 << 16), DB.zeros(1 << 16), DB.zeros(1 << 16)
+    from ntransformer_amd import _lib
+    L = _lib.lib()
+    assert L.ntk_gemm_quant(Y.ptr, W.ptr, X.ptr, 2, 4, 100, G.DT_Q8_0, None, None) == -2       # in not a multiple of the block
+    assert L.ntk_gemm_quant(Y.ptr, W.ptr, X.ptr, 2, 4, 256, 0, None, None) == -1                # dense F32: not a block format
+    assert L.ntk_gemm_quant(Y.ptr, W.ptr + 1, X.ptr, 2, 4, 256, G.DT_Q4_K, None, None) == -4    # odd address
+    assert L.ntk_gemm_quant(None, W.ptr, X.ptr, 2, 4, 256, G.DT_Q4_K, None, None) == -5
+    assert L.ntk_gemm_quant(Y.ptr, W.ptr, X.ptr, 0, 4, 256, G.DT_Q4_K, None, None) == 0         # empty is fine
+
+
 @pytest.mark.parametrize("gt,in_f", [(G.GGML_F32, 3), (G.GGML_F32, 1000), (G.GGML_F16, 1000), (G.GGML_F16, 4096), (G.GGML_F32, 4096)])
 def test_gemv_dense(gt, in_f):
     out_f = 45

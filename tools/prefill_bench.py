@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Prompt-processing benchmark: (a) ntk_gemm_quant at the Llama-3.1 8B / 70B projection shapes, 16 tokens per pass,
+against the per-token GEMV loop it replaces; (b) the engine's prompt pass (Engine.forward over T prompt tokens) with
+batched_prefill on / off on the 8B-shaped synthetic model.
+usage: python tools/prefill_bench.py [--mix Q8_0] [--json out.json]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntransformer_amd import _lib, engine as E, gguf as G, ops  # noqa: E402
+from ntransformer_amd.ops import DeviceBuffer as DB  # noqa: E402
+
+SHAPES = {"8b.q/o": (4096, 4096), "8b.kv": (1024, 4096), "8b.gate/up": (14336, 4096), "8b.down": (4096, 14336),
+          "70b.q/o": (8192, 8192), "70b.gate/up": (28672, 8192), "70b.down": (8192, 28672)}
+GT = {"Q8_0": G.GGML_Q8_0, "Q4_K": G.GGML_Q4_K, "Q6_K": G.GGML_Q6_K}
+
+
+def timed(fn, reps):
+    L = _lib.lib()
+    fn(); ops.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    ops.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mix", default="Q8_0")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--no-engine", action="store_true")
+    a = ap.parse_args()
+    ops.init(0)
+    rng = np.random.default_rng(0)
+    res = {"gemm": [], "engine": []}
+    T = 16
+    for dname, gt in GT.items():
+        dt = G.GGML_TO_DT[gt]
+        for sname, (out_f, in_f) in SHAPES.items():
+            rb = G.row_bytes(gt, in_f)
+            W = DB.from_numpy(rng.integers(0, 60, out_f * rb, dtype=np.uint8))
+            X = DB.from_numpy(rng.standard_normal((T, in_f)).astype(np.float32))
+            Y = DB.zeros(T * out_f * 4)
+            t_gemm = timed(lambda: ops.gemm_quant(Y, W, X, T, out_f, in_f, dt), 20)
+            def loop():
+                for t in range(T): ops.launch_gemv(Y.at(4 * t * out_f), W, X.at(4 * t * in_f), out_f, in_f, dt)
+            t_loop = timed(loop, 5)
+            mb = out_f * rb / 1e6
+            row = {"dtype": dname, "shape": sname, "MB": round(mb, 2), "gemm_us": round(t_gemm * 1e6, 1), "gemv_loop_us": round(t_loop * 1e6, 1),
+                   "weights_per_s_T": round(out_f * in_f / t_gemm / 1e12, 2), "weight_GBps": round(mb / t_gemm / 1e3, 1),
+                   "TFLOPs": round(2.0 * T * out_f * in_f / t_gemm / 1e12, 1)}
+            res["gemm"].append(row)
+            print("%-5s %-12s %8.2f MB  gemm(16 tok) %8.1f us = %6.1f GB/s of weights, %5.1f TFLOP/s | 16 x gemv %8.1f us  (x%.1f)"
+                  % (dname, sname, mb, row["gemm_us"], row["weight_GBps"], row["TFLOPs"], row["gemv_loop_us"], t_loop / t_gemm), flush=True)
+    if not a.no_engine:
+        eng = E.Engine()
+        eng.load_synthetic(E.synth_spec("8b", a.mix), 4096)
+        r = np.random.Generator(np.random.Philox(key=[20260925, 99]))
+        for T, modes in ((16, (1, 0)), (64, (1, 0)), (256, (1,)), (1024, (1,))):
+            prompt = [128000] + [int(t) for t in r.integers(0, 128000, T - 1)]
+            for batched in modes:
+                eng.set_option("batched_prefill", batched)
+                eng.forward(prompt, 0)
+                t0 = time.perf_counter(); eng.forward(prompt, 0); dt_ = time.perf_counter() - t0
+                res["engine"].append({"mix": a.mix, "prompt_tokens": T, "batched": batched, "ms": round(dt_ * 1e3, 2), "tok_s": round(T / dt_, 1)})
+                print("8B %s prompt of %4d tokens, batched_prefill=%d: %9.2f ms = %9.1f tokens/s" % (a.mix, T, batched, dt_ * 1e3, T / dt_), flush=True)
+        eng.close()
+    if a.json: json.dump(res, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
