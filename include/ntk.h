@@ -160,6 +160,15 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale,
                                void* stream);
 
+/* Long-context form of ntk_attention_decode_fused: `nsplit` workgroups share a head (positions interleaved), partial
+ * softmax states go through `scratch` (ntk_attention_split_scratch_bytes) and a second launch merges them.  Same
+ * arguments and results (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches. */
+size_t ntk_attention_split_scratch_bytes(int n_heads, int head_dim, int nsplit);
+int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache,
+                               void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,
+                               int head_dim, int max_seq, float scale, float theta_base, float freq_scale, int nsplit,
+                               float* scratch, void* stream);
+
 /* Batched prompt projection on the matrix cores (replaces the per-token launch_gemv loops of
  * attention.cpp:144-162,200-210 and ffn.cpp:96-133):  Y[t,:] = W . X[t,:] (+ resid[t,:]) for t < n_tokens.
  * X [n_tokens][in] and Y/resid [n_tokens][out] are F32, token-major; W raw GGUF blocks [out][in] (quantised dtypes

@@ -313,6 +313,154 @@ __global__ __launch_bounds__(256) void attention_decode_fused_v2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-KV decode attention for long contexts.  One workgroup per head walks the cache
+// serially, so the single-pass kernel above grows with the context (98 us per layer at position 4095, where the
+// whole layer's KV is only 16.8 MB).  Here `nsplit` workgroups share a head: workgroup (head, sp) takes the
+// positions p = (sp * G + g) + k * nsplit * G of group g (interleaved, so every split sees the same load), keeps
+// the same online-softmax state and writes its un-normalised (m, l, acc[hd]) to `part`; a second launch merges
+// the nsplit partial states per head.  RoPE + KV store of the new token as in the single-pass kernel (store: split
+// 0 of the first head of each KV group).  The engine picks single-pass / 8 / 32 splits by position (host side,
+// one hipGraph per regime).
+// part layout: [n_heads][nsplit][hd + 2] = acc[hd], m, l
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void attention_decode_split_kernel(
+    float* __restrict__ part, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
+    int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale) {
+    constexpr int PPW = 64 / LPR, NW = 4, G = NW * PPW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // XCD-aware head order: workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.
+    // blockIdx.x = i -> kv head i % n_kv_heads: with 8 KV heads (every Llama-3 size) all query heads of a KV head, in
+    // all splits, run on ONE XCD, so its cache rows leave HBM once instead of once per query head (measured: 4x HBM
+    // traffic, 23.6 us per layer at position 4095 with the plain order).
+    const int group = n_heads / n_kv_heads;
+    const int kv_head = blockIdx.x % n_kv_heads, head = kv_head * group + blockIdx.x / n_kv_heads;
+    const int sp = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pos = *d_pos;
+    float* qs = lds;              // [hd] post-RoPE query
+    float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
+    float* vx = kx + hd;          // [hd] value of this token, rounded through half
+    float* ms = vx + hd;          // [G] running maxima
+    float* ls = ms + G;           // [G] running sums
+    float* accs = ls + G;         // [G][hd]
+    const int half_dim = hd / 2;
+    const size_t stride = (size_t)n_kv_heads * hd;
+    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
+    const bool writer = (head % group == 0) && sp == 0 && pos < max_seq;
+    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
+    const uint16_t* kbase = kc + (size_t)kv_head * hd + 8 * part_i;
+    const uint16_t* vbase = vc + (size_t)kv_head * hd + 8 * part_i;
+    const int step = nsplit * G;
+
+    // the walk is latency-bound (each step jumps nsplit * G cache rows): two positions per step, both prefetched a
+    // step ahead -> four 16-byte rows in flight per lane
+    int p = sp * G + g;
+    u32x4 kraw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, vraw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (p + u * step < pos) {
+            kraw[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(p + u * step) * stride);
+            vraw[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)(p + u * step) * stride);
+        }
+    }
+    for (int i = tid; i < half_dim; i += blockDim.x) {
+        float a = q[(size_t)head * hd + i], b = q[(size_t)head * hd + i + half_dim];
+        float ka = k[(size_t)kv_head * hd + i], kb = k[(size_t)kv_head * hd + i + half_dim];
+        const float freq = inv_freq ? inv_freq[i] : 1.0f / (float)pow((double)theta, (double)((2.0f * i) / hd));
+        const float angle = pos * freq * fscale;
+        const float c = cosf(angle), sn = sinf(angle);
+        qs[i] = a * c - b * sn; qs[i + half_dim] = b * c + a * sn;
+        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);
+        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
+        if (writer) { kc[cache_row + i] = ha; kc[cache_row + i + half_dim] = hb; }
+    }
+    for (int i = tid; i < hd; i += blockDim.x) {
+        const uint16_t hv = f2h(v[(size_t)kv_head * hd + i]);
+        vx[i] = h2f(hv);
+        if (writer) vc[cache_row + i] = hv;
+    }
+    __syncthreads();
+
+    float qreg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
+    float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (; p <= pos; p += 2 * step) {
+        float kf[2][8], vf[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pu = p + u * step;
+            if (pu < pos) {
+                unpack8(kraw[u], kf[u]);
+                unpack8(vraw[u], vf[u]);
+            } else {   // the token being decoded (pu == pos), or past the end (masked below)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kf[u][j] = kx[8 * part_i + j]; vf[u][j] = vx[8 * part_i + j]; }
+            }
+            const int pn = pu + 2 * step;
+            if (pn < pos) {
+                kraw[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
+                vraw[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
+            }
+        }
+        float sc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float t = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t = fmaf(qreg[j], kf[u][j], t);
+            sc[u] = group_sum<LPR>(t) * scale;
+        }
+        if (p + step > pos) sc[1] = -INFINITY;   // no second position in this step
+        const float mn = fmaxf(m, fmaxf(sc[0], sc[1]));
+        const float a = expf(m - mn), pw0 = expf(sc[0] - mn), pw1 = expf(sc[1] - mn);
+        l = fmaf(l, a, pw0 + pw1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, fmaf(pw0, vf[0][j], pw1 * vf[1][j]));
+        m = mn;
+    }
+    if (part_i == 0) { ms[g] = m; ls[g] = l; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accs[g * hd + 8 * part_i + j] = acc[j];
+    __syncthreads();
+    float* out = part + ((size_t)head * nsplit + sp) * (hd + 2);
+    float M = ms[0];
+    for (int i = 1; i < G; ++i) M = fmaxf(M, ms[i]);
+    for (int d = tid; d < hd + 1; d += blockDim.x) {
+        float L = 0.0f, o = 0.0f;
+        for (int i = 0; i < G; ++i) {
+            const float w = (ms[i] == -INFINITY) ? 0.0f : expf(ms[i] - M);   // groups (or a whole split) without positions
+            L = fmaf(w, ls[i], L);
+            if (d < hd) o = fmaf(w, accs[i * hd + d], o);
+        }
+        if (d < hd) out[d] = o;
+        else { out[hd] = M; out[hd + 1] = L; }
+    }
+}
+
+__global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __restrict__ output, const float* __restrict__ part,
+                                                                      int hd, int nsplit) {
+    const int head = blockIdx.x;
+    const float* ph = part + (size_t)head * nsplit * (hd + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ph[(size_t)s * (hd + 2) + hd]);
+    for (int d = threadIdx.x; d < hd; d += blockDim.x) {
+        float L = 0.0f, o = 0.0f;
+        for (int s = 0; s < nsplit; ++s) {
+            const float* ps = ph + (size_t)s * (hd + 2);
+            const float w = (ps[hd] == -INFINITY) ? 0.0f : expf(ps[hd] - M);
+            L = fmaf(w, ps[hd + 1], L);
+            o = fmaf(w, ps[d], o);
+        }
+        output[(size_t)head * hd + d] = o / L;
+    }
+}
+
 __global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, const int* __restrict__ positions, int seq_len,
                             int n_heads, int n_kv_heads, int head_dim, float theta, float fscale, int interleaved) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,6 +591,34 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ntk::attention_decode_fused_kernel<0>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, k16, v16, d_pos,
                        n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale);
+    return ntk::last_launch_status();
+}
+
+size_t ntk_attention_split_scratch_bytes(int n_heads, int head_dim, int nsplit) {
+    return (size_t)n_heads * (size_t)nsplit * (size_t)(head_dim + 2) * sizeof(float);
+}
+
+int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
+                               const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                               float scale, float theta_base, float freq_scale, int nsplit, float* scratch, void* stream) {
+    if (!output || !q || !k || !v || !k_cache || !v_cache || !d_pos || !scratch) return NTK_E_NULL;
+    if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || max_seq <= 0 || nsplit < 1 || nsplit > 1024)
+        return NTK_E_SHAPE;
+    if (head_dim != 128 && head_dim != 64 && head_dim != 256) return NTK_E_SHAPE;   // 16-byte row pieces: the engine falls back to the single pass otherwise
+    if ((reinterpret_cast<uintptr_t>(k_cache) & 15) || (reinterpret_cast<uintptr_t>(v_cache) & 15)) return NTK_E_ALIGN;
+    hipStream_t st = ntk::resolve_stream(stream);
+    uint16_t* k16 = static_cast<uint16_t*>(k_cache);
+    uint16_t* v16 = static_cast<uint16_t*>(v_cache);
+    const int G = 4 * (64 / (head_dim / 8));
+    const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
+#define NTK_ATTSP(LPR_) hipLaunchKernelGGL(ntk::attention_decode_split_kernel<LPR_>, dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \
+                                           v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
+    if (head_dim == 128) NTK_ATTSP(16);
+    else if (head_dim == 64) NTK_ATTSP(8);
+    else NTK_ATTSP(32);
+#undef NTK_ATTSP
+    if (ntk::last_launch_status() != NTK_OK) return NTK_E_LAUNCH;
+    hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit);
     return ntk::last_launch_status();
 }
 

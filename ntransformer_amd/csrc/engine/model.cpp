@@ -25,9 +25,11 @@ static bool is_quant(int dt) {
 Model::~Model() { free_all(); }
 
 void Model::free_all() {
-    if (graph_greedy_) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_greedy_));
-    if (graph_logits_) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_logits_));
-    graph_greedy_ = graph_logits_ = nullptr;
+    for (auto& row : graphs_)
+        for (auto& gx : row) {
+            if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx));
+            gx = nullptr;
+        }
     for (void* p : allocs_) nt_hip_free(p);
     allocs_.clear();
     if (h_token_) nt_hip_free_host(h_token_);
@@ -185,6 +187,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_token_ = (int*)dev(64, true);
     argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
+    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
     if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
         !d_pos_ || !d_token_ || !argmax_scratch_ || !h_token_) {
@@ -301,6 +304,7 @@ int Model::set_device_token(int token) {
     return ntk_memcpy_h2d_async(d_token_, h_token_, 4, stream_);
 }
 int Model::set_device_pos(int pos) {
+    host_pos_ = pos;
     // small blocking copy: callers do this once per generation
     nt_hip_memcpy_h2d(d_pos_, &pos, 4);
     return NTK_OK;
@@ -399,8 +403,13 @@ int Model::enqueue_token(bool greedy) {
             NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
         }
         mark(1, true);
-        NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
-                                          cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale, s));
+        if (attn_regime_ == 0)
+            NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
+                                              cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale, s));
+        else
+            NT_TRY(ntk_attention_decode_split(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
+                                              cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale,
+                                              attn_regime_ == 1 ? 8 : 16, attn_scratch_, s));
         mark(1, false);
         NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
@@ -424,9 +433,16 @@ int Model::enqueue_token(bool greedy) {
     return NTK_OK;
 }
 
+void Model::pick_attention_regime() {
+    attn_regime_ = (attn_scratch_ && (cfg_.head_dim == 64 || cfg_.head_dim == 128 || cfg_.head_dim == 256))
+                       ? attention_regime(host_pos_) : 0;
+    ++host_pos_;   // every fused token ends with ntk_advance_pos on the device; set_device_pos() re-bases both
+}
+
 int Model::decode_step_fused(bool greedy, bool use_graph) {
+    pick_attention_regime();
     if (!use_graph) return enqueue_token(greedy);
-    ihipGraphExec_t*& slot = greedy ? graph_greedy_ : graph_logits_;
+    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][attn_regime_];
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
         hipGraph_t g = nullptr;
@@ -448,6 +464,7 @@ int Model::profile_token(float ms[4], int calls[4], bool coarse) {
     rec.reserve(1024);
     prof_ = &rec;
     prof_coarse_ = coarse;
+    pick_attention_regime();
     int rc = enqueue_token(true);
     if (coarse && !rec.empty()) {   // close the last run
         void* e = ntk_event_create();

@@ -47,6 +47,12 @@ public:
     int decode_step_fused(bool greedy, bool use_graph);
     int set_device_token(int token);
     int set_device_pos(int pos);
+    // attention regime by context length: the single-pass kernel walks a head's cache serially (98 us per layer at 4095),
+    // so long contexts split each head over 8 / 32 workgroups (ntk_attention_decode_split)
+    // (measured, tools/attn_bench.py: single pass 9.2 us at 255 / 16.3 at 512 / 97 at 4095; 8 splits 9.3 / 11.5 / 21.8;
+    //  16 splits only pay beyond the 4096-token contexts this engine caps at)
+    static int attention_regime(int pos) { return pos < 320 ? 0 : pos < 8192 ? 1 : 2; }
+    void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)
     float* logits_ptr() { return logits_; }
@@ -104,8 +110,11 @@ private:
     struct Timed { int cls; void* a; void* b; int n; bool shared_a; };   // n launches between events a and b
     bool prof_coarse_ = false;
     std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs
-    ihipGraphExec_t* graph_greedy_ = nullptr;
-    ihipGraphExec_t* graph_logits_ = nullptr;
+    // one captured token per (greedy?, attention regime): regime 0 = single-pass attention, 1 = 8 KV splits, 2 = 16
+    ihipGraphExec_t* graphs_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
+    int attn_regime_ = 0;            // regime enqueue_token() emits
+    float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention
 };
 
 }  // namespace nt

@@ -164,3 +164,27 @@ def test_batched_prefill_fills_the_same_kv_cache(mix, tmp_path):
         eng.close()
     assert np.isfinite(outs[1]).all()
     assert np.abs(outs[1] - outs[0]).max() <= TOL, np.abs(outs[1] - outs[0]).max()
+
+
+def test_long_context_decode_uses_split_attention_and_matches_the_1to1_path(tmp_path):
+    """Decode at positions 314..324 crosses the engine's attention regimes (single pass -> 8 KV splits at 320,
+    Model::attention_regime) and 1020..1030 runs well inside the split regime: the fused path (eager and hipGraph) must
+    keep agreeing with the reference's 1:1 launcher sequence on the same KV cache."""
+    path, z = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)   # head_dim 128, GQA 4, context 2048
+    r = np.random.Generator(np.random.Philox(key=[20260925, 777]))
+    for start in (314, 1020):
+        prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, start - 1)]
+        cont = [int(t) for t in r.integers(0, 256, 10)]
+        outs = {}
+        for mode in ("launchers", "fused", "graph"):
+            eng = E.Engine()
+            eng.load(path, 2048)
+            lg = [eng.forward(prompt, 0)]
+            pos = len(prompt)
+            for t in cont:
+                lg.append(eng.forward([t], pos) if mode == "launchers" else eng.decode_fused(t, pos, mode == "graph"))
+                pos += 1
+            outs[mode] = np.stack(lg)
+            eng.close()
+        for mode in ("fused", "graph"):
+            assert np.abs(outs[mode] - outs["launchers"]).max() <= TOL, (start, mode, np.abs(outs[mode] - outs["launchers"]).max())

@@ -400,6 +400,38 @@ def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd, table
     assert np.array_equal(kcd.numpy(np.uint16)[: pos * nkv * hd], kc[: pos * nkv * hd])   # older rows untouched
 
 
+@pytest.mark.parametrize("pos", [0, 1, 15, 300, 1023, 2047, 4095])
+@pytest.mark.parametrize("nh,nkv,hd,nsplit", [(32, 8, 128, 8), (32, 8, 128, 32), (64, 8, 128, 32), (4, 2, 64, 3)])
+def test_attention_decode_split_equals_oracle_and_single_pass(pos, nh, nkv, hd, nsplit):
+    """Split-KV decode attention (long contexts): against the oracle's rope + store + attention and against the single-pass
+    kernel; any number of splits, including more splits than positions."""
+    r = rng(pos * 3 + nh + nsplit)
+    max_seq = 4096 if pos >= 2048 else 2048
+    kc, vc = make_cache(r, pos, max_seq, nkv, hd)
+    q = r.standard_normal(nh * hd).astype(np.float32)
+    k = r.standard_normal(nkv * hd).astype(np.float32)
+    v = r.standard_normal(nkv * hd).astype(np.float32)
+    scale, theta = float(1 / np.sqrt(hd)), 500000.0
+    rq, rk = O.rope(q, k, [pos], nh, nkv, hd, theta)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    O.copy_to_kv_cache(kc_ref, vc_ref, rk, v, 1, nkv, hd, pos, max_seq)
+    ref = O.attention_decode(rq, kc_ref, vc_ref, pos + 1, nh, nkv, hd, max_seq, scale)
+    outs, caches = [], []
+    for split in (True, False):
+        kcd, vcd = DB.from_numpy(kc), DB.from_numpy(vc)
+        od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+        args = (od, DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v), kcd, vcd, DB.from_numpy(np.array([pos], np.int32)),
+                nh, nkv, hd, max_seq, scale, theta)
+        if split: ops.attention_decode_split(*args, nsplit)
+        else: ops.attention_decode_fused(*args)
+        outs.append(od.numpy())
+        caches.append((kcd.numpy(np.uint16), vcd.numpy(np.uint16)))
+    assert np.isfinite(outs[0]).all()
+    assert np.abs(outs[0] - ref).max() <= 3e-5
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-6                       # same math, different merge order
+    assert np.array_equal(caches[0][0], caches[1][0]) and np.array_equal(caches[0][1], caches[1][1])   # identical cache rows
+
+
 # ------------------------------------------------------------------------------- small ops
 def test_elementwise_and_reductions():
     r = rng(3)

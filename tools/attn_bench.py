@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Decode attention (ntk_attention_decode_fused: RoPE + KV store + GQA attention, one launch) by context length, at the
+Llama-3.1 8B / 70B head geometries.  KV bytes per launch = 2 * (pos + 1) * n_kv_heads * head_dim * 2 (each KV head read
+once in the algorithmic count).  hipGraph-timed, 64 launches over 8 rotating layer caches.
+usage: python tools/attn_bench.py [--json out.json]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntransformer_amd import _lib, ops  # noqa: E402
+from ntransformer_amd.ops import DeviceBuffer as DB  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    ops.init(0)
+    L = _lib.lib()
+    HIP = C.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(0)
+    ev0, ev1 = L.ntk_event_create(), L.ntk_event_create()
+    stream = L.ntk_stream(0)
+    res = []
+    for name, nh, nkv, hd in (("8b", 32, 8, 128), ("70b", 64, 8, 128)):
+        max_seq, nl = 4096, 8
+        per = nkv * hd
+        kc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
+        vc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
+        q = DB.from_numpy(rng.standard_normal(nh * hd).astype(np.float32))
+        k = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
+        v = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
+        out = DB.zeros(nh * hd * 4)
+        scratch = DB(int(L.ntk_attention_split_scratch_bytes(nh, hd, 32)))
+        for pos, nsplit in ((16, 1), (128, 1), (255, 1), (256, 4), (256, 8), (512, 1), (512, 8), (1024, 1), (1024, 8), (1024, 16), (2048, 8), (2048, 16), (4095, 1), (4095, 8), (4095, 16), (4095, 32)):
+            dpos = DB.from_numpy(np.array([pos], np.int32))
+            n = 64
+            def launch(i):
+                if nsplit == 1:
+                    ops.attention_decode_fused(out, q, k, v, kc[i % nl], vc[i % nl], dpos, nh, nkv, hd, max_seq, 1.0 / np.sqrt(hd), 500000.0)
+                else:
+                    _lib.check(L.ntk_attention_decode_split(out.ptr, q.ptr, k.ptr, v.ptr, kc[i % nl].ptr, vc[i % nl].ptr, dpos.ptr, None, nh, nkv, hd,
+                                                            max_seq, 1.0 / np.sqrt(hd), 500000.0, 1.0, nsplit, scratch.ptr, None), "split")
+            launch(0); ops.synchronize()
+            graph, gexec = C.c_void_p(), C.c_void_p()
+            assert HIP.hipStreamBeginCapture(C.c_void_p(stream), 1) == 0
+            for i in range(n): launch(i)
+            assert HIP.hipStreamEndCapture(C.c_void_p(stream), C.byref(graph)) == 0
+            assert HIP.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
+            HIP.hipGraphLaunch(gexec, C.c_void_p(stream)); ops.synchronize()
+            L.ntk_event_record(ev0, None); HIP.hipGraphLaunch(gexec, C.c_void_p(stream)); L.ntk_event_record(ev1, None)
+            L.ntk_event_synchronize(ev1)
+            ms = C.c_float(); L.ntk_event_elapsed_ms(ev0, ev1, C.byref(ms))
+            HIP.hipGraphExecDestroy(gexec); HIP.hipGraphDestroy(graph)
+            us = ms.value * 1e3 / n
+            kvb = 2 * (pos + 1) * per * 2
+            res.append({"model": name, "pos": pos, "nsplit": nsplit, "us": round(us, 2), "kv_MB": round(kvb / 1e6, 3), "GBs": round(kvb / us / 1e3, 1)})
+            print("%-4s pos %5d nsplit %2d: %8.2f us per layer (%s), KV %7.3f MB -> %7.1f GB/s"
+                  % (name, pos, nsplit, us, "1 launch" if nsplit == 1 else "2 launches", kvb / 1e6, kvb / us / 1e3), flush=True)
+    if a.json: json.dump(res, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
