@@ -36,7 +36,7 @@ __device__ __forceinline__ u32x4 asm_load16(const void* base, unsigned off) {
     return v;
 }
 
-constexpr int RB = 4;            // rows (items) per batch between cross-wave combines
+constexpr int RB = 4;            // rows (items) per batch between cross-wave combines (8 measured the same)
 constexpr int XPITCH = 68;       // floats per 64-column lane row in the prologue LDS image (conflict-free b128)
 constexpr int MAX_SEG = 3;
 // tuning ablations, compile-time only (make HIPFLAGS+=-DNTK_GEMV_ABLATE=n; profiles/r01_gemv_ablation.txt):
