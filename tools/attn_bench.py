@@ -36,8 +36,8 @@ def main():
         k = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         v = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         out = DB.zeros(nh * hd * 4)
-        scratch = DB(int(L.ntk_attention_split_scratch_bytes(nh, hd, 32)))
-        for pos, nsplit in ((16, 1), (128, 1), (255, 1), (256, 4), (256, 8), (512, 1), (512, 8), (1024, 1), (1024, 8), (1024, 16), (2048, 8), (2048, 16), (4095, 1), (4095, 8), (4095, 16), (4095, 32)):
+        scratch = DB(int(L.ntk_attention_split_scratch_bytes(nh, hd, 64)))
+        for pos, nsplit in ((16, 1), (128, 1), (255, 1), (320, 1), (320, 8), (320, 16), (320, 32), (512, 1), (512, 8), (512, 32), (1024, 1), (1024, 8), (1024, 16), (1024, 32), (2048, 16), (2048, 32), (4095, 1), (4095, 8), (4095, 16), (4095, 32), (4095, 64)):
             dpos = DB.from_numpy(np.array([pos], np.int32))
             n = 64
             def launch(i):
