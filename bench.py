@@ -115,14 +115,21 @@ def main():
     os.environ["NTK_DEVICE"] = str(local_rank)
 
     from ntransformer_amd import replica
-    backend = "nccl" if world > 1 else None      # torch only as rendezvous / barrier / max-reduce plumbing over RCCL
-    dist = replica.init_distributed("nccl", local_rank) if world > 1 else None
+    # torch only as rendezvous / barrier / max-reduce plumbing: replicas exchange no data, so 8 bytes per run go over gloo
+    # (NT_DIST_BACKEND=nccl for RCCL)
+    dist, backend = replica.init_distributed("gloo", local_rank) if world > 1 else (None, None)
 
     import numpy as np
     from ntransformer_amd import _lib
     from ntransformer_amd import engine as E
     L = _lib.lib()
-    _lib.check(L.ntk_device_init(local_rank), "ntk_device_init(%d)" % local_rank)
+    ndev = L.ntk_device_count()
+    dev = local_rank
+    if ndev > 0 and local_rank >= ndev:   # more ranks than GPUs (only ever a test of the multi-rank plumbing): share devices
+        dev = local_rank % ndev
+        print("bench.py: rank %d shares GPU %d (%d visible)" % (rank, dev, ndev), file=sys.stderr)
+    os.environ["NTK_DEVICE"] = str(dev)
+    _lib.check(L.ntk_device_init(dev), "ntk_device_init(%d)" % dev)
 
     spec = E.synth_spec(args.model, args.mix)
     eng = E.Engine()

@@ -25,12 +25,13 @@ WORKER = textwrap.dedent("""
     sys.path.insert(0, %r)
     from ntransformer_amd import replica
     rank, local, world = replica.env_ranks()
-    dist = replica.init_distributed("gloo", local)
+    dist, backend = replica.init_distributed("gloo", local)
+    assert backend == "gloo"
     per_step = 0.01 * (1 + 3 * rank)            # rank 1 is 4x slower: the job runs at its pace
     def run(k):
         time.sleep(per_step * k)
         return k
-    elapsed, rate, res = replica.timed_steps(run, 10, lambda: None, dist, "gloo")
+    elapsed, rate, res = replica.timed_steps(run, 10, lambda: None, dist, backend)
     print(json.dumps({"rank": rank, "elapsed": elapsed, "rate": rate, "mine": replica.shard_requests(7, rank, world)}), flush=True)
     dist.barrier(); dist.destroy_process_group()
 """) % ROOT
