@@ -104,7 +104,9 @@ int ntk_rope(float* q, float* k, const int* positions, int batch_size, int seq_l
 /* launch_softmax / launch_masked_softmax, kernels.h:29-32 (dead in the reference). mask: 1 byte per elt, !=0 keeps */
 int ntk_softmax(float* output, const float* input, int rows, int cols, void* stream);
 int ntk_masked_softmax(float* output, const float* input, const uint8_t* mask, int rows, int cols, void* stream);
-/* launch_gemv, kernels.h:35-37 / gemm.cu:748-805.  y[out] = W[out,in] . x[in]; W raw GGUF blocks. */
+/* launch_gemv, kernels.h:35-37 / gemm.cu:748-805.  y[out] = W[out,in] . x[in]; W raw GGUF blocks (any even address).
+ * The quantised kernels fetch W in aligned 16-byte pieces: the piece holding the first / last byte of the matrix is read
+ * whole (up to 15 bytes either side, inside the same 16-byte line -- never another page); those bytes are not used. */
 int ntk_gemv(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype,
              void* stream);
 /* launch_gemv_add, kernels.h:40-42 / gemm.cu:846-871.  y += W . x, F16 weights only. */
