@@ -22,8 +22,10 @@
 //     than 4096 columns take further K chunks that accumulate into Y (same thread owns an element in every chunk).
 // Bound: MFMA (f32 16x16x4 = 64 FLOP/clk/SIMD): 2 weights/clk/SIMD = 4.9e12 weights/s, the HBM rate of Q8_0 at
 // 5.2 TB/s -- i.e. balanced for Q8_0, compute-bound for the 4-6 bit formats.  T tokens cost one pass for T <= 16.
-// Measured (round 1): 45-65 TFLOP/s of the 157 TFLOP/s bound -- the MFMA phase itself runs at its rate, but the
-// per-tile phases (stage, barrier, dequantise, reduce) are not overlapped with it yet (tools/gpu_gemm_ablate.sh).
+// Measured (round 1): 45-65 TFLOP/s of the 157 TFLOP/s bound.  Cycle trace of a tile round (tools/gemm_trace.py): stage 500,
+// barrier 300, MFMA phase 6000 for the first wave but ~12500 until the last of the 16 waves reaches the next barrier (8192
+// of matrix-pipe work per SIMD: the dequantisation's VALU issue competes with the MFMA issue), partials + reduce 1000.
+// A 32-token form on v_mfma_f32_32x32x2 (twice the matrix work per dequantised value) measured the same time per token.
 #include "common.hip.h"
 #include <algorithm>
 #include <cstdlib>
@@ -39,6 +41,15 @@ constexpr int GM_SLICE = 256;    // columns per wave step
 constexpr int GM_WAVES = 16;      // waves per workgroup = 256-column slices of K handled side by side (one workgroup per CU;
                                   // 8 waves x 2 workgroups measured 10 % slower: more K chunks, the same cost per round)
 constexpr int GM_RPW = GM_ROWS / GM_WAVES;   // tile rows fetched by one wave
+
+// Phase trace (tuning builds only: make HIPFLAGS+=-DNTK_GEMM_TRACE): thread 0 of workgroup 0 records the cycle counter at
+// the phase boundaries of its tiles; read back with ntk_debug_gemm_trace(), printed by tools/gemm_trace.py.
+#ifdef NTK_GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[256];
+#define GM_STAMP() do { if (trace_on && tslot < 256) g_gemm_trace[tslot++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GM_STAMP() do { } while (0)
+#endif
 
 template <int DT> struct GFmt;
 // BW/BB: weights / bytes per block.  PIECES: 16-byte pieces that cover one row's slice bytes at any 2-byte alignment.
@@ -182,6 +193,11 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gemm_quant_mfma_kernel(const Ge
     const int my_tiles = blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int nchunks = (p.nslices + GM_WAVES - 1) / GM_WAVES;
     int parity = 0;
+#ifdef NTK_GEMM_TRACE
+    const bool trace_on = blockIdx.x == 0 && tid == 0;
+    int tslot = 0;
+#endif
+    GM_STAMP();                                                    // kernel entry
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         // ---- this wave's 256-column slice of the chunk; its activations stay in registers for every tile ----------
@@ -217,6 +233,7 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gemm_quant_mfma_kernel(const Ge
             }
         };
         if (my_tiles > 0) issue(blockIdx.x);
+        GM_STAMP();                                                // chunk prologue done (x in registers, first rows requested)
 
         for (int tl = 0; tl < my_tiles; ++tl) {
             const int tile = blockIdx.x + tl * gridDim.x, row0 = tile * GM_ROWS;
@@ -225,7 +242,9 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gemm_quant_mfma_kernel(const Ge
 #pragma unroll
                 for (int j = 0; j < NLR; ++j)
                     *reinterpret_cast<u32x4*>(tile_img + (wave + GM_WAVES * q) * RPITCH + 16 * (lane + 64 * j)) = pf[q][j];
+            GM_STAMP();                                            // rows landed + staged
             __syncthreads();                                       // B1: the tile image is complete
+            GM_STAMP();                                            // past B1
             // what the reduction adds to (residual / earlier K chunks) is requested BEFORE the prefetch: memory returns in
             // order, so waiting for it later must not mean waiting for the next tile's rows
             float base = 0.0f;
@@ -266,17 +285,21 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gemm_quant_mfma_kernel(const Ge
             }
             // ---- cross-wave reduction: D[i][j], i = 4 (lane / 16) + reg, j = lane % 16.  `red` is double-buffered, so the
             //      barrier below is also the one that frees the tile image for the next tile's rows.
+            GM_STAMP();                                            // MFMAs issued
             float* rd = red + parity * (GM_WAVES * 256);
             parity ^= 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) rd[wave * 256 + (4 * g + e) * 16 + tok] = acc0[e] + acc1[e];
+            GM_STAMP();                                            // partials written
             __syncthreads();                                       // B2
+            GM_STAMP();                                            // past B2
             if (owner) {   // chunk 0 writes (adding the residual), later K chunks accumulate: the same thread owns the element
                 float t = 0.0f;
 #pragma unroll
                 for (int w = 0; w < GM_WAVES; ++w) t += rd[w * 256 + tid];
                 p.Y[o] = base + t;
             }
+            GM_STAMP();                                            // reduced + stored
         }
         __syncthreads();   // the last tile's readers are done before the next chunk's first rows are staged
     }
@@ -319,6 +342,12 @@ static int launch_gemm(float* Y, const void* W, const float* X, int T, int out, 
 }
 
 }  // namespace ntk
+
+#ifdef NTK_GEMM_TRACE
+extern "C" int ntk_debug_gemm_trace(unsigned long long* out256) {
+    return hipMemcpyFromSymbol(out256, HIP_SYMBOL(ntk::g_gemm_trace), 256 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features,
                               int weight_dtype, const float* resid, void* stream) {
