@@ -51,6 +51,14 @@ __device__ unsigned long long g_gemm_trace[256];
 #define GM_STAMP() do { } while (0)
 #endif
 
+// tuning ablations, compile-time only (make HIPFLAGS+=-DNTK_GEMM_ABLATE=n, tools/gpu_gemm_ablate.sh): 1 = skip the
+// dequantisation, 2 = VALU FMAs instead of MFMA, 4 = no weight loads after the first tile.  0 in the product: the
+// sub-block loop stays one basic block.
+#ifndef NTK_GEMM_ABLATE
+#define NTK_GEMM_ABLATE 0
+#endif
+constexpr int kGemmAblate = NTK_GEMM_ABLATE;
+
 template <int DT> struct GFmt;
 // BW/BB: weights / bytes per block.  PIECES: 16-byte pieces that cover one row's slice bytes at any 2-byte alignment.
 template <> struct GFmt<NTK_DT_Q8_0> { static constexpr int BW = 32, BB = 34, SB = 272; };
@@ -68,7 +76,6 @@ struct GemmParams {
     int T, out, in;
     unsigned row_bytes;
     int nslices;          // ceil(in / 256)
-    int ablate;           // tuning only (env NTK_GEMM_ABLATE): 1 = skip the dequantisation, 2 = VALU FMAs instead of MFMA, 4 = no weight loads after the first tile
 };
 
 // The 8 weights of (row image `st`, 32-column sub-block s of the slice, column group g) as F32.
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gemm_quant_mfma_kernel(const Ge
             if (owner && (chunk > 0 || p.resid != nullptr)) base = chunk == 0 ? p.resid[o] : p.Y[o];
             // the next tile's rows fly during this tile's MFMAs (unconditional -- the last tile re-reads itself -- so the
             // number of loads behind `base` is static and hipcc can wait with vmcnt(NLR) instead of vmcnt(0))
-            if (!(p.ablate & 4)) issue(tl + 1 < my_tiles ? tile + (int)gridDim.x : tile);
+            if (!(kGemmAblate & 4)) issue(tl + 1 < my_tiles ? tile + (int)gridDim.x : tile);
             f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};   // two chains: an MFMA waits for its accumulator
             if (active) {
                 const unsigned grow = (unsigned)min(row0 + r, p.out - 1);
@@ -264,13 +271,13 @@ __global__ __launch_bounds__(64 * GM_WAVES) void gemm_quant_mfma_kernel(const Ge
                 for (int s = 0; s < 8; ++s) {
                     if (FULL || s < nsub) {
                         float a[8];
-                        if (p.ablate & 1) {
+                        if (kGemmAblate & 1) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) a[j] = 1.0f;
                         } else {
                             Deq<DT>::run(st, shift, s, g, a);
                         }
-                        if (p.ablate & 2) {
+                        if (kGemmAblate & 2) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j) acc0[j & 3] += a[j] * xr[s][j];
                         } else {
@@ -331,8 +338,6 @@ static int launch_gemm(float* Y, const void* W, const float* X, int T, int out, 
                hipFuncSetAttribute((const void*)gemm_quant_mfma_kernel<DT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    160 * 1024) == hipSuccess;
     }();
-    static const int env_ablate = [] { const char* e = getenv("NTK_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    p.ablate = env_ablate;
     if (!once || lds > 160 * 1024) return NTK_E_SHAPE;
     const int ntiles = (out + GM_ROWS - 1) / GM_ROWS;
     const int grid = std::min(ntiles, 256 * 16 / GM_WAVES);   // 16 waves per CU; a workgroup walks its tiles (prefetching the next)
