@@ -66,6 +66,8 @@ void*  ntk_event_create(void);                       /* create_event ... elapsed
 int    ntk_event_destroy(void* ev);
 int    ntk_event_record(void* ev, void* stream);
 int    ntk_event_synchronize(void* ev);
+int    ntk_stream_wait_event(void* stream, void* ev); /* wait_event, device.cu:96-101: later work on `stream` waits for
+                                                        `ev`; the host thread does not block                  */
 int    ntk_event_elapsed_ms(void* start, void* end, float* ms);
 
 void*  nt_hip_malloc(size_t size);                   /* nt_cuda_malloc  device.cu:154-162 (NULL on failure) */
@@ -105,6 +107,8 @@ int ntk_rope(float* q, float* k, const int* positions, int batch_size, int seq_l
 int ntk_softmax(float* output, const float* input, int rows, int cols, void* stream);
 int ntk_masked_softmax(float* output, const float* input, const uint8_t* mask, int rows, int cols, void* stream);
 /* launch_gemv, kernels.h:35-37 / gemm.cu:748-805.  y[out] = W[out,in] . x[in]; W raw GGUF blocks (any even address).
+ * Limits (NTK_E_SHAPE beyond them; the Llama-3.1 8B / 70B shapes are far inside): in_features <= 32768 for the quantised
+ * dtypes (8 column slices of 4096), out_features * row_bytes < 4 GiB per matrix (32-bit byte offsets inside a launch).
  * The quantised kernels fetch W in aligned 16-byte pieces: the piece holding the first / last byte of the matrix is read
  * whole (up to 15 bytes either side, inside the same 16-byte line -- never another page); those bytes are not used. */
 int ntk_gemv(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype,
@@ -118,7 +122,10 @@ int ntk_gemm_f32(float* C, const float* A, const float* B, int M, int N, int K, 
 int ntk_silu_mul(float* output, const float* gate, const float* up, int size, void* stream);
 /* launch_add_bias, kernels.h:49 (dead) */
 int ntk_add_bias(float* y, const float* bias, int size, void* stream);
-/* launch_attention_decode, kernels.h:52-55 / attention.cu:348-375.  One query token, seq_len keys in cache. */
+/* launch_attention_decode, kernels.h:52-55 / attention.cu:348-375.  One query token, seq_len keys in cache.
+ * Limit (both attention launchers): the score row of one query lives in LDS, so seq_len (decode) / start_pos + seq_len
+ * (prefill) <= ~40 000 keys at head_dim 128 (160 KiB of LDS); NTK_E_SHAPE beyond.  The engine's fused decode
+ * (ntk_attention_decode_fused / _split) keeps no score row and has no such limit. */
 int ntk_attention_decode(float* output, const float* q, const void* k_cache, const void* v_cache, int seq_len,
                          int n_heads, int n_kv_heads, int head_dim, int max_seq, float scale, void* stream);
 /* launch_attention_prefill, kernels.h:56-60 / attention.cu:377-403.  Causal: query t sees keys 0..start_pos+t. */

@@ -34,7 +34,7 @@ void CUDADevice::synchronize_stream(StreamType st) { ntk_stream_synchronize(stre
 void* CUDADevice::create_event() { return ntk_event_create(); }
 void CUDADevice::destroy_event(void* e) { ntk_event_destroy(e); }
 void CUDADevice::record_event(void* e, StreamType st) { ntk_event_record(e, streams_[st]); }
-void CUDADevice::wait_event(StreamType, void* e) { ntk_event_synchronize(e); }
+void CUDADevice::wait_event(StreamType st, void* e) { ntk_stream_wait_event(streams_[st], e); }   // stream side, like device.cu:96-101
 float CUDADevice::elapsed_ms(void* a, void* b) {
     float ms = 0;
     ntk_event_synchronize(b);

@@ -27,9 +27,11 @@ static void usage(const char* prog) {
             "  --no-fuse / --no-graph   Use the 15-launch/layer sequence / launch eagerly\n"
             "  --no-batched-prefill     Prompt tokens one by one (the reference's GEMV loops) instead of 16 per weight pass\n"
             "  --synthetic <shape:mix>  8b|70b|tiny : Q8_0|Q4_K_M|Q6_K|...  seeded synthetic weights, no file\n"
-            "Accepted for CLI compatibility, no effect (weights are always resident in 288 GB HBM):\n"
-            "  --streaming --draft-model <p> --draft-k <n> --self-spec --early-exit <f> --skip-threshold <f>\n"
-            "  --requant-q4k --delta-model <p>\n",
+            "Accepted for CLI compatibility, no effect on the output (weights are always resident in 288 GB HBM;\n"
+            "speculative decoding only changes speed, and plain decode is what runs):\n"
+            "  --streaming --draft-model <p> --draft-k <n> --self-spec\n"
+            "Refused (in the reference they CHANGE the generated text; this engine does not implement them):\n"
+            "  --early-exit <f> --skip-threshold <f> --requant-q4k --delta-model <p>\n",
             prog);
 }
 
@@ -40,7 +42,16 @@ int main(int argc, char** argv) {
     nt::GenerateConfig cfg;
     cfg.verbose = true;
     nt::Engine engine;
-    auto noop = [](const char* flag) { fprintf(stderr, "Note: %s has no effect: weights are fully resident on MI355X\n", flag); };
+    // reference main.cpp:52-103.  Streaming and speculative decoding change HOW tokens are produced, not WHICH tokens
+    // (greedy speculative decoding verifies every draft token against the full model); they are accepted and plain resident
+    // decode runs.  Early exit, layer skipping, Q6_K->Q4_K requantisation and delta models change the logits: silently
+    // ignoring them would hand the user different text than the reference produces for the same command line, so they fail.
+    auto noop = [](const char* flag, const char* why) { fprintf(stderr, "Note: %s has no effect: %s\n", flag, why); };
+    auto refuse = [](const char* flag) {
+        fprintf(stderr, "Error: %s is not supported by the MI355X engine (it changes the model's outputs in the reference: "
+                        "layer skip / early exit / requantised or delta weights are not implemented here)\n", flag);
+        return 2;
+    };
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : nullptr; };
@@ -61,8 +72,11 @@ int main(int argc, char** argv) {
         else if (a == "--no-batched-prefill") engine.options().batched_prefill = false;
         else if (a == "--no-graph") engine.options().graph = false;
         else if (a == "--synthetic") { if (auto v = val()) synthetic = v; }
-        else if (a == "--streaming" || a == "--self-spec" || a == "--requant-q4k") noop(a.c_str());
-        else if (a == "--draft-model" || a == "--draft-k" || a == "--early-exit" || a == "--skip-threshold" || a == "--delta-model") { (void)val(); noop(a.c_str()); }
+        else if (a == "--streaming") noop(a.c_str(), "weights are fully resident on MI355X");
+        else if (a == "--self-spec") noop(a.c_str(), "plain decode runs (same tokens under greedy decoding, no draft pass)");
+        else if (a == "--draft-model" || a == "--draft-k") { (void)val(); noop(a.c_str(), "plain decode runs (same tokens under greedy decoding, no draft model is loaded)"); }
+        else if (a == "--requant-q4k") return refuse(a.c_str());
+        else if (a == "--early-exit" || a == "--skip-threshold" || a == "--delta-model") { (void)val(); return refuse(a.c_str()); }
         else { fprintf(stderr, "Unknown option: %s\n", a.c_str()); usage(argv[0]); return 1; }
     }
     if (model_path.empty() && synthetic.empty()) { fprintf(stderr, "Error: model path required (-m)\n\n"); usage(argv[0]); return 1; }

@@ -29,6 +29,10 @@ int ggml_type_to_dtype(uint32_t t) {
     }
 }
 
+bool ggml_type_known(uint32_t t) {
+    switch (t) { case 0: case 1: case 2: case 8: case 10: case 12: case 13: case 14: case 26: return true; default: return false; }
+}
+
 const char* dtype_name(int dt) {
     static const char* n[] = {"F32", "F16", "Q8_0", "Q4_0", "Q4_K_M", "Q6_K", "Q5_K", "Q2_K", "I32"};
     return dt >= 0 && dt <= 8 ? n[dt] : "UNKNOWN";
@@ -216,7 +220,10 @@ int GgufFile::parse() {   // reference loader.cpp:56-187
         ti.ggml_type = c.get<uint32_t>();
         ti.offset = c.get<uint64_t>();
         ti.dtype = ggml_type_to_dtype(ti.ggml_type);
-        ti.nbytes = ntk_row_bytes(ti.dtype, ti.numel());
+        ti.known_type = ggml_type_known(ti.ggml_type);
+        const int64_t ne = ti.numel();
+        if (ne < 0) { err_ = "Tensor '" + ti.name + "' has a non-positive or overflowing shape"; return NTK_E_FORMAT; }
+        ti.nbytes = ntk_row_bytes(ti.dtype, ne);
         index_[ti.name] = (size_t)t;
     }
     if (!c.ok) { err_ = "Truncated GGUF tensor table"; return NTK_E_FORMAT; }
@@ -226,8 +233,11 @@ int GgufFile::parse() {   // reference loader.cpp:56-187
         align = (size_t)it->second.i;
     const size_t header = (size_t)(c.p - base_);
     data_offset_ = (header + align - 1) / align * align;
+    if (data_offset_ > size_) { err_ = "GGUF data section starts beyond the file"; return NTK_E_FORMAT; }
+    const uint64_t data_size = size_ - data_offset_;
     for (const auto& ti : tensors_) {
-        if (data_offset_ + ti.offset + ti.nbytes > size_) {   // the reference aborts here (loader.cpp:266-274)
+        // offsets and sizes are file-controlled 64-bit values: compare without forming sums that can wrap
+        if (ti.offset > data_size || (uint64_t)ti.nbytes > data_size - ti.offset) {   // the reference aborts here (loader.cpp:266-274)
             err_ = "Tensor '" + ti.name + "' extends beyond the file";
             return NTK_E_FORMAT;
         }

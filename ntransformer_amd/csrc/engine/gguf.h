@@ -44,7 +44,17 @@ struct GgufTensor {
     int dtype = 0;               // NTK_DT_* (nt::DType numeric value)
     uint64_t offset = 0;         // relative to the data section
     size_t nbytes = 0;
-    int64_t numel() const { int64_t n = 1; for (auto d : dims) n *= d; return n; }
+    bool known_type = true;      // false: a ggml type outside types.h:202-215 (the reference reads those as F32; the model
+                                 // loader refuses to USE such a tensor instead of reading quantised bytes as floats)
+    // product of the dims; -1 if a dim is <= 0 or the product overflows (file-controlled values)
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto d : dims) {
+            if (d <= 0 || n > INT64_MAX / d) return -1;
+            n *= d;
+        }
+        return n;
+    }
 };
 
 struct GgufVocab {
@@ -92,6 +102,7 @@ private:
 };
 
 int ggml_type_to_dtype(uint32_t ggml_type);   // reference src/core/types.h:202-215 (unknown -> F32)
+bool ggml_type_known(uint32_t ggml_type);     // one of the types that table lists
 const char* dtype_name(int dtype);
 
 }  // namespace nt

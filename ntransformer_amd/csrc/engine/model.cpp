@@ -35,19 +35,36 @@ void Model::free_all() {
     if (h_token_) nt_hip_free_host(h_token_);
     h_token_ = nullptr;
     layers_.clear();
+    // a second load() on the same object starts from a clean slate
+    token_embd_ = output_norm_ = output_ = DevTensor();
+    weight_bytes_ = 0;
+    output_tied_ = false;
+    host_pos_ = 0;
+    attn_regime_ = 0;
+    k_cache_ = v_cache_ = nullptr;
+    hidden_ = residual_ = workspace_ = logits_ = argmax_scratch_ = rope_inv_freq_ = attn_scratch_ = nullptr;
+    positions_ = tokens_dev_ = d_pos_ = d_token_ = nullptr;
 }
 
 int Model::upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int64_t out_f, size_t nbytes) {
     void* d = nt_hip_malloc((nbytes + 255) / 256 * 256 + 256);   // tail padding: kernels may read the last 16-byte chunk whole
     if (!d) { err_ = "out of device memory"; return NTK_E_NOMEM; }
     allocs_.push_back(d);
-    if (host) nt_hip_memcpy_h2d(d, host, nbytes);
+    if (host && nbytes) {   // a failed upload must not leave silently garbage weights behind
+        if (hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice) != hipSuccess) { err_ = "weight upload (H2D copy) failed"; return NTK_E_LAUNCH; }
+    }
     dst.ptr = d; dst.dtype = dtype; dst.in_f = in_f; dst.out_f = out_f; dst.nbytes = nbytes;
     weight_bytes_ += nbytes;
     return NTK_OK;
 }
 
 int Model::load(const std::string& path, int max_context) {
+    const int st = load_impl(path, max_context);
+    if (st != NTK_OK) free_all();   // nothing stays resident after a failed load
+    return st;
+}
+
+int Model::load_impl(const std::string& path, int max_context) {
     free_all();
     fprintf(stderr, "Loading model: %s\n", path.c_str());
     GgufFile f;
@@ -76,7 +93,7 @@ int Model::load(const std::string& path, int max_context) {
             return NTK_E_SHAPE;
         }
         if (vec && t->dtype != NTK_DT_F32) { err_ = name + " must be F32"; return NTK_E_DTYPE; }
-        if (t->nbytes == 0) { err_ = "Unsupported tensor type for " + name; return NTK_E_DTYPE; }
+        if (t->nbytes == 0 || !t->known_type) { err_ = "Unsupported tensor type for " + name; return NTK_E_DTYPE; }
         return upload(dst, f.data(*t), t->dtype, in_f, out_f, t->nbytes);
     };
     NT_TRY(take("token_embd.weight", token_embd_, H, cfg_.vocab_size, false));
@@ -148,8 +165,9 @@ int Model::load_synthetic(const SynthSpec& spec, int max_context, int nthreads) 
         if (rc != NTK_OK) break;
     }
     nt_hip_free_host(stage);
-    if (rc != NTK_OK) return rc;
-    return finish_load(max_context);
+    if (rc == NTK_OK) rc = finish_load(max_context);
+    if (rc != NTK_OK) free_all();
+    return rc;
 }
 
 int Model::finish_load(int /*max_context*/) {
@@ -221,6 +239,8 @@ uint64_t Model::bytes_per_token(int pos) const {
 // ---------------------------------------------------------------------------------------------------
 float* Model::forward(const int* tokens, int T, int start_pos) {
     if (T <= 0 || start_pos < 0 || start_pos + T > cfg_.max_seq_len) { err_ = "forward: sequence exceeds context"; return nullptr; }
+    for (int i = 0; i < T; ++i)   // the embedding gather indexes the table with these on the device
+        if (tokens[i] < 0 || tokens[i] >= cfg_.vocab_size) { err_ = "forward: token id out of range"; return nullptr; }
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     void* s = stream_;
@@ -253,8 +273,8 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     const bool batched = batched_prefill_ && T > 1;
     auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
         if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
-            ok(ntk_gemm_quant(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s));
-            return;
+            const int st = ntk_gemm_quant(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s);
+            if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }   // those two: shapes only the per-token loop takes
         }
         for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, X + (size_t)t * xstride);
     };
@@ -262,8 +282,8 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     // projection adds the residual in its epilogue, the reference sequence goes through residual_ and launch_add_inplace
     auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
         if (batched && is_quant(w.dtype) && (size_t)w.out_f == (size_t)H && xstride == (size_t)w.in_f) {
-            ok(ntk_gemm_quant(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s));
-            return;
+            const int st = ntk_gemm_quant(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s);
+            if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }
         }
         project(residual_, w, X, H, xstride);
         ok(ntk_add_inplace(hidden_, residual_, T * H, s));
@@ -300,6 +320,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
 // fused single-token path
 // ---------------------------------------------------------------------------------------------------
 int Model::set_device_token(int token) {
+    if (token < 0 || token >= cfg_.vocab_size) { err_ = "token id out of range"; return NTK_E_SHAPE; }
     *h_token_ = token;
     return ntk_memcpy_h2d_async(d_token_, h_token_, 4, stream_);
 }

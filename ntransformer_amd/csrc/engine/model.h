@@ -75,6 +75,7 @@ public:
     void* stream() const { return stream_; }
 
 private:
+    int load_impl(const std::string& gguf_path, int max_context);
     int finish_load(int max_context);
     int alloc_buffers();
     int upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int64_t out_f, size_t nbytes);

@@ -146,6 +146,10 @@ int ntk_event_synchronize(void* ev) {
     if (!ev) return NTK_E_NULL;
     return hipEventSynchronize(static_cast<hipEvent_t>(ev)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
 }
+int ntk_stream_wait_event(void* stream, void* ev) {   // reference device.cu:96-101: cudaStreamWaitEvent -- stream side, the host does not block
+    if (!ev) return NTK_E_NULL;
+    return hipStreamWaitEvent(resolve_stream(stream), static_cast<hipEvent_t>(ev), 0) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
 int ntk_event_elapsed_ms(void* start, void* end, float* ms) {
     if (!start || !end || !ms) return NTK_E_NULL;
     return hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(end)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;

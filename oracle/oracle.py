@@ -268,9 +268,10 @@ class OracleModel:
 
 
 def run_ref_logits(gguf_path: str, prompt: Sequence[int], forced: Sequence[int] = (), n_greedy: int = 0,
-                   ctx: int = 4096, out_path: Optional[str] = None):
-    """Run oracle/_ref/ref_logits (reference host code + CPU kernels). Returns (fed, argmax, logits[steps,V])."""
-    exe = os.path.join(_HERE, "_ref", "ref_logits")
+                   ctx: int = 4096, out_path: Optional[str] = None, exe_name: str = "ref_logits"):
+    """Run oracle/_ref/ref_logits (reference host code + CPU kernels). Returns (fed, argmax, logits[steps,V]).
+    exe_name="ref_logits_hip": the same reference host code linked over the product's HIP library (GPU tests)."""
+    exe = os.path.join(_HERE, "_ref", exe_name)
     if not os.path.exists(exe):
         raise FileNotFoundError(exe)
     out_path = out_path or (gguf_path + ".ref_logits.bin")
