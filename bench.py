@@ -14,11 +14,16 @@ every rank runs an independent whole-model replica on its own GPU (the path has 
 Besides the contract fields the line carries
   roofline     -- HBM roofline of the dominant kernel (the dequant-fused GEMV): algorithmic bytes per launch /
                   average launch duration measured with HIP event pairs on the compute stream
-  cpu_baseline -- the oracle (CPU restatement of the reference kernels) timed on this host on a bounded sample
+  cpu_baseline -- the reference's own CLI + host loop (oracle/_ref/ntransformer_cpu: reference src/main.cpp, engine.cpp,
+                  transformer.cpp ... compiled unmodified, linked with the CPU restatement of its CUDA kernels) run on the
+                  SAME full-size 8B Q8_0 GGUF on this host's cores; its own `Decode: ... tok/s` line is the value
+  config.also  -- (N=1) BASELINE configs 3 and 4 -- 8B Q4_K_M and 70B Q4_K_M -- timed in the same process the same way
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -40,61 +45,17 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="the reference's 15-launch/layer sequence")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-persistent", action="store_true", help="fused launches instead of the persistent token kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-tokens", type=int, default=24, help="-n of the reference CLI run that is the CPU baseline")
+    ap.add_argument("--no-also", action="store_true", help="skip BASELINE configs 3 and 4 (8B Q4_K_M, 70B Q4_K_M)")
     ap.add_argument("--no-pmc-note", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(args, spec_full, prompt):
-    """Oracle decode on a bounded sample: SAMPLE_LAYERS layers of the same shape + the full LM head, timed per
-    section and scaled to the full depth.  The oracle is the CPU restatement of the reference's kernels driven in
-    the reference's launch order (oracle/oracle.py); OpenMP over output rows."""
-    import numpy as np
-    from ntransformer_amd import engine as E
-    from oracle import oracle as O
-    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-    threads = O.pick_threads()      # what this host really schedules, not what it advertises
-    sample_layers = 2 if args.model in ("8b", "70b") else E.PRESETS[args.model]["layers"]
-    spec = E.synth_spec(args.model, args.mix, layers=sample_layers)
-    path = "/dev/shm/_bench_cpu_sample.gguf" if os.path.isdir("/dev/shm") else "/tmp/_bench_cpu_sample.gguf"
-    E.synth_write_gguf(path, spec)
-    try:
-        m = O.OracleModel(path, max_context=256)
-        full_layers = E.PRESETS[args.model]["layers"]
-        m.forward(prompt[:4], 0)                               # warm page cache / threads
-        # time one decode step split into [layers] and [final norm + LM head] by differencing two model depths
-        t_steps, pos, tok = [], 4, int(prompt[4])
-        t_budget = time.perf_counter() + args.cpu_seconds
-        while len(t_steps) < 2 or (time.perf_counter() < t_budget and len(t_steps) < 64):
-            t0 = time.perf_counter()
-            lg = m.forward([tok], pos)
-            t_steps.append(time.perf_counter() - t0)
-            tok, pos = int(np.argmax(lg)), pos + 1
-        m1 = O.OracleModel(path, max_context=256, n_layers=1)
-        m1.forward(prompt[:4], 0)
-        t1 = []
-        for i in range(max(2, min(8, len(t_steps)))):
-            t0 = time.perf_counter()
-            m1.forward([tok], 4 + i)
-            t1.append(time.perf_counter() - t0)
-        t_full, t_one = float(np.median(t_steps)), float(np.median(t1))
-        t_layer = max((t_full - t_one) / max(sample_layers - 1, 1), 1e-9)
-        t_head = max(t_one - t_layer, 0.0)
-        tok_s = 1.0 / (t_head + full_layers * t_layer)
-        cores = threads
-        return {"value": round(tok_s, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
-                "sample": "%d of %d layers + full LM head of the same %s %s model, %d decode steps on the CPU oracle "
-                          "(%.3f s/layer, %.3f s head+embed); layers scaled to full depth"
-                          % (sample_layers, full_layers, args.model, args.mix, len(t_steps), t_layer, t_head),
-                "host": _cpu_model()}
-    finally:
-        try:
-            os.remove(path)
-        except OSError:
-            pass
-
-
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -103,6 +64,179 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def host_cpu_budget():
+    """Threads the CPU baseline should use: the physical cores this process may run on (affinity mask, SMT siblings
+    counted once), capped by the cgroup CPU quota when there is one.  Returned with everything it was derived from, so two
+    boxes that report different `cores` explain themselves."""
+    aff = sorted(os.sched_getaffinity(0))
+    phys = set()
+    for c in aff:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        phys.add(sib)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    threads = len(phys)
+    if quota is not None:
+        threads = max(1, min(threads, int(quota)))
+    try:
+        load1 = os.getloadavg()[0]
+    except OSError:
+        load1 = None
+    info = {"nproc_online": os.cpu_count(), "affinity_cpus": len(aff), "physical_cores_in_affinity": len(phys),
+            "cgroup_cpu_quota": quota, "loadavg_1m": load1, "threads_used": threads}
+    return threads, info
+
+
+def _scratch_file(name, need_bytes):
+    import shutil
+    for d in ("/dev/shm", "/tmp"):
+        try:
+            if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need_bytes * 1.1:
+                return os.path.join(d, name)
+        except OSError:
+            continue
+    return None
+
+
+def cpu_baseline_reference_cli(args, spec):
+    """SURVEY 8(d) / BASELINE.md section 3: oracle/_ref/ntransformer_cpu -- the reference's unmodified main.cpp / Engine /
+    Transformer host loop, CPU-only -- on the full-size GGUF of the headline workload, greedy; the number is the CLI's own
+    `Decode: N tokens, T ms (R tok/s)` statistics line (reference src/inference/engine.cpp:595-600)."""
+    from ntransformer_amd import engine as E
+    exe = os.path.join(ROOT, "oracle", "_ref", "ntransformer_cpu")
+    if not os.path.exists(exe):
+        raise FileNotFoundError("oracle/_ref/ntransformer_cpu is not built (make -C oracle ref, needs /root/reference)")
+    threads, info = host_cpu_budget()
+    gguf_bytes = 9.2e9 if args.model == "8b" else 1e9
+    path = _scratch_file("_bench_cpu_%s_%s.gguf" % (args.model, args.mix.lower()), gguf_bytes)
+    if path is None:
+        raise RuntimeError("no scratch space for the %.1f GB GGUF" % (gguf_bytes / 1e9))
+    t0 = time.perf_counter()
+    E.synth_write_gguf(path, spec)
+    t_write = time.perf_counter() - t0
+    try:
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive")
+        cmd = [exe, "-m", path, "-p", "Hi", "-n", str(args.cpu_tokens), "-t", "0", "--repeat-penalty", "1.0", "-c", str(args.ctx)]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        wall = time.perf_counter() - t0
+        txt = r.stderr + r.stdout
+        m = re.search(r"Decode:\s+(\d+) tokens,\s+([0-9.]+) ms \(([0-9.]+) tok/s\)", txt)
+        mp = re.search(r"Prompt:\s+(\d+) tokens,\s+([0-9.]+) ms", txt)
+        if r.returncode != 0 or not m:
+            raise RuntimeError("reference CLI failed (rc %d): %s" % (r.returncode, txt[-400:]))
+        n_dec, ms_dec = int(m.group(1)), float(m.group(2))
+        return {"value": round(n_dec / (ms_dec * 1e-3), 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+                "sample": "reference CLI (oracle/_ref/ntransformer_cpu: reference main.cpp + Engine + Transformer host code, "
+                          "unmodified; kernels = the CPU restatement, OpenMP over output rows) on the FULL %s %s GGUF "
+                          "(%.1f GB in %s), -p Hi -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Stats line, %d decode tokens in "
+                          "%.0f ms (prompt %s tokens %s ms); whole run %.1f s + %.1f s writing the file"
+                          % (args.model, args.mix, os.path.getsize(path) / 1e9, os.path.dirname(path), args.cpu_tokens, args.ctx,
+                             n_dec, ms_dec, mp.group(1) if mp else "?", mp.group(2) if mp else "?", wall, t_write),
+                "host": _cpu_model(), "host_cpus": info}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------
+# one workload on this rank's GPU
+# ---------------------------------------------------------------------------------------------------
+def _gemv_bytes_per_token(spec, mix):
+    """Bytes of the matrices the GEMV launches stream per token = weights minus the embedding table (gathered, 1 row)."""
+    from ntransformer_amd import gguf as G
+    shape = G.LlamaShape("b", spec.hidden, spec.inter, spec.layers, spec.heads, spec.kv_heads, spec.vocab)
+    types = G.tensor_types(shape, mix if mix == "Q4_K_M" else {"Q4_K": "Q4_K", "Q5_K": "Q5_K"}.get(mix, mix))
+    hd = spec.hidden // spec.heads
+    dims = {"attn_q": (spec.hidden, spec.heads * hd), "attn_k": (spec.hidden, spec.kv_heads * hd), "attn_v": (spec.hidden, spec.kv_heads * hd),
+            "attn_output": (spec.heads * hd, spec.hidden), "ffn_gate": (spec.hidden, spec.inter), "ffn_up": (spec.hidden, spec.inter),
+            "ffn_down": (spec.inter, spec.hidden)}
+    total = G.row_bytes(types["output.weight"], spec.hidden) * spec.vocab
+    for name, t in types.items():
+        if name.startswith("blk."):
+            i, o = dims[name.split(".")[2]]
+            total += G.row_bytes(t, i) * o
+    return total
+
+
+def run_workload(args, model, mix, steps, warmup, timed, sync):
+    """Load `model`:`mix` resident, prompt + first token untimed, `warmup` tokens untimed, exactly `steps` greedy decode
+    tokens timed by `timed` (replica.timed_steps partial).  Returns the measurements (rank-local roofline included)."""
+    import numpy as np
+    from ntransformer_amd import engine as E
+    spec = E.synth_spec(model, mix)
+    eng = E.Engine()
+    eng.set_option("fused", not args.no_fuse)
+    eng.set_option("graph", not args.no_graph)
+    if args.no_persistent:
+        eng.set_option("persistent", 0)
+    t_load = time.perf_counter()
+    eng.load_synthetic(spec, args.ctx)
+    t_load = time.perf_counter() - t_load
+    rng = np.random.Generator(np.random.Philox(key=[20260925, 99]))
+    prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, args.prompt_len - 1)]
+    # prefill + first token (untimed), exactly Engine::generate's first half
+    first = eng.generate_tokens(prompt, 1, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False)
+    tok, pos = first[0], len(prompt)
+    warm = eng.decode_greedy_steps(tok, pos, warmup) if warmup > 0 else []
+    if warm:
+        tok = warm[-1]
+    pos += warmup
+    elapsed, _, out = timed(lambda k: eng.decode_greedy_steps(tok, pos, k), steps)
+    pos_end = pos + steps
+    res = {"spec": spec, "elapsed": elapsed, "pos": pos, "pos_end": pos_end, "t_load": t_load,
+           "b_tok": eng.bytes_per_token(pos + steps // 2), "path": eng.decode_path() if hasattr(eng, "decode_path") else None}
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the compute stream over a few eagerly
+    # launched tokens (the fused launch sequence: the persistent token kernel has no per-operator boundaries to put
+    # events on).  `coarse`: one event per run of GEMV launches (o, gate|up, down, next qkv between two attention
+    # launches), so the events' own cost (~2 us each) is paid once per 4 launches; `fine` (an event pair per launch,
+    # reads ~2 us high per launch) is reported beside it.  rocprofv3's kernel trace of this command is in profiles/.
+    def prof(coarse, n_prof=4):
+        ms, calls = [0.0] * 4, [0] * 4
+        for i in range(n_prof):
+            m_, c_ = eng.profile_token(out[-1] if out else tok, min(pos_end + i, args.ctx - 1), coarse)
+            ms = [a + b for a, b in zip(ms, m_)]
+            calls = [a + b for a, b in zip(calls, c_)]
+        return [m / n_prof for m in ms], [c / n_prof for c in calls]
+    ms, calls = prof(True)
+    ms_fine, calls_fine = prof(False)
+    res.update(ms=ms, calls=calls, ms_fine=ms_fine, calls_fine=calls_fine, gemv_bytes_tok=_gemv_bytes_per_token(spec, mix))
+    eng.close()
+    return res
+
+
+def roofline_block(args, model, mix, r):
+    launches_tok = r["calls"][0]
+    avg_launch_ms = r["ms"][0] / max(r["calls"][0], 1)
+    achieved = (r["gemv_bytes_tok"] / max(launches_tok, 1)) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic, traffic_src = _pmc_traffic(model, mix)
+    return {"bound": "hbm", "kernel": "gemv_quant_kernel<%s> (all projection launches of a token pooled)" % mix,
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "bytes_per_launch": int(r["gemv_bytes_tok"] / max(launches_tok, 1)), "launches_per_token": launches_tok,
+            "avg_launch_us": round(avg_launch_ms * 1e3, 2),
+            "avg_launch_us_event_pair_per_launch": round(r["ms_fine"][0] / max(r["calls_fine"][0], 1) * 1e3, 2),
+            "timed_runs_per_token": r["calls"][3],
+            "token_ms_by_class_eager": {"gemv": round(r["ms"][0], 4), "attention": round(r["ms"][1], 4), "other": round(r["ms"][2], 4)}}
 
 
 def main():
@@ -119,7 +253,6 @@ def main():
     # (NT_DIST_BACKEND=nccl for RCCL)
     dist, backend = replica.init_distributed("gloo", local_rank) if world > 1 else (None, None)
 
-    import numpy as np
     from ntransformer_amd import _lib
     from ntransformer_amd import engine as E
     L = _lib.lib()
@@ -131,112 +264,78 @@ def main():
     os.environ["NTK_DEVICE"] = str(dev)
     _lib.check(L.ntk_device_init(dev), "ntk_device_init(%d)" % dev)
 
-    spec = E.synth_spec(args.model, args.mix)
-    eng = E.Engine()
-    eng.set_option("fused", not args.no_fuse)
-    eng.set_option("graph", not args.no_graph)
-    t_load = time.perf_counter()
-    eng.load_synthetic(spec, args.ctx)
-    t_load = time.perf_counter() - t_load
+    def sync():
+        _lib.check(L.ntk_device_synchronize(), "device sync")
 
-    rng = np.random.Generator(np.random.Philox(key=[20260925, 99]))
-    prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, args.prompt_len - 1)]
-    # prefill + first token (untimed), exactly Engine::generate's first half
-    first = eng.generate_tokens(prompt, 1, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False)
-    tok, pos = first[0], len(prompt)
-    warm = eng.decode_greedy_steps(tok, pos, args.warmup) if args.warmup > 0 else []
-    if warm:
-        tok = warm[-1]
-    pos += args.warmup
+    def timed_all_ranks(fn, k):
+        return replica.timed_steps(fn, k, sync, dist, backend)
 
-    elapsed, _, out = replica.timed_steps(lambda k: eng.decode_greedy_steps(tok, pos, k), args.steps,
-                                          lambda: _lib.check(L.ntk_device_synchronize(), "device sync"), dist, backend)
-    pos_end = pos + args.steps
+    def timed_local(fn, k):
+        return replica.timed_steps(fn, k, sync, None, None)
+
+    r = run_workload(args, args.model, args.mix, args.steps, args.warmup, timed_all_ranks, sync)
 
     if rank == 0:
+        elapsed = r["elapsed"]
         tok_s = world * args.steps / elapsed
-        b_tok = eng.bytes_per_token(pos + args.steps // 2)
-        # ---- roofline of the dominant kernel, measured live with HIP events on the compute stream over a few eagerly
-        # launched tokens.  `coarse`: one event per run of GEMV launches (o, gate|up, down, next qkv between two attention
-        # launches), so the events' own cost (~2 us each) is paid once per 4 launches; `fine` (an event pair per launch,
-        # reads ~2 us high per launch) is reported beside it.  rocprofv3's kernel trace of this command is in profiles/.
-        def prof(coarse, n_prof=4):
-            ms, calls = [0.0] * 4, [0] * 4
-            for i in range(n_prof):
-                m_, c_ = eng.profile_token(out[-1] if out else tok, min(pos_end + i, args.ctx - 1), coarse)
-                ms = [a + b for a, b in zip(ms, m_)]
-                calls = [a + b for a, b in zip(calls, c_)]
-            return [m / n_prof for m in ms], [c / n_prof for c in calls]
-        ms, calls = prof(True)
-        ms_fine, calls_fine = prof(False)
-        gemv_bytes_tok = _gemv_bytes_per_token(eng, spec, args.mix)
-        launches_tok = calls[0]
-        avg_launch_ms = ms[0] / max(calls[0], 1)
-        achieved = (gemv_bytes_tok / max(launches_tok, 1)) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        traffic, traffic_src = _pmc_traffic(args)
+        headline = (args.model, args.mix) == ("8b", "Q8_0")
         line = {
-            "metric": "decode tokens/sec (Llama-3.1-8B Q8_0 class, resident weights, greedy, batch 1)" if (args.model, args.mix) == ("8b", "Q8_0")
+            "metric": "decode tokens/sec (Llama-3.1-8B Q8_0 class, resident weights, greedy, batch 1)" if headline
                       else "decode tokens/sec (%s %s, resident weights, greedy, batch 1)" % (args.model, args.mix),
             "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(tok_s / world / REF_3090_TOK_S, 3) if (args.model, args.mix) == ("8b", "Q8_0") else None,
+            "vs_baseline": round(tok_s / world / REF_3090_TOK_S, 3) if headline else None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Llama-3.1-%s-shaped %s GGUF tensors (seed 20260925), resident in HBM, %d-token prompt, greedy decode"
                                    % (args.model.upper(), args.mix, args.prompt_len),
-                       "ctx": args.ctx, "decode_positions": [pos, pos_end], "replicas": world,
-                       "path": "1:1 launchers (15/layer)" if args.no_fuse else "fused (5 launches/layer)",
+                       "ctx": args.ctx, "decode_positions": [r["pos"], r["pos_end"]], "replicas": world,
+                       "path": "1:1 launchers (15/layer)" if args.no_fuse else (r["path"] or "fused (5 launches/layer)"),
                        "hipgraph": not args.no_graph and not args.no_fuse,
-                       "algorithmic_bytes_per_token": b_tok, "load_seconds": round(t_load, 2)},
-            "hbm_fraction_of_8TBs_end_to_end": round(b_tok * tok_s / world / (HBM_PEAK_GBS * 1e9), 4),
-            "roofline": {"bound": "hbm", "kernel": "gemv_quant_kernel<%s> (all projection launches of a token pooled)" % args.mix,
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": int(gemv_bytes_tok / max(launches_tok, 1)), "launches_per_token": launches_tok,
-                         "avg_launch_us": round(avg_launch_ms * 1e3, 2),
-                         "avg_launch_us_event_pair_per_launch": round(ms_fine[0] / max(calls_fine[0], 1) * 1e3, 2),
-                         "timed_runs_per_token": calls[3],
-                         "token_ms_by_class_eager": {"gemv": round(ms[0], 4), "attention": round(ms[1], 4), "other": round(ms[2], 4)}},
+                       "algorithmic_bytes_per_token": r["b_tok"], "load_seconds": round(r["t_load"], 2)},
+            "hbm_fraction_of_8TBs_end_to_end": round(r["b_tok"] * tok_s / world / (HBM_PEAK_GBS * 1e9), 4),
+            "roofline": roofline_block(args, args.model, args.mix, r),
         }
+        # ---- BASELINE configs 3 and 4 under the same clock (N = 1 only: they are single-GPU configurations) ----
+        if world == 1 and headline and not args.no_also:
+            also = []
+            for model, mix, steps in (("8b", "Q4_K_M", 128), ("70b", "Q4_K_M", 64)):
+                try:
+                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local, sync)
+                    a_tok_s = steps / a["elapsed"]
+                    rb = roofline_block(args, model, mix, a)
+                    also.append({"workload": "Llama-3.1-%s-shaped %s, resident, %d-token prompt, greedy decode" % (model.upper(), mix, args.prompt_len),
+                                 "value": round(a_tok_s, 3), "unit": "tokens/s", "steps": steps, "warmup": min(args.warmup, 8),
+                                 "ms_per_step": round(1e3 * a["elapsed"] / steps, 4),
+                                 "algorithmic_bytes_per_token": a["b_tok"],
+                                 "frac": round(a["b_tok"] * a_tok_s / (HBM_PEAK_GBS * 1e9), 4),
+                                 "gemv_launch_frac": rb["frac"], "gemv_avg_launch_us": rb["avg_launch_us"],
+                                 "gemv_launches_per_token": rb["launches_per_token"], "path": a["path"],
+                                 "load_seconds": round(a["t_load"], 2)})
+                except Exception as e:   # the headline must survive a problem in an extra workload
+                    also.append({"workload": "%s %s" % (model, mix), "value": None, "error": repr(e)})
+            line["config"]["also"] = also
         if not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args, spec, prompt)
+                line["cpu_baseline"] = cpu_baseline_reference_cli(args, r["spec"])
             except Exception as e:   # the GPU number must survive a CPU-side problem
                 line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(line), flush=True)
-    eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _pmc_traffic(args):
+def _pmc_traffic(model, mix):
     """HBM bytes per GEMV launch from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate runs of this
     command, decode window, gfx950 x2 correction on FETCH_SIZE: tools/pmc_summary.py -> profiles/pmc_traffic.json).
     PMC collection needs rocprofv3 around the process, so the number is read back, not measured in this run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-    key = "%s_%s" % (args.model, args.mix.lower())
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    key = "%s_%s" % (model, mix.lower())
     try:
         g = json.load(open(path))[key]["ntk::gemv_quant_kernel"]
         return int(g["fetch_bytes_per_launch"] + g["write_bytes_per_launch_raw"]), "profiles/pmc_traffic.json[%s]" % key
     except Exception:
         return None, None
-
-
-def _gemv_bytes_per_token(eng, spec, mix):
-    """Bytes of the matrices the GEMV launches stream per token = weights minus the embedding table (gathered, 1 row)."""
-    from ntransformer_amd import gguf as G
-    shape = G.LlamaShape("b", spec.hidden, spec.inter, spec.layers, spec.heads, spec.kv_heads, spec.vocab)
-    types = G.tensor_types(shape, mix if mix == "Q4_K_M" else {"Q4_K": "Q4_K", "Q5_K": "Q5_K"}.get(mix, mix))
-    hd = spec.hidden // spec.heads
-    dims = {"attn_q": (spec.hidden, spec.heads * hd), "attn_k": (spec.hidden, spec.kv_heads * hd), "attn_v": (spec.hidden, spec.kv_heads * hd),
-            "attn_output": (spec.heads * hd, spec.hidden), "ffn_gate": (spec.hidden, spec.inter), "ffn_up": (spec.hidden, spec.inter),
-            "ffn_down": (spec.inter, spec.hidden)}
-    total = G.row_bytes(types["output.weight"], spec.hidden) * spec.vocab
-    for name, t in types.items():
-        if name.startswith("blk."):
-            i, o = dims[name.split(".")[2]]
-            total += G.row_bytes(t, i) * o
-    return total
 
 
 if __name__ == "__main__":
