@@ -303,10 +303,11 @@ def test_cli_binary_generates_and_reports_decode_rate():
     exe = os.path.join(os.path.dirname(E.__file__), "ntransformer")
     assert os.path.exists(exe), "CLI not built"
     r = subprocess.run([exe, "--synthetic", "tiny:Q4_K_M", "-p", "hi", "-n", "8", "-t", "0", "--repeat-penalty", "1.0"],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    m = re.search(r"Decode:\s+(\d+) tokens.*?([0-9.]+) tok/s", r.stderr + r.stdout)
-    assert m, (r.stderr + r.stdout)[-2000:]
+                       capture_output=True, timeout=300)
+    txt = (r.stderr + r.stdout).decode("utf-8", "replace")
+    assert r.returncode == 0, txt[-2000:]
+    m = re.search(r"Decode:\s+(\d+) tokens.*?([0-9.]+) tok/s", txt)
+    assert m, txt[-2000:]
     assert int(m.group(1)) >= 1 and float(m.group(2)) > 0
     # flags whose reference semantics change the output are refused, not silently ignored
     r = subprocess.run([exe, "--synthetic", "tiny:Q4_K_M", "-p", "hi", "-n", "2", "--early-exit", "0.9"],
@@ -344,6 +345,7 @@ def test_reference_cli_runs_on_the_hip_library():
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/ntransformer_ref_hip not built (needs /root/reference at build time)")
     r = subprocess.run([exe, "-m", os.path.join(GOLDEN, "tiny_q8_0.gguf"), "-p", "hello", "-n", "8", "-t", "0",
-                        "--repeat-penalty", "1.0", "-c", "128"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert re.search(r"Decode:\s+\d+ tokens", r.stderr + r.stdout), (r.stderr + r.stdout)[-2000:]
+                        "--repeat-penalty", "1.0", "-c", "128"], capture_output=True, timeout=300)
+    txt = (r.stderr + r.stdout).decode("utf-8", "replace")   # a random-weight model prints arbitrary bytes
+    assert r.returncode == 0, txt[-2000:]
+    assert re.search(r"Decode:\s+\d+ tokens", txt), txt[-2000:]
