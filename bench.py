@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="the reference's 15-launch/layer sequence")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-persistent", action="store_true", help="fused launches instead of the persistent token kernel")
+    ap.add_argument("--persistent", action="store_true", help="the persistent one-launch-per-token kernel instead of fused launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=24, help="-n of the reference CLI run that is the CPU baseline")
     ap.add_argument("--no-also", action="store_true", help="skip BASELINE configs 3 and 4 (8B Q4_K_M, 70B Q4_K_M)")
@@ -67,40 +67,10 @@ def _cpu_model():
 
 
 def host_cpu_budget():
-    """Threads the CPU baseline should use: the physical cores this process may run on (affinity mask, SMT siblings
-    counted once), capped by the cgroup CPU quota when there is one.  Returned with everything it was derived from, so two
-    boxes that report different `cores` explain themselves."""
-    aff = sorted(os.sched_getaffinity(0))
-    phys = set()
-    for c in aff:
-        try:
-            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
-        except OSError:
-            sib = str(c)
-        phys.add(sib)
-    quota = None
-    try:
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            quota = float(q) / float(p)
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / p
-        except (OSError, ValueError):
-            pass
-    threads = len(phys)
-    if quota is not None:
-        threads = max(1, min(threads, int(quota)))
-    try:
-        load1 = os.getloadavg()[0]
-    except OSError:
-        load1 = None
-    info = {"nproc_online": os.cpu_count(), "affinity_cpus": len(aff), "physical_cores_in_affinity": len(phys),
-            "cgroup_cpu_quota": quota, "loadavg_1m": load1, "threads_used": threads}
-    return threads, info
+    """Threads the CPU baseline uses and everything they were derived from (oracle.host_cpu_budget: affinity mask, SMT
+    siblings counted once, cgroup CPU quota), so two boxes that report different `cores` explain themselves."""
+    from oracle import oracle as O
+    return O.host_cpu_budget()
 
 
 def _scratch_file(name, need_bytes):
@@ -186,8 +156,8 @@ def run_workload(args, model, mix, steps, warmup, timed, sync):
     eng = E.Engine()
     eng.set_option("fused", not args.no_fuse)
     eng.set_option("graph", not args.no_graph)
-    if args.no_persistent:
-        eng.set_option("persistent", 0)
+    if args.persistent:
+        eng.set_option("persistent", 1)
     t_load = time.perf_counter()
     eng.load_synthetic(spec, args.ctx)
     t_load = time.perf_counter() - t_load

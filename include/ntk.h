@@ -178,6 +178,48 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale, int nsplit,
                                float* scratch, void* stream);
 
+/* One decode token as ONE persistent launch (csrc/decode_persistent.hip): the operator table of a token -- the same fused
+ * operators as above, in order -- is compiled once into a device-resident plan; ntk_persistent_launch then runs the whole
+ * table in a single kernel (one workgroup per CU, weights prefetched across operator boundaries, activations handed
+ * between workgroups through an in-launch grid barrier).  Results = the launch-by-launch sequence (summation order of the
+ * RMSNorm / attention reductions aside).  Constraints (NTK_E_* from plan_create otherwise, callers fall back to launches):
+ * quantised dtypes only, 16-byte aligned W / x / norm_w / caches, in_features % 4 == 0 and <= 32768, norm only with
+ * in_features <= 8192, head_dim 64 / 128 / 256. */
+enum { NTK_POP_GEMV = 0, NTK_POP_ATTENTION = 1 };
+typedef struct ntk_pop {
+    int kind;                 /* NTK_POP_GEMV: the arguments of ntk_gemv_fused; NTK_POP_ATTENTION: of ntk_attention_decode_fused */
+    int wait;                 /* != 0: the operator reads activations written earlier in the launch -> waits for the grid */
+    int arrive;               /* != 0: a later operator reads what this one writes -> signals the grid when done        */
+    int plain_store;          /* != 0: outputs are only read after the launch (logits): ordinary stores                */
+    /* GEMV */
+    ntk_gemv_seg segs[3];
+    int nseg, in_features, silu_pair;
+    float eps;
+    const float* x;
+    const float* norm_w;
+    const float* resid;
+    /* attention */
+    float* out;
+    const float* q;
+    const float* k;
+    const float* v;
+    void* k_cache;
+    void* v_cache;
+    const float* inv_freq;
+    int n_heads, n_kv_heads, head_dim, max_seq;
+    float scale, theta_base, freq_scale;
+} ntk_pop;
+int  ntk_persistent_plan_create(const ntk_pop* ops, int nops, void** plan_out);
+void ntk_persistent_plan_destroy(void* plan);
+/* d_pos: DEVICE int, the position of the token (as ntk_attention_decode_fused).  Enqueues a memset of the barrier words and
+ * the kernel on `stream`; capturable. */
+int  ntk_persistent_launch(void* plan, const int* d_pos, void* stream);
+/* after a synchronise: NTK_OK, or NTK_E_LAUNCH if a bounded in-kernel wait gave up (op_index_out = the operator) */
+int  ntk_persistent_error(void* plan, int* op_index_out);
+int  ntk_persistent_grid(void* plan);
+/* debugging aid: per-operator timestamps of two workgroups (see decode_persistent.hip); returns the operator count */
+int  ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int cap_ops);
+
 /* Batched prompt projection on the matrix cores (replaces the per-token launch_gemv loops of
  * attention.cpp:144-162,200-210 and ffn.cpp:96-133):  Y[t,:] = W . X[t,:] (+ resid[t,:]) for t < n_tokens.
  * X [n_tokens][in] and Y/resid [n_tokens][out] are F32, token-major; W raw GGUF blocks [out][in] (quantised dtypes

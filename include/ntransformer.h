@@ -60,7 +60,7 @@ typedef struct nt_synth_spec { /* seeded synthetic Llama-shaped model (no checkp
 
 int  nt_engine_load_ex(nt_engine_t e, const char* model_path, int max_context);
 int  nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_context);
-/* "fused" / "graph" / "device_sampling" = "0" | "1" */
+/* "fused" / "graph" / "device_sampling" / "batched_prefill" / "persistent" = "0" | "1" */
 int  nt_engine_set_option(nt_engine_t e, const char* key, const char* value);
 const char* nt_engine_last_error(nt_engine_t e);
 void nt_gen_params_default(nt_gen_params* p);
@@ -84,6 +84,9 @@ int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int o
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */
 uint64_t nt_engine_weight_bytes(nt_engine_t e);
 int  nt_engine_max_context(nt_engine_t e);
+/* which form the fused decode step takes for this model: "persistent (...)" or "fused (5 launches/layer)" */
+const char* nt_engine_decode_path(nt_engine_t e);
+void* nt_engine_persistent_plan(nt_engine_t e);   /* plan handle for ntk_persistent_debug (NULL if the model does not qualify) */
 /* write a synthetic GGUF v3 file with the same generator (0 = ok) */
 int  nt_synth_write_gguf(const char* path, const nt_synth_spec* spec, int nthreads);
 /* fill one tensor of the synthetic plan into host memory (for CPU baselines); returns bytes or negative */

@@ -1,0 +1,885 @@
+// decode_persistent.hip -- one decode token as ONE persistent launch on gfx950 (CDNA4, wave64).
+//
+// Replaces, for the engine's decode step, the 5-launches-per-layer sequence of engine/model.cpp (itself the fused form of
+// the reference's 15 launches per layer: reference src/model/transformer.cpp:604-669, attention.cpp:120-211,
+// ffn.cpp:85-134).  Same operators, same arithmetic per weight row (gemv_core.hip.h) and per attention head
+// (attention.hip's single-pass online softmax); what changes is WHEN bytes move:
+//
+//   * One workgroup of 16 waves per CU stays resident for the whole token and walks an operator table
+//     (norm+Q|K|V, RoPE+KV store+attention, Wo+residual, norm+gate|up+SiLU, down+residual, ... , norm+LM head).
+//   * Weights never depend on activations, so every wave keeps a two-deep queue of ITS next weight rows -- one row
+//     staged in LDS, one in flight in VGPRs -- that runs straight across operator boundaries: while the grid waits for
+//     the activations of operator k+1, HBM is streaming the first 2 x 4096 rows of operator k+1 (or k+2).  A kernel
+//     boundary instead costs ~1.7 us of idle HBM plus ~2.7 us until the first byte returns (profiles/r01_launch_floor.txt),
+//     161 times per 8B token.
+//   * Activations cross workgroups inside the launch: producers store y write-through (agent-scope relaxed atomic store,
+//     `sc1`), drain their stores, and arrive on an XCD-hierarchical counter (8 group counters -> 1 top counter);
+//     consumers poll the top counter from one lane (relaxed agent loads + s_sleep) and then read x with `sc1` loads that
+//     bypass the non-coherent L1 / per-XCD L2 (MI355X_MICROARCH.md, inter-workgroup visibility; cdna_hip_programming.md G16).
+//   * Every spin is bounded; a timeout raises a device error word the host checks after the token (the engine then falls
+//     back to the launch path).  All polled words are zeroed by a memset node in front of the launch.
+//
+// HBM-bound like the GEMV it is made of: algorithmic bytes per token = sum of the weight matrices.
+#include "gemv_core.hip.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace ntk {
+
+constexpr int PW = 16;                                  // waves per workgroup (one workgroup per CU)
+constexpr int PT = PW * 64;
+constexpr int P_SLOT = 4368;                            // one row slice in LDS: 4096 Q8_0 columns (4352 B) + alignment slack
+constexpr int P_RING = 2;                               // slots per wave: the row being decoded + the row after it
+constexpr int P_RINGB = PW * P_RING * P_SLOT;           // 139 776 B
+constexpr int P_XIMG = 64 * XPITCH * 4;                 // 17 408 B: activation image of ONE column slice (also attention scratch)
+constexpr int P_TAIL_FLOATS = 2 * PW * RB + 32 + 16;    // cross-slice partials [2][16][RB], reduction scratch, spare
+constexpr int P_QSTATE = P_RINGB + P_XIMG + P_TAIL_FLOATS * 4;   // per-wave queue records (16 dwords each)
+constexpr int P_LDS = P_QSTATE;
+
+enum { PF_NORM = 1, PF_SILU = 2, PF_WAIT = 4, PF_ARRIVE = 8, PF_PLAIN = 16 };
+enum { PK_GEMV = 0, PK_ATTN = 1 };
+// sync words (unsigned), each on its own 128-byte line: [g * 32] group counter g < 8, [8 * 32] top counter, [9 * 32] error
+constexpr int SY_TOP = 8 * 32, SY_ERR = 9 * 32, SY_WORDS = 10 * 32;
+constexpr unsigned SPIN_LIMIT = 400000;                 // polls (~1 us each under load) before a wait gives up
+
+struct PSeg {
+    const uint8_t* W;   // 16-byte aligned
+    float* y;
+    int rows;
+    int pad;
+};
+
+struct POp {            // one operator of the token, device resident, read through the scalar cache
+    int kind, dtype, flags, nseg;
+    PSeg seg[MAX_SEG];
+    int total_rows;     // SiLU pair: rows of ONE matrix
+    int in, ns, slice_cols, nbatch, nl;
+    unsigned row_bytes;
+    float eps;
+    const float* x;
+    const float* norm_w;
+    const float* resid;
+    // attention
+    const float* q;
+    const float* k;
+    const float* v;
+    float* out;
+    uint16_t* kc;
+    uint16_t* vc;
+    const float* inv_freq;
+    int n_heads, n_kv_heads, hd, max_seq;
+    float scale, theta, fscale;
+    int pad;
+};
+
+// The operator table is constant for the whole launch: reading it through the constant address space lets uniform reads be
+// scalar loads (s_load, scalar cache) also inside non-inlined functions, where a plain pointer is a flat pointer and every
+// field read would be a vector load.
+typedef const __attribute__((address_space(4))) POp COp;
+
+// Arguments of a non-inlined device function arrive in vector registers and count as divergent: every load through them
+// would be a vector load (with a vmcnt wait that also drains the weight DMA) and every branch an EXEC-mask branch.  These
+// put a value that IS wave-uniform back into scalar registers.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    return reinterpret_cast<T*>(((uintptr_t)hi << 32) | lo);
+}
+
+// ---- agent-scope accesses (sc1: bypass the non-coherent caches) -------------------------------------------------
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// N 16-byte sc1 loads and their wait in ONE asm statement (the compiler does not count asm loads)
+__device__ __forceinline__ void ld16_agent_x1(u32x4& a, const float* pa) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(pa) : "memory");
+}
+__device__ __forceinline__ void ld16_agent_x2(u32x4& a, u32x4& b, const float* pa, const float* pb) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(pa), "v"(pb) : "memory");
+}
+__device__ __forceinline__ void ld16_agent_x4(u32x4& a, u32x4& b, u32x4& c, u32x4& d, const float* pa, const float* pb,
+                                              const float* pc, const float* pd) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
+}
+
+// ---- LDS-DMA: 1 KiB per wave instruction straight from HBM into the wave's ring slot (no VGPR bounce, no ds_write) ----
+// lds_dst: wave-uniform LDS byte address of the chunk; gsrc: this lane's 16 source bytes.  M0 is compiler-reserved: it is
+// saved, set and restored inside the one statement that uses it (cdna_hip_programming.md section 5.7).  Inactive lanes
+// (EXEC) move nothing.  The compiler does not count these loads: waits are explicit (wait_vm).
+__device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// wait until at most n of the wave's vector-memory operations are outstanding (they complete in order): n = the DMA
+// instructions issued AFTER the row that must have landed.  Anything else issued after it (a y store, a residual load)
+// only makes the wait stricter than needed, never weaker.
+__device__ __forceinline__ void wait_vm(int n) {   // wave-uniform
+    if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- grid barrier: arrive / wait split, XCD-hierarchical counters, bounded spin ----------------------------------
+// newer: DMA instructions this wave issued after its last y store (they may stay in flight)
+__device__ __forceinline__ void grid_arrive(unsigned* sync, unsigned epoch, int newer) {
+    wait_vm(newer);        // every wave: its write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned grp = blockIdx.x & 7u, gsize = (gridDim.x - grp + 7u) / 8u;
+        const unsigned old = __hip_atomic_fetch_add(&sync[grp * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == epoch * gsize) __hip_atomic_fetch_add(&sync[SY_TOP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void grid_wait(unsigned* sync, unsigned epoch, int op_index) {
+    if (threadIdx.x == 0) {
+        const unsigned target = epoch * (gridDim.x < 8u ? gridDim.x : 8u);
+        if (__hip_atomic_load(&sync[SY_ERR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(&sync[SY_TOP], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) {   // give up: results are garbage, the host sees the error word
+                    __hip_atomic_store(&sync[SY_ERR], 1u + (unsigned)op_index, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ int fmt_bw(int dt) { return (dt == NTK_DT_Q8_0 || dt == NTK_DT_Q4_0) ? 32 : 256; }
+__device__ __forceinline__ int fmt_bb(int dt) {
+    return dt == NTK_DT_Q8_0 ? 34 : dt == NTK_DT_Q4_0 ? 18 : dt == NTK_DT_Q4_K ? 144 : dt == NTK_DT_Q5_K ? 176 : 210;
+}
+
+__device__ __forceinline__ void attn_unpack8(const u32x4 r, float (&f)[8]) {
+    f[0] = h2f((uint16_t)(r.x & 0xFFFF)); f[1] = h2f((uint16_t)(r.x >> 16));
+    f[2] = h2f((uint16_t)(r.y & 0xFFFF)); f[3] = h2f((uint16_t)(r.y >> 16));
+    f[4] = h2f((uint16_t)(r.z & 0xFFFF)); f[5] = h2f((uint16_t)(r.z >> 16));
+    f[6] = h2f((uint16_t)(r.w & 0xFFFF)); f[7] = h2f((uint16_t)(r.w >> 16));
+}
+
+// ---- RoPE + KV store + attention of one head by the whole workgroup: attention.hip's single-pass online softmax on 16
+//      waves.  The position groups of a wave merge in registers (shuffles), the 16 waves through 8 KB of LDS. ----
+template <int LPR>
+__device__ __attribute__((noinline)) void p_attention(const POp* op_arg, float* lds_arg, int pos_arg, int tid) {
+    constexpr int PPW = 64 / LPR, G = PW * PPW;
+    COp& op = *(COp*)uni_ptr(op_arg);
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_att[];
+    float* lds = reinterpret_cast<float*>(smem_att + P_RINGB);   // the activation-image region (not a flat pointer argument)
+    (void)lds_arg;
+    const int pos = uni(pos_arg);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hd = op.hd, n_kv = op.n_kv_heads, group = op.n_heads / n_kv, half_dim = hd / 2;
+    float* qs = lds;              // [hd] post-RoPE query
+    float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
+    float* vx = kx + hd;          // [hd] value of this token, rounded through half
+    float* ms = vx + hd;          // [PW] running maxima, one per wave
+    float* ls = ms + PW;          // [PW] running sums
+    float* accs = ls + PW;        // [PW][hd]
+    const size_t stride = (size_t)n_kv * hd;
+    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
+    for (int head = blockIdx.x; head < op.n_heads; head += gridDim.x) {
+        const int kv_head = head / group;
+        const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
+        const bool writer = (head % group == 0) && pos < op.max_seq;
+        const uint16_t* kbase = op.kc + (size_t)kv_head * hd + 8 * part_i;
+        const uint16_t* vbase = op.vc + (size_t)kv_head * hd + 8 * part_i;
+        int p = g;
+        u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
+        if (p < pos) {
+            kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
+            vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
+        }
+        for (int i = tid; i < half_dim; i += PT) {
+            const float a = ld_agent(op.q + (size_t)head * hd + i), b = ld_agent(op.q + (size_t)head * hd + i + half_dim);
+            const float ka = ld_agent(op.k + (size_t)kv_head * hd + i), kb = ld_agent(op.k + (size_t)kv_head * hd + i + half_dim);
+            // reference rotary.cu:46-60; inv_freq holds 1/powf(theta, 2i/hd) computed once on the host
+            const float freq = op.inv_freq ? op.inv_freq[i] : 1.0f / (float)pow((double)op.theta, (double)((2.0f * i) / hd));
+            const float angle = pos * freq * op.fscale;
+            const float c = cosf(angle), sn = sinf(angle);
+            qs[i] = a * c - b * sn; qs[i + half_dim] = b * c + a * sn;
+            const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
+            kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
+            if (writer) { op.kc[cache_row + i] = ha; op.kc[cache_row + i + half_dim] = hb; }
+        }
+        for (int i = tid; i < hd; i += PT) {
+            const uint16_t hv = f2h(ld_agent(op.v + (size_t)kv_head * hd + i));
+            vx[i] = h2f(hv);
+            if (writer) op.vc[cache_row + i] = hv;
+        }
+        __syncthreads();
+        float qreg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
+        float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (; p <= pos; p += G) {
+            float kf[8], vf[8];
+            if (p < pos) {
+                attn_unpack8(kraw, kf);
+                attn_unpack8(vraw, vf);
+            } else {   // the token being decoded
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
+            }
+            const int pn = p + G;
+            if (pn < pos) {
+                kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
+                vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
+            }
+            float sc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
+            sc = group_sum<LPR>(sc);
+            sc *= op.scale;
+            const float mn = fmaxf(m, sc);
+            const float a = expf(m - mn), pw = expf(sc - mn);
+            l = fmaf(l, a, pw);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, pw * vf[j]);
+            m = mn;
+        }
+        // merge the wave's PPW position groups (lanes part_i, part_i + LPR, ...): (m, l, acc) -> max-rescaled sums
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+            const float mn = fmaxf(m, mo);
+            const float wa = (m == -INFINITY) ? 0.0f : expf(m - mn), wb = (mo == -INFINITY) ? 0.0f : expf(mo - mn);
+            l = fmaf(l, wa, lo * wb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], wa, __shfl_xor(acc[j], off, 64) * wb);
+            m = mn;
+        }
+        if (lane == 0) { ms[wave] = m; ls[wave] = l; }
+        if (sub == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) accs[wave * hd + 8 * part_i + j] = acc[j];
+        }
+        __syncthreads();
+        for (int d = tid; d < hd; d += PT) {
+            float M = ms[0];
+            for (int i = 1; i < PW; ++i) M = fmaxf(M, ms[i]);
+            float L = 0.0f, o = 0.0f;
+            for (int i = 0; i < PW; ++i) {
+                const float w = (ms[i] == -INFINITY) ? 0.0f : expf(ms[i] - M);   // waves that saw no position
+                L = fmaf(w, ls[i], L);
+                o = fmaf(w, accs[i * hd + d], o);
+            }
+            st_agent(op.out + (size_t)head * hd + d, o / L);
+        }
+        __syncthreads();   // the scratch is reused by the next head / operator
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The wave's weight-row queue: two LDS slots filled by DMA, running ahead of the decode cursor ACROSS operators.
+// Everything in it is wave-uniform (scalar registers).  Between operators it is parked in a per-wave record (QState).
+// ------------------------------------------------------------------------------------------------------------------
+struct QState {
+    int f_op, f_q, f_n, f_seg, f_row, f_rows, f_step, f_silu;
+    unsigned f_slice_byte0, f_slice_bytes;
+    int q_cnt, q_rd, q_chunks_new, q_shift0, q_shift1, q_since;
+};
+
+struct Queue {
+    COp* ops;
+    int nops, wave;
+    uint32_t ring_lds;            // LDS byte address of the wave's two slots
+    // fetch cursor = the next row slice to request
+    int f_op, f_q, f_n;           // operator, item index, items of this wave in that operator
+    int f_seg, f_row, f_rows, f_step, f_silu;
+    unsigned f_slice_byte0, f_slice_bytes;
+    int q_cnt;                    // rows in the queue (0..2)
+    int q_rd;                     // slot of the oldest row
+    int q_chunks_new;             // DMA instructions of the NEWEST queued row
+    int q_shift0, q_shift1;       // byte offset of the slice inside slot 0 / 1
+    int q_since;                  // DMA instructions issued since mark() (= newer than the wave's last y store)
+
+    __device__ __forceinline__ static void wave_geom(COp& op, int wave, int& s, int& group, int& ngroups, int& n_my) {
+        const int rw = PW / op.ns;
+        s = wave % op.ns;
+        group = (int)blockIdx.x * rw + wave / op.ns;
+        ngroups = (int)gridDim.x * rw;
+        const int mats = (op.flags & PF_SILU) ? 2 : 1;
+        n_my = (op.total_rows > group) ? ((op.total_rows - 1 - group) / ngroups + 1) * mats : 0;
+    }
+    __device__ __forceinline__ void reset() {
+        f_op = -1; f_q = f_n = 0; f_seg = f_row = f_rows = f_step = f_silu = 0; f_slice_byte0 = f_slice_bytes = 0;
+        q_cnt = q_rd = q_chunks_new = q_shift0 = q_shift1 = 0;
+        q_since = 0;
+    }
+#define NTK_RFL(x) __builtin_amdgcn_readfirstlane(x)
+    __device__ __forceinline__ void load(const QState& st) {   // the record is per-lane memory: make the copies scalar again
+        f_op = NTK_RFL(st.f_op); f_q = NTK_RFL(st.f_q); f_n = NTK_RFL(st.f_n); f_seg = NTK_RFL(st.f_seg);
+        f_row = NTK_RFL(st.f_row); f_rows = NTK_RFL(st.f_rows); f_step = NTK_RFL(st.f_step); f_silu = NTK_RFL(st.f_silu);
+        f_slice_byte0 = NTK_RFL(st.f_slice_byte0); f_slice_bytes = NTK_RFL(st.f_slice_bytes);
+        q_cnt = NTK_RFL(st.q_cnt); q_rd = NTK_RFL(st.q_rd); q_chunks_new = NTK_RFL(st.q_chunks_new);
+        q_shift0 = NTK_RFL(st.q_shift0); q_shift1 = NTK_RFL(st.q_shift1);
+        q_since = 0;
+    }
+#undef NTK_RFL
+    __device__ __forceinline__ void save(QState& st) const {
+        if ((threadIdx.x & 63) != 0) return;   // one lane writes the wave's record
+        st.f_op = f_op; st.f_q = f_q; st.f_n = f_n; st.f_seg = f_seg; st.f_row = f_row; st.f_rows = f_rows; st.f_step = f_step;
+        st.f_silu = f_silu; st.f_slice_byte0 = f_slice_byte0; st.f_slice_bytes = f_slice_bytes;
+        st.q_cnt = q_cnt; st.q_rd = q_rd; st.q_chunks_new = q_chunks_new; st.q_shift0 = q_shift0; st.q_shift1 = q_shift1;
+        st.q_since = q_since;
+    }
+    __device__ __forceinline__ void fetch_next_op() {   // move the fetch cursor to the next GEMV operator in which this wave owns rows
+        f_n = 0;
+        for (++f_op; f_op < nops; ++f_op) {
+            COp& op = ops[f_op];
+            if (op.kind != PK_GEMV) continue;
+            int s, group, ngroups, n_my;
+            wave_geom(op, wave, s, group, ngroups, n_my);
+            if (n_my <= 0) continue;
+            f_n = n_my; f_q = 0; f_step = ngroups; f_silu = (op.flags & PF_SILU) ? 1 : 0;
+            const int my_len = min(op.slice_cols, op.in - s * op.slice_cols);
+            f_slice_byte0 = (unsigned)((size_t)s * op.slice_cols / fmt_bw(op.dtype) * fmt_bb(op.dtype));
+            f_slice_bytes = (unsigned)(my_len / fmt_bw(op.dtype) * fmt_bb(op.dtype));
+            f_seg = 0; f_row = group; f_rows = f_silu ? 0x7fffffff : op.seg[0].rows;
+            while (!f_silu && f_seg + 1 < op.nseg && f_row >= f_rows) { f_row -= f_rows; ++f_seg; f_rows = op.seg[f_seg].rows; }
+            return;
+        }
+    }
+    __device__ __forceinline__ void issue(int lane) {   // request the row slice under the fetch cursor into the free slot
+        COp& op = ops[f_op];
+        const unsigned rel = (unsigned)f_row * op.row_bytes + f_slice_byte0;
+        const unsigned shift = rel & 15u;
+        const unsigned nbytes = shift + f_slice_bytes;
+        const int slot = (q_rd + q_cnt) & 1;
+        if (slot) q_shift1 = (int)shift; else q_shift0 = (int)shift;
+        const uint8_t* a = op.seg[f_seg].W + (rel & ~15u) + 16u * (unsigned)lane;
+        const uint32_t dst = ring_lds + (uint32_t)slot * P_SLOT;   // wave-uniform
+        const int chunks = (int)((nbytes + 1023u) >> 10);
+        for (int j = 0; j < chunks; ++j) {
+            if (16u * (unsigned)lane + 1024u * (unsigned)j < nbytes)
+                dma16(__builtin_amdgcn_readfirstlane(dst + 1024u * (uint32_t)j), a + 1024u * (unsigned)j);
+        }
+        q_chunks_new = chunks;
+        q_since += chunks;
+        ++q_cnt;
+        if (++f_q < f_n) {
+            if (f_silu) {
+                if (f_seg == 0) f_seg = 1; else { f_seg = 0; f_row += f_step; }
+            } else {
+                f_row += f_step;
+                while (f_seg + 1 < op.nseg && f_row >= f_rows) { f_row -= f_rows; ++f_seg; f_rows = op.seg[f_seg].rows; }
+            }
+        } else {
+            fetch_next_op();
+        }
+    }
+    __device__ __forceinline__ void fill(int lane) { while (q_cnt < P_RING && f_n > 0) issue(lane); }
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// One GEMV operator of the token for one weight format: activation prologue + this wave's rows.  Inlined into the kernel
+// (a real call would park registers in scratch, and a scratch reload queues behind the weight DMA: measured 3-5 us per
+// operator); the kernel is instantiated per SET of formats a model uses, so a single-format model (Q8_0, Q6_K) gets the
+// register allocation of a single-format kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int DT>
+__device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, int tid, unsigned long long* dbg) {
+    constexpr bool A16 = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);   // K-quant blocks of 144 / 176 B: slices start 16-byte aligned
+    auto stamp = [&](int i) { if (dbg && tid == 0) dbg[i] = wall_clock64(); };
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = tid & 63;
+    const int wave = Q.wave;
+    uint8_t* ring = smem + (size_t)wave * (P_RING * P_SLOT);     // this wave's two slots
+    float* ximg = reinterpret_cast<float*>(smem + P_RINGB);
+    float* part = reinterpret_cast<float*>(smem + P_RINGB + P_XIMG);
+    float* red = part + 2 * PW * RB;
+    const int dummy = 64 * XPITCH + 2 * PW * RB + 32;   // (floats from ximg) 16 spare floats at the end of the allocation
+
+    COp& op = ops[k];
+    int s, group, ngroups, n_my;
+    Queue::wave_geom(op, wave, s, group, ngroups, n_my);
+    const int ns = op.ns;
+    const bool silu = (op.flags & PF_SILU) != 0, plain = (op.flags & PF_PLAIN) != 0;
+    const int mats = silu ? 2 : 1;
+    const int my_len = min(op.slice_cols, op.in - s * op.slice_cols);
+    const int ncols = min(64, max(0, my_len - 64 * lane));
+    // decode cursor
+    int cu_seg = 0, cu_row = group, cu_rows = silu ? 0x7fffffff : op.seg[0].rows;
+    auto cursor_normalise = [&]() {
+        while (cu_seg + 1 < op.nseg && cu_row >= cu_rows) { cu_row -= cu_rows; ++cu_seg; cu_rows = op.seg[cu_seg].rows; }
+    };
+    if (!silu) cursor_normalise();
+    auto cursor_advance = [&]() {
+        if (silu) {
+            if (cu_seg == 0) cu_seg = 1; else { cu_seg = 0; cu_row += ngroups; }
+        } else {
+            cu_row += ngroups;
+            cursor_normalise();
+        }
+    };
+    auto locate = [&](int q, int& seg, int& row) {   // per-lane form (cross-slice combine)
+        int r = group + (q >> (mats - 1)) * ngroups;
+        if (silu) { seg = q & 1; row = r; return; }
+        seg = 0;
+        while (seg + 1 < op.nseg && r >= op.seg[seg].rows) { r -= op.seg[seg].rows; ++seg; }
+        row = r;
+    };
+    // residual of the wave's first row (ns == 1) / first batch (ns > 1): requested now, hidden by the prologue
+    float res_next = 0.0f, res_pf = 0.0f;
+    const bool has_res = op.resid != nullptr;
+    if (has_res && ns == 1 && n_my > 0 && cu_seg == 0) res_next = ld_agent(op.resid + cu_row);
+    auto prefetch_resid = [&](int b) {
+        if (!has_res || s != 0 || lane >= RB || b * RB + lane >= n_my) return;
+        int seg, row;
+        locate(b * RB + lane, seg, row);
+        res_pf = ld_agent(op.resid + row);
+    };
+    if (ns > 1) prefetch_resid(0);
+    stamp(4);
+
+    // ---- prologue: the lane's 64 activations into registers.  Slice sp of x (<= 4096 columns = one float4 per thread)
+    //      goes through the padded LDS image; the waves that own slice sp read their lane rows back. ----
+    f32x2 x2[32];
+    {
+        const bool have_lo = ncols > 0, have_hi = ncols > 32;
+        auto read_own_row = [&]() {
+            const float* xr0 = ximg + lane * XPITCH, *xr1 = xr0 + 32;
+            if constexpr (DT == NTK_DT_Q6_K) {   // lane owns columns 32t + [0,32) of image rows (lane & ~1), (lane | 1): see Dot<Q6_K>
+                xr0 = ximg + (lane & ~1) * XPITCH + 32 * (lane & 1);
+                xr1 = xr0 + XPITCH;
+            }
+#pragma unroll
+            for (int j = 0; j < 64; j += 4) {
+                const float4 v = *reinterpret_cast<const float4*>((j < 32 ? xr0 : xr1 - 32) + j);
+                const bool have = j < 32 ? have_lo : have_hi;
+                x2[j / 2] = f32x2{have ? v.x : 0.0f, have ? v.y : 0.0f};
+                x2[j / 2 + 1] = f32x2{have ? v.z : 0.0f, have ? v.w : 0.0f};
+            }
+        };
+        const int cc = tid * 4;                       // this thread's column inside a slice
+        const int img = (cc >> 6) * XPITCH + (cc & 63);
+        auto xaddr = [&](int sp) { return op.x + min(min(sp, ns - 1) * op.slice_cols + cc, op.in - 4); };
+        u32x4 xv[4];
+        const bool norm = (op.flags & PF_NORM) != 0;
+        if (norm) {   // in <= 8192 (plan): ns <= 2, both slices are loaded and normalised here
+            u32x4 wv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wv[i] = *reinterpret_cast<const u32x4*>(op.norm_w + min(min(i, ns - 1) * op.slice_cols + cc, op.in - 4));
+            ld16_agent_x2(xv[0], xv[1], xaddr(0), xaddr(1));
+            float ssq = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int len = i < ns ? min(op.slice_cols, op.in - i * op.slice_cols) : 0;
+                const float m = cc < len ? 1.0f : 0.0f;
+                const float x0 = __uint_as_float(xv[i].x), x1 = __uint_as_float(xv[i].y), x2_ = __uint_as_float(xv[i].z), x3 = __uint_as_float(xv[i].w);
+                ssq = fmaf(x0 * m, x0, ssq); ssq = fmaf(x1 * m, x1, ssq); ssq = fmaf(x2_ * m, x2_, ssq); ssq = fmaf(x3 * m, x3, ssq);
+            }
+            ssq = wave_sum(ssq);
+            if (lane == 0) red[wave] = ssq;
+            __syncthreads();
+            float tot = 0.0f;
+            for (int w = 0; w < PW; ++w) tot += red[w];
+            const float rms_inv = 1.0f / sqrtf(tot / (float)op.in + op.eps);   // rsqrtf(mean + eps), rmsnorm.cu:60-61
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {   // x * rms_inv * w, the reference's association (rmsnorm.cu:68)
+                xv[i].x = __float_as_uint(__uint_as_float(xv[i].x) * rms_inv * __uint_as_float(wv[i].x));
+                xv[i].y = __float_as_uint(__uint_as_float(xv[i].y) * rms_inv * __uint_as_float(wv[i].y));
+                xv[i].z = __float_as_uint(__uint_as_float(xv[i].z) * rms_inv * __uint_as_float(wv[i].z));
+                xv[i].w = __float_as_uint(__uint_as_float(xv[i].w) * rms_inv * __uint_as_float(wv[i].w));
+            }
+            xv[2] = xv[0]; xv[3] = xv[1];
+        }
+        stamp(5);
+        // one image pass per column slice; ONE copy of the own-row read in the code: the loop stays rolled, the slice's
+        // float4 is picked by wave-uniform selects
+#pragma clang loop unroll(disable)
+        for (int sp = 0; sp < ns; ++sp) {
+            const int i = sp & 3;
+            if (i == 0 && !norm) {
+                if (ns - sp >= 3) ld16_agent_x4(xv[0], xv[1], xv[2], xv[3], xaddr(sp), xaddr(sp + 1), xaddr(sp + 2), xaddr(sp + 3));
+                else if (ns - sp == 2) ld16_agent_x2(xv[0], xv[1], xaddr(sp), xaddr(sp + 1));
+                else ld16_agent_x1(xv[0], xaddr(sp));
+            }
+            const u32x4 v = i == 0 ? xv[0] : i == 1 ? xv[1] : i == 2 ? xv[2] : xv[3];
+            const int len = min(op.slice_cols, op.in - sp * op.slice_cols);
+            *reinterpret_cast<u32x4*>(ximg + (cc < len ? img : dummy)) = v;
+            __syncthreads();
+            if (s == sp) read_own_row();
+            __syncthreads();
+        }
+    }
+    float sx16[4], sx32[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += x2[8 * r + j].x + x2[8 * r + j].y;
+        sx16[r] = t;
+    }
+    sx32[0] = sx16[0] + sx16[1];
+    sx32[1] = sx16[2] + sx16[3];
+    if constexpr (DT == NTK_DT_Q4_K) {   // high nibbles are used in place (byte value 16 n): those activations carry 1/16
+#pragma unroll
+        for (int j = 16; j < 32; ++j) x2[j] *= 0.0625f;
+    }
+    if constexpr (DT == NTK_DT_Q4_0) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) if ((j & 8) != 0) x2[j] *= 0.0625f;
+    }
+    float gate_carry = 0.0f;
+    stamp(6);
+
+    auto store_y = [&](float* p, float v) { if (plain) *p = v; else st_agent(p, v); };
+    auto combine = [&](int b, int cnt) {   // ns > 1: wave s == 0 of each row group sums the slice partials of batch b
+        if (s != 0) return;
+        const float* pg = part + (size_t)(b & 1) * PW * RB + (size_t)wave * RB;   // wave = g * ns (s == 0)
+        float t = 0.0f;
+        if (lane < cnt)
+            for (int ss = 0; ss < ns; ++ss) t += pg[ss * RB + lane];
+        const float nxt = __shfl_down(t, 1, 64);
+        if (lane < cnt) {
+            int seg, row;
+            locate(b * RB + lane, seg, row);
+            if (silu) {
+                if ((lane & 1) == 0) store_y(op.seg[0].y + row, t / (1.0f + expf(-t)) * nxt);
+            } else {
+                float v = t;
+                if (has_res && seg == 0) v = res_pf + v;
+                store_y(op.seg[seg].y + row, v);
+            }
+        }
+        prefetch_resid(b + 1);
+    };
+
+    // ---- rows: slot q_rd holds row q (or is landing), the other slot row q+1 -------------------------------
+    for (int q = 0; q < n_my; ++q) {
+        const int seg = cu_seg, row = cu_row;
+        const float res = res_next;
+        if (q + 1 < n_my) {
+            cursor_advance();
+            if (has_res && ns == 1 && cu_seg == 0) res_next = ld_agent(op.resid + cu_row);
+        }
+        wait_vm(Q.q_cnt > 1 ? Q.q_chunks_new : 0);       // the oldest queued row has landed in LDS
+        const uint8_t* st = ring + Q.q_rd * P_SLOT;
+        const float acc = Dot<DT, A16>::run(st, A16 ? 0 : (Q.q_rd ? Q.q_shift1 : Q.q_shift0), lane, ncols, x2, sx16, sx32);
+        __builtin_amdgcn_wave_barrier();   // all reads of the slot precede the DMA that refills it
+        Q.q_rd ^= 1;
+        --Q.q_cnt;
+        // The freed slot takes the wave's next row -- except behind the operator's last two rows: vector-memory operations
+        // complete in order, so a row requested now would sit in front of the final y store and the arrival would have to wait
+        // for it (measured 3-4 us).  The queue drains instead and is refilled (two rows) right after the last store.
+        if (q + 2 < n_my) Q.fill(lane);
+        const float tot = wave_sum_lane63(acc);
+        if (ns == 1) {
+            if (lane == 63) {
+                if (silu) {
+                    if ((q & 1) == 0) gate_carry = tot;
+                    else store_y(op.seg[0].y + row, gate_carry / (1.0f + expf(-gate_carry)) * tot);   // gemm.cu:719-724
+                } else {
+                    float v = tot;
+                    if (has_res && seg == 0) v = res + v;                                            // elementwise.cu:23-32
+                    store_y(op.seg[seg].y + row, v);
+                }
+            }
+        } else {
+            const int b = q / RB, i = q % RB;
+            if (lane == 63) part[(size_t)(b & 1) * PW * RB + (size_t)wave * RB + i] = tot;
+            if (i == RB - 1) {
+                __syncthreads();
+                combine(b, RB);
+            }
+        }
+    }
+    if (ns > 1) {   // close a partial batch, keep barrier counts equal across the workgroup
+        int done = n_my / RB;
+        if (n_my % RB) {
+            __syncthreads();
+            combine(done, n_my % RB);
+            ++done;
+        }
+        for (; done < op.nbatch; ++done) __syncthreads();
+    }
+    // After the wave's LAST y store: refill the queue with rows of the next operators.  Everything requested from here on is
+    // newer than the stores, so the arrival only has to wait until at most `q_since` vector-memory operations are outstanding.
+    Q.q_since = 0;
+    Q.fill(lane);
+    stamp(7);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------------------------
+// dbg (optional): per operator 8 timestamps (100 MHz wall clock) of wave 0 of workgroups 0 and gridDim/2:
+// [k][w][0] operator reached, [1] grid wait passed, [2] operator body done, [3] arrived, [4..7] inside a GEMV operator
+constexpr unsigned fmt_bit(int dt) { return 1u << dt; }
+template <unsigned MASK>
+__global__ __launch_bounds__(PT) void decode_persistent_kernel(const POp* __restrict__ ops_arg, int nops, unsigned* sync,
+                                                               const int* __restrict__ d_pos, unsigned long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    COp* ops = (COp*)ops_arg;
+    const int tid0 = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    float* ximg = reinterpret_cast<float*>(smem + P_RINGB);
+    Queue Q;
+    Q.ops = ops; Q.nops = nops; Q.wave = wave;
+    Q.ring_lds = (uint32_t)(uintptr_t)(smem + (size_t)wave * (P_RING * P_SLOT));   // generic -> LDS address: low 32 bits
+    Q.reset();
+    Q.fetch_next_op();
+    Q.fill(tid0 & 63);   // the wave's first two row slices are on their way
+    const int pos = *d_pos;
+    unsigned epoch = 0;
+    const int dbg_w = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
+    auto stamp = [&](int k, int i) {
+        if (dbg && dbg_w >= 0 && tid0 == 0) dbg[((size_t)k * 2 + dbg_w) * 8 + i] = wall_clock64();
+    };
+    for (int k = 0; k < nops; ++k) {
+        COp& op = ops[k];
+        // Re-derive the thread index behind an opaque barrier every operator: otherwise every lane-dependent address of every
+        // operator kind is loop-invariant, gets hoisted out of this loop and stays live (and spilled) for the whole token.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        stamp(k, 0);
+        if (op.flags & PF_WAIT) grid_wait(sync, epoch, k);
+        stamp(k, 1);
+        int since = 0;
+        if (op.kind == PK_ATTN) {
+            if ((int)blockIdx.x < op.n_heads) {   // the other workgroups go straight to the arrival
+                if (op.hd == 128) p_attention<16>((const POp*)&op, ximg, pos, tid);
+                else p_attention<8>((const POp*)&op, ximg, pos, tid);
+            }
+        } else {
+            unsigned long long* rec = (dbg && dbg_w >= 0) ? dbg + ((size_t)k * 2 + dbg_w) * 8 : nullptr;
+            const int dt = op.dtype;   // wave-uniform
+            if ((MASK & fmt_bit(NTK_DT_Q8_0)) && (MASK == fmt_bit(NTK_DT_Q8_0) || dt == NTK_DT_Q8_0)) p_gemv_op<NTK_DT_Q8_0>(ops, nops, k, Q, tid, rec);
+            else if ((MASK & fmt_bit(NTK_DT_Q4_0)) && (MASK == fmt_bit(NTK_DT_Q4_0) || dt == NTK_DT_Q4_0)) p_gemv_op<NTK_DT_Q4_0>(ops, nops, k, Q, tid, rec);
+            else if ((MASK & fmt_bit(NTK_DT_Q4_K)) && (MASK == fmt_bit(NTK_DT_Q4_K) || dt == NTK_DT_Q4_K)) p_gemv_op<NTK_DT_Q4_K>(ops, nops, k, Q, tid, rec);
+            else if ((MASK & fmt_bit(NTK_DT_Q5_K)) && (MASK == fmt_bit(NTK_DT_Q5_K) || dt == NTK_DT_Q5_K)) p_gemv_op<NTK_DT_Q5_K>(ops, nops, k, Q, tid, rec);
+            else if ((MASK & fmt_bit(NTK_DT_Q6_K)) && (MASK == fmt_bit(NTK_DT_Q6_K) || dt == NTK_DT_Q6_K)) p_gemv_op<NTK_DT_Q6_K>(ops, nops, k, Q, tid, rec);
+            since = Q.q_since;
+        }
+        stamp(k, 2);
+        // a GEMV operator's final refill is issued after its last y store: the arrival waits for the stores, not for those rows
+        if (op.flags & PF_ARRIVE) grid_arrive(sync, ++epoch, since);
+        stamp(k, 3);
+    }
+}
+
+constexpr unsigned M_Q8 = fmt_bit(NTK_DT_Q8_0), M_Q40 = fmt_bit(NTK_DT_Q4_0), M_Q4K = fmt_bit(NTK_DT_Q4_K), M_Q5K = fmt_bit(NTK_DT_Q5_K),
+                   M_Q6K = fmt_bit(NTK_DT_Q6_K), M_ALL = M_Q8 | M_Q40 | M_Q4K | M_Q5K | M_Q6K;
+typedef void (*PersistentKernel)(const POp*, int, unsigned*, const int*, unsigned long long*);
+static PersistentKernel pick_kernel(unsigned mask) {   // the smallest instantiation that covers the model's formats
+    if (mask == M_Q8) return decode_persistent_kernel<M_Q8>;
+    if (mask == M_Q40) return decode_persistent_kernel<M_Q40>;
+    if (mask == M_Q4K) return decode_persistent_kernel<M_Q4K>;
+    if (mask == M_Q5K) return decode_persistent_kernel<M_Q5K>;
+    if (mask == M_Q6K) return decode_persistent_kernel<M_Q6K>;
+    if ((mask & ~(M_Q4K | M_Q6K)) == 0) return decode_persistent_kernel<M_Q4K | M_Q6K>;              // llama.cpp Q4_K_M at 8B
+    if ((mask & ~(M_Q4K | M_Q5K | M_Q6K)) == 0) return decode_persistent_kernel<M_Q4K | M_Q5K | M_Q6K>;   // ... at 70B
+    return decode_persistent_kernel<M_ALL>;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+struct PersistentPlan {
+    POp* d_ops = nullptr;
+    unsigned* d_sync = nullptr;
+    unsigned long long* d_dbg = nullptr;   // optional timestamps (ntk_persistent_debug)
+    PersistentKernel kernel = nullptr;
+    int nops = 0;
+    int grid = 0;
+};
+
+static int fmt_host(int dt, int& bw, int& bb, int& nl) {
+    switch (dt) {
+        case NTK_DT_Q8_0: bw = 32; bb = 34; nl = 5; return NTK_OK;
+        case NTK_DT_Q4_0: bw = 32; bb = 18; nl = 3; return NTK_OK;
+        case NTK_DT_Q4_K: bw = 256; bb = 144; nl = 3; return NTK_OK;
+        case NTK_DT_Q5_K: bw = 256; bb = 176; nl = 3; return NTK_OK;
+        case NTK_DT_Q6_K: bw = 256; bb = 210; nl = 4; return NTK_OK;
+        default: return NTK_E_DTYPE;
+    }
+}
+
+}  // namespace ntk
+
+extern "C" {
+
+using namespace ntk;
+
+int ntk_persistent_plan_create(const ntk_pop* ops, int nops, void** plan_out) {
+    if (!ops || !plan_out || nops <= 0) return NTK_E_NULL;
+    *plan_out = nullptr;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NTK_E_NODEVICE;
+    unsigned mask = 0;
+    for (int i = 0; i < nops; ++i)
+        if (ops[i].kind == NTK_POP_GEMV && ops[i].nseg >= 1 && ops[i].segs[0].dtype >= 0 && ops[i].segs[0].dtype < 31)
+            mask |= fmt_bit(ops[i].segs[0].dtype);
+    if (mask == 0 || (mask & ~M_ALL)) return NTK_E_DTYPE;
+    const PersistentKernel kernel = pick_kernel(mask);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS) != hipSuccess)
+        return NTK_E_LAUNCH;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PT, P_LDS) != hipSuccess || per_cu < 1) return NTK_E_LAUNCH;
+    int grid = prop.multiProcessorCount;   // one workgroup per CU: every workgroup is resident, the grid barrier cannot strand one
+    if (const char* e = getenv("NTK_PERSISTENT_GRID")) grid = std::max(1, std::min(grid, atoi(e)));
+    std::vector<POp> dev_ops((size_t)nops);
+    for (int i = 0; i < nops; ++i) {
+        const ntk_pop& a = ops[i];
+        POp& o = dev_ops[i];
+        memset(&o, 0, sizeof o);
+        o.flags = (a.wait ? PF_WAIT : 0) | (a.arrive ? PF_ARRIVE : 0);
+        if (a.kind == NTK_POP_ATTENTION) {
+            o.kind = PK_ATTN;
+            if (!a.q || !a.k || !a.v || !a.out || !a.k_cache || !a.v_cache) return NTK_E_NULL;
+            if (a.n_heads <= 0 || a.n_kv_heads <= 0 || a.n_heads % a.n_kv_heads != 0) return NTK_E_SHAPE;
+            if (a.head_dim != 64 && a.head_dim != 128 && a.head_dim != 256) return NTK_E_SHAPE;
+            if ((reinterpret_cast<uintptr_t>(a.k_cache) & 15) || (reinterpret_cast<uintptr_t>(a.v_cache) & 15)) return NTK_E_ALIGN;
+            o.q = a.q; o.k = a.k; o.v = a.v; o.out = a.out;
+            o.kc = static_cast<uint16_t*>(a.k_cache); o.vc = static_cast<uint16_t*>(a.v_cache);
+            o.inv_freq = a.inv_freq;
+            o.n_heads = a.n_heads; o.n_kv_heads = a.n_kv_heads; o.hd = a.head_dim; o.max_seq = a.max_seq;
+            o.scale = a.scale; o.theta = a.theta_base; o.fscale = a.freq_scale;
+            continue;
+        }
+        if (a.kind != NTK_POP_GEMV) return NTK_E_SHAPE;
+        o.kind = PK_GEMV;
+        if (a.nseg < 1 || a.nseg > MAX_SEG || !a.x) return NTK_E_SHAPE;
+        int bw, bb, nl;
+        const int dt = a.segs[0].dtype;
+        if (fmt_host(dt, bw, bb, nl) != NTK_OK) return NTK_E_DTYPE;
+        const int in = a.in_features;
+        if (in <= 0 || in % bw != 0 || in % 4 != 0) return NTK_E_SHAPE;
+        const size_t row_bytes = (size_t)in / bw * bb;
+        long total = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            if (a.segs[s].dtype != dt) return NTK_E_DTYPE;
+            if (a.segs[s].rows <= 0 || !a.segs[s].W || !a.segs[s].y) return NTK_E_NULL;
+            if ((size_t)a.segs[s].rows * row_bytes > 0xFFFFFFF0ull) return NTK_E_SHAPE;
+            if (reinterpret_cast<uintptr_t>(a.segs[s].W) & 15) return NTK_E_ALIGN;
+            o.seg[s].W = static_cast<const uint8_t*>(a.segs[s].W);
+            o.seg[s].y = a.segs[s].y;
+            o.seg[s].rows = a.segs[s].rows;
+            total += a.segs[s].rows;
+        }
+        if (a.silu_pair) {
+            if (a.nseg != 2 || a.segs[0].rows != a.segs[1].rows || a.resid) return NTK_E_SHAPE;
+            total = a.segs[0].rows;
+            o.flags |= PF_SILU;
+        }
+        if (reinterpret_cast<uintptr_t>(a.x) & 15) return NTK_E_ALIGN;
+        if (a.norm_w) {
+            if ((reinterpret_cast<uintptr_t>(a.norm_w) & 15) || in > 2 * PT * 4) return NTK_E_SHAPE;
+            o.flags |= PF_NORM;
+        }
+        if (a.plain_store) o.flags |= PF_PLAIN;
+        o.dtype = dt; o.nseg = a.nseg; o.total_rows = (int)total; o.in = in; o.nl = nl;
+        // column slices: a power of two so that the 16 waves of a workgroup split evenly into row groups
+        int ns = 1;
+        while (ns * 4096 < in) ns *= 2;
+        if (ns > 8) return NTK_E_SHAPE;
+        const int align = bw == 256 ? 256 : 64;
+        o.ns = ns;
+        o.slice_cols = ((in + ns - 1) / ns + align - 1) / align * align;
+        if ((long)(ns - 1) * o.slice_cols >= in || o.slice_cols % 4 != 0 || o.slice_cols > 4096) return NTK_E_SHAPE;
+        const int rw = PW / ns, mats = a.silu_pair ? 2 : 1;
+        const long ngroups = (long)grid * rw;
+        const long rows_per_group = (total + ngroups - 1) / ngroups;
+        o.nbatch = (int)((rows_per_group * mats + RB - 1) / RB);
+        o.row_bytes = (unsigned)row_bytes;
+        o.eps = a.eps;
+        o.x = a.x; o.norm_w = a.norm_w; o.resid = a.resid;
+    }
+    PersistentPlan* p = new PersistentPlan();
+    p->nops = nops;
+    p->grid = grid;
+    p->kernel = kernel;
+    if (hipMalloc(reinterpret_cast<void**>(&p->d_ops), sizeof(POp) * (size_t)nops) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&p->d_sync), SY_WORDS * sizeof(unsigned)) != hipSuccess ||
+        hipMemcpy(p->d_ops, dev_ops.data(), sizeof(POp) * (size_t)nops, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(p->d_sync, 0, SY_WORDS * sizeof(unsigned)) != hipSuccess) {
+        if (p->d_ops) (void)hipFree(p->d_ops);
+        if (p->d_sync) (void)hipFree(p->d_sync);
+        delete p;
+        return NTK_E_NOMEM;
+    }
+    *plan_out = p;
+    return NTK_OK;
+}
+
+void ntk_persistent_plan_destroy(void* plan) {
+    PersistentPlan* p = static_cast<PersistentPlan*>(plan);
+    if (!p) return;
+    if (p->d_ops) (void)hipFree(p->d_ops);
+    if (p->d_sync) (void)hipFree(p->d_sync);
+    if (p->d_dbg) (void)hipFree(p->d_dbg);
+    delete p;
+}
+
+int ntk_persistent_launch(void* plan, const int* d_pos, void* stream) {
+    PersistentPlan* p = static_cast<PersistentPlan*>(plan);
+    if (!p || !d_pos) return NTK_E_NULL;
+    hipStream_t st = resolve_stream(stream);
+    // every polled word is zeroed in front of every launch (a memset node when captured): epochs count within the launch.
+    // The error word survives until the host reads it (ntk_persistent_error clears it).
+    if (hipMemsetAsync(p->d_sync, 0, SY_ERR * sizeof(unsigned), st) != hipSuccess) return NTK_E_LAUNCH;
+    hipLaunchKernelGGL(p->kernel, dim3(p->grid), dim3(PT), P_LDS, st, (const POp*)p->d_ops, p->nops, p->d_sync, d_pos, p->d_dbg);
+    return last_launch_status();
+}
+
+int ntk_persistent_error(void* plan, int* op_index_out) {
+    PersistentPlan* p = static_cast<PersistentPlan*>(plan);
+    if (!p) return NTK_E_NULL;
+    unsigned e = 0;
+    if (hipMemcpy(&e, p->d_sync + SY_ERR, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
+    if (op_index_out) *op_index_out = e ? (int)e - 1 : -1;
+    if (e) {
+        (void)hipMemset(p->d_sync + SY_ERR, 0, sizeof(unsigned));
+        return NTK_E_LAUNCH;
+    }
+    return NTK_OK;
+}
+
+// Debug: enable per-operator timestamps for launches made AFTER this call (graphs captured before keep their argument), or read
+// them back: out[nops][2][4] ticks of the 100 MHz wall clock (workgroups 0 and grid/2, wave 0).  Returns the operator count.
+int ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int cap_ops) {
+    PersistentPlan* p = static_cast<PersistentPlan*>(plan);
+    if (!p) return NTK_E_NULL;
+    if (enable && !p->d_dbg) {
+        if (hipMalloc(reinterpret_cast<void**>(&p->d_dbg), sizeof(unsigned long long) * 16 * (size_t)p->nops) != hipSuccess) return NTK_E_NOMEM;
+        (void)hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)p->nops);
+    }
+    if (out && p->d_dbg) {
+        const int n = cap_ops < p->nops ? cap_ops : p->nops;
+        if (hipMemcpy(out, p->d_dbg, sizeof(unsigned long long) * 16 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
+    }
+    return p->nops;
+}
+
+int ntk_persistent_grid(void* plan) {
+    PersistentPlan* p = static_cast<PersistentPlan*>(plan);
+    return p ? p->grid : 0;
+}
+
+}  // extern "C"

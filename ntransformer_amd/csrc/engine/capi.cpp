@@ -53,6 +53,7 @@ int nt_engine_set_option(nt_engine_t e, const char* key, const char* value) {
     else if (k == "graph") E(e)->options().graph = on;
     else if (k == "batched_prefill") { E(e)->options().batched_prefill = on; E(e)->model().set_batched_prefill(on); }
     else if (k == "device_sampling") E(e)->options().device_sampling = on;
+    else if (k == "persistent") { E(e)->options().persistent = on; E(e)->model().set_persistent(on); }
     else if (k == "synth_threads") E(e)->options().synth_threads = atoi(value);
     else return NTK_E_SHAPE;
     return NTK_OK;
@@ -128,8 +129,13 @@ int nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, flo
     if (rc != NTK_OK) return rc;
     rc = m.decode_step_fused(false, use_graph != 0);
     if (rc != NTK_OK) return rc;
-    return m.copy_logits(logits_out);
+    rc = m.copy_logits(logits_out);
+    if (rc != NTK_OK) return rc;
+    return m.check_persistent();
 }
+
+void* nt_engine_persistent_plan(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().persistent_plan() : nullptr; }
+const char* nt_engine_decode_path(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().decode_path() : ""; }
 
 int nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int* out) {
     if (!e || !E(e)->loaded()) return NTK_E_NULL;

@@ -106,6 +106,7 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
         if (!emit(next)) break;
     }
     stats_.decode_ms = ms_since(d0);
+    if (rc == NTK_OK && opt_.fused) rc = model_.check_persistent();
     if (rc != NTK_OK) err_ = std::string("decode failed: ") + ntk_status_string(rc);
     return rc;
 }
@@ -124,7 +125,7 @@ int Engine::decode_greedy_steps(int token, int pos, int n, int* out) {
             next = model_.host_token();
             if (out) out[i] = next;
         }
-        return NTK_OK;
+        return model_.check_persistent();   // a bounded in-kernel wait that gave up invalidates the run (and disables the path)
     }
     std::vector<float> host(model_.config().vocab_size);
     for (int i = 0; i < n; ++i) {

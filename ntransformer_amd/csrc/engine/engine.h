@@ -39,6 +39,7 @@ struct EngineOptions {
     bool graph = true;            // replay the fused token from a hipGraph
     bool batched_prefill = true;  // prompts: one pass over each weight matrix per 16 tokens (false: per-token GEMV loops)
     bool device_sampling = true;  // greedy argmax on the device when temperature <= 0 and repeat_penalty <= 1
+    bool persistent = false;      // short contexts: the whole token in one persistent launch (decode_persistent.hip)
     int synth_threads = 0;        // 0 = hardware concurrency
 };
 

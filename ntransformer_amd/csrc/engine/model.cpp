@@ -30,6 +30,8 @@ void Model::free_all() {
             if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx));
             gx = nullptr;
         }
+    if (persistent_plan_) ntk_persistent_plan_destroy(persistent_plan_);
+    persistent_plan_ = nullptr;
     for (void* p : allocs_) nt_hip_free(p);
     allocs_.clear();
     if (h_token_) nt_hip_free_host(h_token_);
@@ -174,6 +176,7 @@ int Model::finish_load(int /*max_context*/) {
     stream_ = ntk_stream(0);
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
+    (void)build_persistent_plan();   // optional fast path: failure only means the launch path is used
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
     fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights)\nFree VRAM: %.1f GB\n",
@@ -414,6 +417,12 @@ int Model::enqueue_token(bool greedy) {
     const int est = ntk_embed_rows(hidden_, token_embd_.ptr, d_token_, 1, H, token_embd_.dtype, s);
     mark(2, false);
     if (est != NTK_OK && est != NTK_E_DTYPE) return est;
+    if (use_persistent_now()) {   // every layer and the LM head in one launch
+        NT_TRY(ntk_persistent_launch(persistent_plan_, d_pos_, s));
+        if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
+        NT_TRY(ntk_advance_pos(d_pos_, s));
+        return NTK_OK;
+    }
     for (int i = 0; i < cfg_.n_layers; ++i) {
         const LayerWeights& L = layers_[i];
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
@@ -454,6 +463,120 @@ int Model::enqueue_token(bool greedy) {
     return NTK_OK;
 }
 
+bool Model::use_persistent_now() const {
+    return persistent_plan_ && persistent_on_ && attn_regime_ == 0 && !prof_;
+}
+
+const char* Model::decode_path() const {
+    return (persistent_plan_ && persistent_on_) ? "persistent (1 launch per token while pos < 320, fused launches beyond)" : "fused (5 launches/layer)";
+}
+
+int Model::check_persistent() {
+    if (!persistent_plan_) return NTK_OK;
+    int op = -1;
+    const int st = ntk_persistent_error(persistent_plan_, &op);
+    if (st != NTK_OK) {
+        persistent_on_ = false;
+        err_ = "persistent decode kernel: a bounded grid wait gave up at operator " + std::to_string(op) + "; falling back to launches";
+        fprintf(stderr, "%s\n", err_.c_str());
+    }
+    return st;
+}
+
+// The token's operator table for the persistent kernel: exactly the sequence enqueue_token() launches.
+int Model::build_persistent_plan() {
+    const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
+    const int qd = nh * hd, kvd = nkv * hd;
+    if (hd != 64 && hd != 128) return NTK_E_SHAPE;
+    if (const char* e = getenv("NTK_NO_PERSISTENT")) { if (atoi(e)) return NTK_E_SHAPE; }
+    const float scale = 1.0f / sqrtf((float)hd);
+    const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
+    float* q_buf = workspace_;
+    float* k_buf = q_buf + qd;
+    float* v_buf = k_buf + kvd;
+    float* attn_out = v_buf + kvd;
+    float* gate_buf = workspace_;
+    float* up_buf = gate_buf + I;
+    std::vector<ntk_pop> ops;
+    bool ok = true;
+    // n matrices sharing x: one operator per dtype group (Q4_K_M: attn_v is Q6_K / Q5_K next to Q4_K q, k); only the first
+    // waits for x, only the last signals
+    auto gemv_group = [&](const DevTensor* const* ws, float* const* ys, int n, const float* x, const DevTensor* norm, const float* resid,
+                          bool wait, bool arrive, bool plain) {
+        bool done[3] = {false, false, false};
+        std::vector<ntk_pop> grp;
+        for (int a = 0; a < n; ++a) {
+            if (done[a]) continue;
+            if (!is_quant(ws[a]->dtype)) { ok = false; return; }
+            ntk_pop o;
+            memset(&o, 0, sizeof o);
+            o.kind = NTK_POP_GEMV;
+            for (int b = a; b < n; ++b) {
+                if (done[b] || ws[b]->dtype != ws[a]->dtype) continue;
+                o.segs[o.nseg++] = {ws[b]->ptr, ys[b], (int)ws[b]->out_f, ws[b]->dtype};
+                done[b] = true;
+            }
+            o.in_features = (int)ws[a]->in_f;
+            o.eps = cfg_.norm_eps;
+            o.x = x;
+            o.norm_w = norm ? (const float*)norm->ptr : nullptr;
+            o.resid = resid;
+            o.plain_store = plain ? 1 : 0;
+            grp.push_back(o);
+        }
+        for (size_t i = 0; i < grp.size(); ++i) {
+            grp[i].wait = (wait && i == 0) ? 1 : 0;
+            grp[i].arrive = (arrive && i + 1 == grp.size()) ? 1 : 0;
+            ops.push_back(grp[i]);
+        }
+    };
+    for (int i = 0; i < cfg_.n_layers && ok; ++i) {
+        const LayerWeights& L = layers_[i];
+        {
+            const DevTensor* ws[3] = {&L.wq, &L.wk, &L.wv};
+            float* ys[3] = {q_buf, k_buf, v_buf};
+            gemv_group(ws, ys, 3, hidden_, &L.attn_norm, nullptr, i > 0, true, false);   // layer 0 reads the embedding kernel's output
+        }
+        ntk_pop a;
+        memset(&a, 0, sizeof a);
+        a.kind = NTK_POP_ATTENTION; a.wait = 1; a.arrive = 1;
+        a.out = attn_out; a.q = q_buf; a.k = k_buf; a.v = v_buf;
+        a.k_cache = k_cache_ + (size_t)i * kv_layer; a.v_cache = v_cache_ + (size_t)i * kv_layer;
+        a.inv_freq = rope_inv_freq_;
+        a.n_heads = nh; a.n_kv_heads = nkv; a.head_dim = hd; a.max_seq = cfg_.max_seq_len;
+        a.scale = scale; a.theta_base = cfg_.rope_theta; a.freq_scale = cfg_.rope_freq_scale;
+        ops.push_back(a);
+        {
+            const DevTensor* ws[1] = {&L.wo};
+            float* ys[1] = {hidden_};
+            gemv_group(ws, ys, 1, attn_out, nullptr, hidden_, true, true, false);
+        }
+        if (!(is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype)) { ok = false; break; }
+        {
+            ntk_pop o;
+            memset(&o, 0, sizeof o);
+            o.kind = NTK_POP_GEMV; o.wait = 1; o.arrive = 1;
+            o.segs[0] = {L.w_gate.ptr, gate_buf, I, L.w_gate.dtype};
+            o.segs[1] = {L.w_up.ptr, up_buf, I, L.w_up.dtype};
+            o.nseg = 2; o.in_features = H; o.silu_pair = 1; o.eps = cfg_.norm_eps;
+            o.x = hidden_; o.norm_w = (const float*)L.ffn_norm.ptr;
+            ops.push_back(o);
+        }
+        {
+            const DevTensor* ws[1] = {&L.w_down};
+            float* ys[1] = {hidden_};
+            gemv_group(ws, ys, 1, gate_buf, nullptr, hidden_, true, true, false);
+        }
+    }
+    if (ok) {
+        const DevTensor* ws[1] = {&output_};
+        float* ys[1] = {logits_};
+        gemv_group(ws, ys, 1, hidden_, &output_norm_, nullptr, true, false, true);
+    }
+    if (!ok) return NTK_E_DTYPE;
+    return ntk_persistent_plan_create(ops.data(), (int)ops.size(), &persistent_plan_);
+}
+
 void Model::pick_attention_regime() {
     attn_regime_ = (attn_scratch_ && (cfg_.head_dim == 64 || cfg_.head_dim == 128 || cfg_.head_dim == 256))
                        ? attention_regime(host_pos_) : 0;
@@ -463,7 +586,7 @@ void Model::pick_attention_regime() {
 int Model::decode_step_fused(bool greedy, bool use_graph) {
     pick_attention_regime();
     if (!use_graph) return enqueue_token(greedy);
-    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][attn_regime_];
+    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? 3 : attn_regime_];
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
         hipGraph_t g = nullptr;

@@ -67,6 +67,15 @@ public:
     // Prompts (seq_len > 1) project all tokens of a chunk with one pass over each weight matrix (ntk_gemm_quant) instead
     // of the reference's per-token GEMV loops; off = the reference's exact launch sequence.
     void set_batched_prefill(bool on) { batched_prefill_ = on; }
+    // One decode token as ONE persistent launch (csrc/decode_persistent.hip) instead of 5 launches per layer.  On by default
+    // when the model qualifies (quantised matrices, head_dim 64 / 128); short contexts only (single-pass attention regime),
+    // longer ones keep the launch path.  Turned off for good if the kernel ever reports a bounded wait that gave up.
+    void set_persistent(bool on) { persistent_on_ = on; }
+    bool persistent_available() const { return persistent_plan_ != nullptr; }
+    void* persistent_plan() const { return persistent_plan_; }
+    // which form decode_step_fused(…) emits at the current position: "persistent" / "fused launches"
+    const char* decode_path() const;
+    int check_persistent();   // after a sync: NTK_OK, or NTK_E_LAUNCH (and the path is disabled) if a wait timed out
     // One fused token launched eagerly and timed with HIP events on the compute stream.
     // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos); calls[3] = timed
     // intervals.  fine (coarse = false): an event pair around every launch.  coarse: one event per change of class, so
@@ -81,6 +90,8 @@ private:
     int upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int64_t out_f, size_t nbytes);
     void free_all();
     int enqueue_token(bool greedy);   // the fused launch sequence for one token
+    bool use_persistent_now() const;
+    int build_persistent_plan();      // the same operator sequence as a table for ntk_persistent_launch (nullptr plan if unsupported)
 
     ModelConfig cfg_;
     GgufVocab vocab_;
@@ -112,10 +123,13 @@ private:
     bool prof_coarse_ = false;
     std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs
     // one captured token per (greedy?, attention regime): regime 0 = single-pass attention, 1 = 8 KV splits, 2 = 16
-    ihipGraphExec_t* graphs_[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    // (the persistent form of regime 0 has its own slot, index 3)
+    ihipGraphExec_t* graphs_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
     int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
     int attn_regime_ = 0;            // regime enqueue_token() emits
     float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention
+    void* persistent_plan_ = nullptr;
+    bool persistent_on_ = false;   // opt-in until it beats the launch path on the bench (set_persistent / "persistent" option)
 };
 
 }  // namespace nt

@@ -73,6 +73,8 @@ def _bind():
     L.nt_engine_bytes_per_token.restype = C.c_uint64
     L.nt_engine_weight_bytes.argtypes = [vp]
     L.nt_engine_weight_bytes.restype = C.c_uint64
+    L.nt_engine_decode_path.argtypes = [vp]
+    L.nt_engine_decode_path.restype = C.c_char_p
     L.nt_synth_write_gguf.argtypes = [C.c_char_p, C.POINTER(SynthSpec), i]
     L.nt_synth_tensor.argtypes = [C.POINTER(SynthSpec), C.c_char_p, vp, C.c_size_t, i]
     L.nt_synth_tensor.restype = C.c_int64
@@ -179,6 +181,9 @@ class Engine:
 
     def bytes_per_token(self, pos: int = 0) -> int:
         return int(self.L.nt_engine_bytes_per_token(self.h, pos))
+
+    def decode_path(self) -> str:
+        return (self.L.nt_engine_decode_path(self.h) or b"").decode()
 
     def weight_bytes(self) -> int:
         return int(self.L.nt_engine_weight_bytes(self.h))

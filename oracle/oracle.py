@@ -48,10 +48,49 @@ def build_ref() -> bool:
     return True
 
 
+def host_cpu_budget():
+    """(threads, info): the physical cores this process may run on (affinity mask, SMT siblings counted once), capped by the
+    cgroup CPU quota when there is one.  The GPU boxes advertise 256 CPUs behind a 16-CPU quota: OpenMP's default of one
+    thread per advertised CPU is 16x oversubscribed there (a 12-token tiny-model check took 38 s)."""
+    aff = sorted(os.sched_getaffinity(0))
+    phys = set()
+    for c in aff:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            sib = str(c)
+        phys.add(sib)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    threads = len(phys)
+    if quota is not None:
+        threads = max(1, min(threads, int(quota)))
+    try:
+        load1 = os.getloadavg()[0]
+    except OSError:
+        load1 = None
+    info = {"nproc_online": os.cpu_count(), "affinity_cpus": len(aff), "physical_cores_in_affinity": len(phys),
+            "cgroup_cpu_quota": quota, "loadavg_1m": load1, "threads_used": threads}
+    return threads, info
+
+
 def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = C.CDLL(build())
+        _LIB.oracle_set_threads(C.c_int(host_cpu_budget()[0]))
         _LIB.oracle_h2f.restype = C.c_float
         _LIB.oracle_h2f.argtypes = [C.c_uint16]
         _LIB.oracle_f2h.restype = C.c_uint16
@@ -163,7 +202,7 @@ def pick_threads(candidates=(1, 2, 4, 8, 16, 32, 64, 128)) -> int:
     W = rng.integers(0, 255, 2048 * 4352, dtype=np.uint8)
     x = rng.standard_normal(4096).astype(np.float32)
     best, best_t = 1, float("inf")
-    limit = os.cpu_count() or 1
+    limit = host_cpu_budget()[0]
     for n in candidates:
         if n > limit:
             break

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-operator timeline of the persistent decode kernel (ntk_persistent_debug): where a token's time goes.
+    python tools/persistent_trace.py [--model 8b] [--mix Q8_0]"""
+import argparse, ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from ntransformer_amd import engine as E, _lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="8b"); ap.add_argument("--mix", default="Q8_0"); ap.add_argument("--layers", type=int, default=None)
+a = ap.parse_args()
+L = _lib.lib()
+L.nt_engine_persistent_plan.restype = C.c_void_p; L.nt_engine_persistent_plan.argtypes = [C.c_void_p]
+L.ntk_persistent_debug.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+eng = E.Engine()
+eng.set_option("graph", 0)                      # eager: the debug pointer is a launch argument
+eng.load_synthetic(E.synth_spec(a.model, a.mix, layers=a.layers), 4096)
+plan = L.nt_engine_persistent_plan(eng.h)
+assert plan, "model does not qualify for the persistent path"
+nops = L.ntk_persistent_debug(plan, 1, None, 0)
+toks = eng.decode_greedy_steps(1234, 20, 4)
+buf = np.zeros((nops, 2, 8), np.uint64)
+L.ntk_persistent_debug(plan, 1, buf.ctypes.data_as(C.c_void_p), nops)
+t = buf.astype(np.int64)
+t0 = t[0, :, 0].min()
+us = (t - t0) / 100.0                            # 100 MHz ticks -> us
+print("ops %d, token span wg0 %.1f us, wg%d %.1f us" % (nops, us[-1, 0, 3] - us[0, 0, 0], 128, us[-1, 1, 3] - us[0, 1, 0]))
+per = 5 if a.mix == "Q8_0" else None
+print("%4s | %8s %8s %8s %8s | %8s %8s %8s %8s" % ("op", "wait", "body", "arrive", "total", "wait", "body", "arrive", "total"))
+tot = np.zeros((2, 3))
+for k in range(nops):
+    row = []
+    for w in range(2):
+        wait, body, arr = us[k, w, 1] - us[k, w, 0], us[k, w, 2] - us[k, w, 1], us[k, w, 3] - us[k, w, 2]
+        tot[w] += (wait, body, arr)
+        row += [wait, body, arr, wait + body + arr]
+    if k < 12 or k >= nops - 3:
+        print("%4d | %8.2f %8.2f %8.2f %8.2f | %8.2f %8.2f %8.2f %8.2f" % tuple([k] + row))
+print("sum  | wait %.1f body %.1f arrive %.1f | wait %.1f body %.1f arrive %.1f (us)" % (tuple(tot[0]) + tuple(tot[1])))
+if per:
+    body = (us[:, :, 2] - us[:, :, 1])[: (nops - 1) // per * per].reshape(-1, per, 2).mean(axis=0)
+    wait = (us[:, :, 1] - us[:, :, 0])[: (nops - 1) // per * per].reshape(-1, per, 2).mean(axis=0)
+    arr = (us[:, :, 3] - us[:, :, 2])[: (nops - 1) // per * per].reshape(-1, per, 2).mean(axis=0)
+    for i, name in enumerate(["qkv", "attn", "wo", "gate|up", "down"]):
+        print("%-8s wait %6.2f body %6.2f arrive %6.2f   | wait %6.2f body %6.2f arrive %6.2f" % (name, wait[i, 0], body[i, 0], arr[i, 0], wait[i, 1], body[i, 1], arr[i, 1]))
+# inside a GEMV operator: [4] entered (queue state loaded, residual requested), [5] x loaded (+ normalised), [6] image passes
+# done (activations in registers), [7] rows done
+if per:
+    n = (nops - 1) // per * per
+    seg = {"entry": us[:n, :, 4] - us[:n, :, 1], "x+norm": us[:n, :, 5] - us[:n, :, 4], "image": us[:n, :, 6] - us[:n, :, 5],
+           "rows": us[:n, :, 7] - us[:n, :, 6], "exit": us[:n, :, 2] - us[:n, :, 7]}
+    for i, name in enumerate(["qkv", "attn", "wo", "gate|up", "down"]):
+        if name == "attn":
+            continue
+        print("%-8s " % name + "  ".join("%s %5.2f/%5.2f" % (k_, v[:n].reshape(-1, per, 2).mean(axis=0)[i, 0], v[:n].reshape(-1, per, 2).mean(axis=0)[i, 1]) for k_, v in seg.items()))
+eng.close()
