@@ -127,8 +127,10 @@ __device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* gsrc) {
 // instructions issued AFTER the row that must have landed.  Anything else issued after it (a y store, a residual load)
 // only makes the wait stricter than needed, never weaker.
 __device__ __forceinline__ void wait_vm(int n) {   // wave-uniform
-    if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -139,10 +141,8 @@ __device__ __forceinline__ void wait_vm(int n) {   // wave-uniform
 }
 
 // ---- grid barrier: arrive / wait split, XCD-hierarchical counters, bounded spin ----------------------------------
-// newer: DMA instructions this wave issued after its last y store (they may stay in flight)
-__device__ __forceinline__ void grid_arrive(unsigned* sync, unsigned epoch, int newer) {
-    wait_vm(newer);        // every wave: its write-through stores have been acknowledged
-    __syncthreads();
+__device__ __forceinline__ void grid_arrive(unsigned* sync, unsigned epoch) {
+    __syncthreads();       // (every wave has waited for the acknowledgement of its write-through stores)
     if (threadIdx.x == 0) {
         const unsigned grp = blockIdx.x & 7u, gsize = (gridDim.x - grp + 7u) / 8u;
         const unsigned old = __hip_atomic_fetch_add(&sync[grp * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -295,27 +295,44 @@ __device__ __attribute__((noinline)) void p_attention(const POp* op_arg, float* 
 
 // ------------------------------------------------------------------------------------------------------------------
 // The wave's weight-row queue: two LDS slots filled by DMA, running ahead of the decode cursor ACROSS operators.
-// Everything in it is wave-uniform (scalar registers).  Between operators it is parked in a per-wave record (QState).
+// Everything in it is wave-uniform (scalar registers).
 // ------------------------------------------------------------------------------------------------------------------
-struct QState {
-    int f_op, f_q, f_n, f_seg, f_row, f_rows, f_step, f_silu;
-    unsigned f_slice_byte0, f_slice_bytes;
-    int q_cnt, q_rd, q_chunks_new, q_shift0, q_shift1, q_since;
+// position in the wave's row-slice sequence: (operator, item) with the incremental (segment, row) of that item
+struct Cursor {
+    int op, q, n;                 // operator, item index, items of this wave in that operator (n == 0: past the end)
+    int seg, row, rows, step, silu;
+    unsigned slice_byte0, slice_bytes;
+
+    __device__ __forceinline__ void reset() { op = -1; q = n = seg = row = rows = step = silu = 0; slice_byte0 = slice_bytes = 0; }
+    __device__ __forceinline__ void next_op(COp* ops, int nops, int wave);
+    __device__ __forceinline__ void advance(COp* ops, int nops, int wave) {
+        if (++q < n) {
+            COp& o = ops[op];
+            if (silu) {
+                if (seg == 0) seg = 1; else { seg = 0; row += step; }
+            } else {
+                row += step;
+                while (seg + 1 < o.nseg && row >= rows) { row -= rows; ++seg; rows = o.seg[seg].rows; }
+            }
+        } else {
+            next_op(ops, nops, wave);
+        }
+    }
 };
 
 struct Queue {
     COp* ops;
     int nops, wave;
     uint32_t ring_lds;            // LDS byte address of the wave's two slots
-    // fetch cursor = the next row slice to request
-    int f_op, f_q, f_n;           // operator, item index, items of this wave in that operator
-    int f_seg, f_row, f_rows, f_step, f_silu;
-    unsigned f_slice_byte0, f_slice_bytes;
+    Cursor f;                     // fetch cursor = the next row slice to request by DMA
     int q_cnt;                    // rows in the queue (0..2)
     int q_rd;                     // slot of the oldest row
-    int q_chunks_new;             // DMA instructions of the NEWEST queued row
     int q_shift0, q_shift1;       // byte offset of the slice inside slot 0 / 1
-    int q_since;                  // DMA instructions issued since mark() (= newer than the wave's last y store)
+    // Vector-memory operations of a wave complete in order, so "row r has landed" == "at most (operations issued after
+    // r's last DMA chunk) are outstanding".  vm_count counts the operations this wave certainly issued (DMA chunks, y stores,
+    // residual loads); vm_mark0/1 = its value right after the DMA of slot 0 / 1.  Operations that are NOT counted (debug
+    // stamps, lane-conditional loads) only make a wait stricter, never weaker.
+    int vm_count, vm_mark0, vm_mark1, vm_store;   // vm_store: value after the wave's last y store
 
     __device__ __forceinline__ static void wave_geom(COp& op, int wave, int& s, int& group, int& ngroups, int& n_my) {
         const int rw = PW / op.ns;
@@ -326,74 +343,58 @@ struct Queue {
         n_my = (op.total_rows > group) ? ((op.total_rows - 1 - group) / ngroups + 1) * mats : 0;
     }
     __device__ __forceinline__ void reset() {
-        f_op = -1; f_q = f_n = 0; f_seg = f_row = f_rows = f_step = f_silu = 0; f_slice_byte0 = f_slice_bytes = 0;
-        q_cnt = q_rd = q_chunks_new = q_shift0 = q_shift1 = 0;
-        q_since = 0;
+        f.reset();
+        q_cnt = q_rd = q_shift0 = q_shift1 = 0;
+        vm_count = vm_mark0 = vm_mark1 = vm_store = 0;
     }
-#define NTK_RFL(x) __builtin_amdgcn_readfirstlane(x)
-    __device__ __forceinline__ void load(const QState& st) {   // the record is per-lane memory: make the copies scalar again
-        f_op = NTK_RFL(st.f_op); f_q = NTK_RFL(st.f_q); f_n = NTK_RFL(st.f_n); f_seg = NTK_RFL(st.f_seg);
-        f_row = NTK_RFL(st.f_row); f_rows = NTK_RFL(st.f_rows); f_step = NTK_RFL(st.f_step); f_silu = NTK_RFL(st.f_silu);
-        f_slice_byte0 = NTK_RFL(st.f_slice_byte0); f_slice_bytes = NTK_RFL(st.f_slice_bytes);
-        q_cnt = NTK_RFL(st.q_cnt); q_rd = NTK_RFL(st.q_rd); q_chunks_new = NTK_RFL(st.q_chunks_new);
-        q_shift0 = NTK_RFL(st.q_shift0); q_shift1 = NTK_RFL(st.q_shift1);
-        q_since = 0;
-    }
-#undef NTK_RFL
-    __device__ __forceinline__ void save(QState& st) const {
-        if ((threadIdx.x & 63) != 0) return;   // one lane writes the wave's record
-        st.f_op = f_op; st.f_q = f_q; st.f_n = f_n; st.f_seg = f_seg; st.f_row = f_row; st.f_rows = f_rows; st.f_step = f_step;
-        st.f_silu = f_silu; st.f_slice_byte0 = f_slice_byte0; st.f_slice_bytes = f_slice_bytes;
-        st.q_cnt = q_cnt; st.q_rd = q_rd; st.q_chunks_new = q_chunks_new; st.q_shift0 = q_shift0; st.q_shift1 = q_shift1;
-        st.q_since = q_since;
-    }
-    __device__ __forceinline__ void fetch_next_op() {   // move the fetch cursor to the next GEMV operator in which this wave owns rows
-        f_n = 0;
-        for (++f_op; f_op < nops; ++f_op) {
-            COp& op = ops[f_op];
-            if (op.kind != PK_GEMV) continue;
-            int s, group, ngroups, n_my;
-            wave_geom(op, wave, s, group, ngroups, n_my);
-            if (n_my <= 0) continue;
-            f_n = n_my; f_q = 0; f_step = ngroups; f_silu = (op.flags & PF_SILU) ? 1 : 0;
-            const int my_len = min(op.slice_cols, op.in - s * op.slice_cols);
-            f_slice_byte0 = (unsigned)((size_t)s * op.slice_cols / fmt_bw(op.dtype) * fmt_bb(op.dtype));
-            f_slice_bytes = (unsigned)(my_len / fmt_bw(op.dtype) * fmt_bb(op.dtype));
-            f_seg = 0; f_row = group; f_rows = f_silu ? 0x7fffffff : op.seg[0].rows;
-            while (!f_silu && f_seg + 1 < op.nseg && f_row >= f_rows) { f_row -= f_rows; ++f_seg; f_rows = op.seg[f_seg].rows; }
-            return;
-        }
-    }
+    __device__ __forceinline__ void count_vm(int n) { vm_count += n; }
+    __device__ __forceinline__ void count_store() { vm_count += 1; vm_store = vm_count; }
+    __device__ __forceinline__ void wait_oldest() const { wait_vm(vm_count - (q_rd ? vm_mark1 : vm_mark0)); }   // slot q_rd has landed
+    __device__ __forceinline__ void wait_stores() const { wait_vm(vm_count - vm_store); }                       // every y store is acknowledged
+    __device__ __forceinline__ void drained() { vm_mark0 = vm_mark1 = vm_store = vm_count; }                     // after a vmcnt(0)
     __device__ __forceinline__ void issue(int lane) {   // request the row slice under the fetch cursor into the free slot
-        COp& op = ops[f_op];
-        const unsigned rel = (unsigned)f_row * op.row_bytes + f_slice_byte0;
+        COp& op = ops[f.op];
+        const unsigned rel = (unsigned)f.row * op.row_bytes + f.slice_byte0;
         const unsigned shift = rel & 15u;
-        const unsigned nbytes = shift + f_slice_bytes;
+        const unsigned nbytes = shift + f.slice_bytes;
         const int slot = (q_rd + q_cnt) & 1;
         if (slot) q_shift1 = (int)shift; else q_shift0 = (int)shift;
-        const uint8_t* a = op.seg[f_seg].W + (rel & ~15u) + 16u * (unsigned)lane;
+        const uint8_t* a = op.seg[f.seg].W + (rel & ~15u) + 16u * (unsigned)lane;
         const uint32_t dst = ring_lds + (uint32_t)slot * P_SLOT;   // wave-uniform
         const int chunks = (int)((nbytes + 1023u) >> 10);
         for (int j = 0; j < chunks; ++j) {
             if (16u * (unsigned)lane + 1024u * (unsigned)j < nbytes)
                 dma16(__builtin_amdgcn_readfirstlane(dst + 1024u * (uint32_t)j), a + 1024u * (unsigned)j);
         }
-        q_chunks_new = chunks;
-        q_since += chunks;
+        vm_count += chunks;
+        if (slot) vm_mark1 = vm_count; else vm_mark0 = vm_count;
         ++q_cnt;
-        if (++f_q < f_n) {
-            if (f_silu) {
-                if (f_seg == 0) f_seg = 1; else { f_seg = 0; f_row += f_step; }
-            } else {
-                f_row += f_step;
-                while (f_seg + 1 < op.nseg && f_row >= f_rows) { f_row -= f_rows; ++f_seg; f_rows = op.seg[f_seg].rows; }
-            }
-        } else {
-            fetch_next_op();
-        }
+        f.advance(ops, nops, wave);
     }
-    __device__ __forceinline__ void fill(int lane) { while (q_cnt < P_RING && f_n > 0) issue(lane); }
+    __device__ __forceinline__ void fill(int lane) { while (q_cnt < P_RING && f.n > 0) issue(lane); }
+    __device__ __forceinline__ void start(int lane) {   // kernel entry: the wave's first two row slices are requested
+        f.next_op(ops, nops, wave);
+        fill(lane);
+    }
 };
+
+__device__ __forceinline__ void Cursor::next_op(COp* ops, int nops, int wave) {   // next GEMV operator in which this wave owns rows
+    n = 0;
+    for (++op; op < nops; ++op) {
+        COp& o = ops[op];
+        if (o.kind != PK_GEMV) continue;
+        int s, group, ngroups, n_my;
+        Queue::wave_geom(o, wave, s, group, ngroups, n_my);
+        if (n_my <= 0) continue;
+        n = n_my; q = 0; step = ngroups; silu = (o.flags & PF_SILU) ? 1 : 0;
+        const int my_len = min(o.slice_cols, o.in - s * o.slice_cols);
+        slice_byte0 = (unsigned)((size_t)s * o.slice_cols / fmt_bw(o.dtype) * fmt_bb(o.dtype));
+        slice_bytes = (unsigned)(my_len / fmt_bw(o.dtype) * fmt_bb(o.dtype));
+        seg = 0; row = group; rows = silu ? 0x7fffffff : o.seg[0].rows;
+        while (!silu && seg + 1 < o.nseg && row >= rows) { row -= rows; ++seg; rows = o.seg[seg].rows; }
+        return;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // One GEMV operator of the token for one weight format: activation prologue + this wave's rows.  Inlined into the kernel
@@ -446,7 +447,7 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
     // residual of the wave's first row (ns == 1) / first batch (ns > 1): requested now, hidden by the prologue
     float res_next = 0.0f, res_pf = 0.0f;
     const bool has_res = op.resid != nullptr;
-    if (has_res && ns == 1 && n_my > 0 && cu_seg == 0) res_next = ld_agent(op.resid + cu_row);
+    if (has_res && ns == 1 && n_my > 0 && cu_seg == 0) { res_next = ld_agent(op.resid + cu_row); Q.count_vm(1); }
     auto prefetch_resid = [&](int b) {
         if (!has_res || s != 0 || lane >= RB || b * RB + lane >= n_my) return;
         int seg, row;
@@ -485,6 +486,7 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
 #pragma unroll
             for (int i = 0; i < 2; ++i) wv[i] = *reinterpret_cast<const u32x4*>(op.norm_w + min(min(i, ns - 1) * op.slice_cols + cc, op.in - 4));
             ld16_agent_x2(xv[0], xv[1], xaddr(0), xaddr(1));
+            Q.drained();
             float ssq = 0.0f;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -518,6 +520,7 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
                 if (ns - sp >= 3) ld16_agent_x4(xv[0], xv[1], xv[2], xv[3], xaddr(sp), xaddr(sp + 1), xaddr(sp + 2), xaddr(sp + 3));
                 else if (ns - sp == 2) ld16_agent_x2(xv[0], xv[1], xaddr(sp), xaddr(sp + 1));
                 else ld16_agent_x1(xv[0], xaddr(sp));
+                Q.drained();
             }
             const u32x4 v = i == 0 ? xv[0] : i == 1 ? xv[1] : i == 2 ? xv[2] : xv[3];
             const int len = min(op.slice_cols, op.in - sp * op.slice_cols);
@@ -551,6 +554,7 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
     auto store_y = [&](float* p, float v) { if (plain) *p = v; else st_agent(p, v); };
     auto combine = [&](int b, int cnt) {   // ns > 1: wave s == 0 of each row group sums the slice partials of batch b
         if (s != 0) return;
+        Q.count_store();   // cnt >= 1: lane 0 stores
         const float* pg = part + (size_t)(b & 1) * PW * RB + (size_t)wave * RB;   // wave = g * ns (s == 0)
         float t = 0.0f;
         if (lane < cnt)
@@ -576,9 +580,9 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
         const float res = res_next;
         if (q + 1 < n_my) {
             cursor_advance();
-            if (has_res && ns == 1 && cu_seg == 0) res_next = ld_agent(op.resid + cu_row);
+            if (has_res && ns == 1 && cu_seg == 0) { res_next = ld_agent(op.resid + cu_row); Q.count_vm(1); }
         }
-        wait_vm(Q.q_cnt > 1 ? Q.q_chunks_new : 0);       // the oldest queued row has landed in LDS
+        Q.wait_oldest();                   // the oldest queued row has landed in LDS
         const uint8_t* st = ring + Q.q_rd * P_SLOT;
         const float acc = Dot<DT, A16>::run(st, A16 ? 0 : (Q.q_rd ? Q.q_shift1 : Q.q_shift0), lane, ncols, x2, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the slot precede the DMA that refills it
@@ -600,6 +604,7 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
                     store_y(op.seg[seg].y + row, v);
                 }
             }
+            if (!silu || (q & 1)) Q.count_store();   // (lane 63 exists in every wave: the store instruction was issued)
         } else {
             const int b = q / RB, i = q % RB;
             if (lane == 63) part[(size_t)(b & 1) * PW * RB + (size_t)wave * RB + i] = tot;
@@ -620,7 +625,6 @@ __device__ __forceinline__ void p_gemv_op(COp* ops, int nops, int k, Queue& Q, i
     }
     // After the wave's LAST y store: refill the queue with rows of the next operators.  Everything requested from here on is
     // newer than the stores, so the arrival only has to wait until at most `q_since` vector-memory operations are outstanding.
-    Q.q_since = 0;
     Q.fill(lane);
     stamp(7);
 }
@@ -643,13 +647,15 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(const POp* __rest
     Q.ops = ops; Q.nops = nops; Q.wave = wave;
     Q.ring_lds = (uint32_t)(uintptr_t)(smem + (size_t)wave * (P_RING * P_SLOT));   // generic -> LDS address: low 32 bits
     Q.reset();
-    Q.fetch_next_op();
-    Q.fill(tid0 & 63);   // the wave's first two row slices are on their way
+    Q.start(tid0 & 63);   // the wave's first two row slices are on their way
     const int pos = *d_pos;
     unsigned epoch = 0;
     const int dbg_w = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
     auto stamp = [&](int k, int i) {
-        if (dbg && dbg_w >= 0 && tid0 == 0) dbg[((size_t)k * 2 + dbg_w) * 8 + i] = wall_clock64();
+        if (!dbg || tid0 != 0) return;
+        const unsigned long long t = wall_clock64();
+        if (dbg_w >= 0) dbg[((size_t)k * 2 + dbg_w) * 32 + i] = t;
+        if (i == 1 || i == 2) dbg[(size_t)nops * 64 + ((size_t)k * gridDim.x + blockIdx.x) * 2 + (i - 1)] = t;   // every workgroup: body begin / end
     };
     for (int k = 0; k < nops; ++k) {
         COp& op = ops[k];
@@ -660,25 +666,26 @@ __global__ __launch_bounds__(PT) void decode_persistent_kernel(const POp* __rest
         stamp(k, 0);
         if (op.flags & PF_WAIT) grid_wait(sync, epoch, k);
         stamp(k, 1);
-        int since = 0;
         if (op.kind == PK_ATTN) {
             if ((int)blockIdx.x < op.n_heads) {   // the other workgroups go straight to the arrival
                 if (op.hd == 128) p_attention<16>((const POp*)&op, ximg, pos, tid);
                 else p_attention<8>((const POp*)&op, ximg, pos, tid);
             }
         } else {
-            unsigned long long* rec = (dbg && dbg_w >= 0) ? dbg + ((size_t)k * 2 + dbg_w) * 8 : nullptr;
+            unsigned long long* rec = (dbg && dbg_w >= 0) ? dbg + ((size_t)k * 2 + dbg_w) * 32 : nullptr;
             const int dt = op.dtype;   // wave-uniform
             if ((MASK & fmt_bit(NTK_DT_Q8_0)) && (MASK == fmt_bit(NTK_DT_Q8_0) || dt == NTK_DT_Q8_0)) p_gemv_op<NTK_DT_Q8_0>(ops, nops, k, Q, tid, rec);
             else if ((MASK & fmt_bit(NTK_DT_Q4_0)) && (MASK == fmt_bit(NTK_DT_Q4_0) || dt == NTK_DT_Q4_0)) p_gemv_op<NTK_DT_Q4_0>(ops, nops, k, Q, tid, rec);
             else if ((MASK & fmt_bit(NTK_DT_Q4_K)) && (MASK == fmt_bit(NTK_DT_Q4_K) || dt == NTK_DT_Q4_K)) p_gemv_op<NTK_DT_Q4_K>(ops, nops, k, Q, tid, rec);
             else if ((MASK & fmt_bit(NTK_DT_Q5_K)) && (MASK == fmt_bit(NTK_DT_Q5_K) || dt == NTK_DT_Q5_K)) p_gemv_op<NTK_DT_Q5_K>(ops, nops, k, Q, tid, rec);
             else if ((MASK & fmt_bit(NTK_DT_Q6_K)) && (MASK == fmt_bit(NTK_DT_Q6_K) || dt == NTK_DT_Q6_K)) p_gemv_op<NTK_DT_Q6_K>(ops, nops, k, Q, tid, rec);
-            since = Q.q_since;
         }
         stamp(k, 2);
         // a GEMV operator's final refill is issued after its last y store: the arrival waits for the stores, not for those rows
-        if (op.flags & PF_ARRIVE) grid_arrive(sync, ++epoch, since);
+        if (op.flags & PF_ARRIVE) {
+            if (op.kind == PK_GEMV) Q.wait_stores(); else { wait_vm(0); Q.drained(); }
+            grid_arrive(sync, ++epoch);
+        }
         stamp(k, 3);
     }
 }
@@ -867,12 +874,14 @@ int ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int ca
     PersistentPlan* p = static_cast<PersistentPlan*>(plan);
     if (!p) return NTK_E_NULL;
     if (enable && !p->d_dbg) {
-        if (hipMalloc(reinterpret_cast<void**>(&p->d_dbg), sizeof(unsigned long long) * 16 * (size_t)p->nops) != hipSuccess) return NTK_E_NOMEM;
-        (void)hipMemset(p->d_dbg, 0, sizeof(unsigned long long) * 16 * (size_t)p->nops);
+        const size_t n = sizeof(unsigned long long) * (64 + 2 * (size_t)p->grid) * (size_t)p->nops;
+        if (hipMalloc(reinterpret_cast<void**>(&p->d_dbg), n) != hipSuccess) return NTK_E_NOMEM;
+        (void)hipMemset(p->d_dbg, 0, n);
     }
     if (out && p->d_dbg) {
-        const int n = cap_ops < p->nops ? cap_ops : p->nops;
-        if (hipMemcpy(out, p->d_dbg, sizeof(unsigned long long) * 16 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
+        // cap_ops >= nops: the whole record (two-workgroup detail [nops][2][8], then every workgroup's body begin/end [nops][grid][2])
+        const size_t n = cap_ops >= p->nops ? (64 + 2 * (size_t)p->grid) * (size_t)p->nops : 64 * (size_t)cap_ops;
+        if (hipMemcpy(out, p->d_dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
     }
     return p->nops;
 }

@@ -14,13 +14,18 @@ L.nt_engine_persistent_plan.restype = C.c_void_p; L.nt_engine_persistent_plan.ar
 L.ntk_persistent_debug.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
 eng = E.Engine()
 eng.set_option("graph", 0)                      # eager: the debug pointer is a launch argument
+eng.set_option("persistent", 1)
 eng.load_synthetic(E.synth_spec(a.model, a.mix, layers=a.layers), 4096)
 plan = L.nt_engine_persistent_plan(eng.h)
 assert plan, "model does not qualify for the persistent path"
 nops = L.ntk_persistent_debug(plan, 1, None, 0)
 toks = eng.decode_greedy_steps(1234, 20, 4)
-buf = np.zeros((nops, 2, 8), np.uint64)
-L.ntk_persistent_debug(plan, 1, buf.ctypes.data_as(C.c_void_p), nops)
+L.ntk_persistent_grid.argtypes = [C.c_void_p]
+grid = L.ntk_persistent_grid(plan)
+raw = np.zeros(nops * (64 + 2 * grid), np.uint64)
+L.ntk_persistent_debug(plan, 1, raw.ctypes.data_as(C.c_void_p), nops)
+buf = raw[: nops * 64].reshape(nops, 2, 32)
+allwg = raw[nops * 64:].reshape(nops, grid, 2).astype(np.int64)
 t = buf.astype(np.int64)
 t0 = t[0, :, 0].min()
 us = (t - t0) / 100.0                            # 100 MHz ticks -> us
@@ -53,4 +58,16 @@ if per:
         if name == "attn":
             continue
         print("%-8s " % name + "  ".join("%s %5.2f/%5.2f" % (k_, v[:n].reshape(-1, per, 2).mean(axis=0)[i, 0], v[:n].reshape(-1, per, 2).mean(axis=0)[i, 1]) for k_, v in seg.items()))
+# every workgroup: body duration per operator kind -- who is slow?
+if per:
+    n = (nops - 1) // per * per
+    dur = ((allwg[:n, :, 1] - allwg[:n, :, 0]) / 100.0).reshape(-1, per, grid)        # [layer][kind][wg] us
+    beg = ((allwg[:n, :, 0] - allwg[:n, :, 0].min(axis=1, keepdims=True)) / 100.0).reshape(-1, per, grid)
+    for i, name in enumerate(["qkv", "attn", "wo", "gate|up", "down"]):
+        d = dur[:, i, :].mean(axis=0)
+        order = np.argsort(d)
+        print("%-8s body over workgroups: min %.2f  p10 %.2f  median %.2f  p90 %.2f  max %.2f | start skew p90 %.2f max %.2f | slowest wgs %s | per-XCD mean %s"
+              % (name, d.min(), np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max(),
+                 np.percentile(beg[:, i, :].mean(axis=0), 90), beg[:, i, :].mean(axis=0).max(), list(order[-6:]),
+                 " ".join("%.1f" % d[x::8].mean() for x in range(8))))
 eng.close()
