@@ -150,7 +150,7 @@ typedef struct ntk_gemv_seg {
     const void* W;      /* raw GGUF blocks [rows][in]              */
     float*      y;      /* output [rows]                            */
     int         rows;
-    int         dtype;  /* all segments of one call share one dtype */
+    int         dtype;  /* one format per call, or two for the plain (no resid / SiLU) form: Q4_K with Q6_K or Q5_K */
 } ntk_gemv_seg;
 
 /* y_s = W_s . f(x) for up to 3 row segments sharing x (fused Q|K|V or gate|up):

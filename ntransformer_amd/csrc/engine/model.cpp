@@ -379,6 +379,19 @@ int Model::enqueue_token(bool greedy) {
                        const float* resid) -> int {
         const float* nw = norm ? (const float*)norm->ptr : nullptr;
         bool done[3] = {false, false, false};
+        if (n > 1 && !resid) {   // matrices in two K-quant formats (Q4_K_M's attn_v): still one launch when the library has the pair
+            bool all_quant = true, mixed = false;
+            for (int a = 0; a < n; ++a) { all_quant = all_quant && is_quant(ws[a]->dtype); mixed = mixed || ws[a]->dtype != ws[0]->dtype; }
+            if (all_quant && mixed) {
+                ntk_gemv_seg segs[3];
+                for (int a = 0; a < n; ++a) segs[a] = {ws[a]->ptr, ys[a], (int)ws[a]->out_f, ws[a]->dtype};
+                mark(0, true);
+                const int st = ntk_gemv_fused(segs, n, x, (int)ws[0]->in_f, nw, cfg_.norm_eps, nullptr, 0, s);
+                mark(0, false);
+                if (st == NTK_OK) return NTK_OK;
+                if (st != NTK_E_DTYPE && st != NTK_E_ALIGN) return st;   // those two: formats / alignment only the per-format launches take
+            }
+        }
         for (int a = 0; a < n; ++a) {
             if (done[a]) continue;
             const DevTensor& w = *ws[a];

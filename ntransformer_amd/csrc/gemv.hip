@@ -33,7 +33,7 @@ namespace ntk {
 //   [A, ..)  partial sums [2][rw][ns][RB] + 16 floats reduction scratch
 // ------------------------------------------------------------------------------------------------
 template <int DT, bool NORM, bool XFAST, bool A16>
-__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
+__device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int bid, const int nblk) {   // workgroup bid of nblk
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
     constexpr int STAGE = NL * 1024 + 64;
@@ -58,8 +58,8 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     const int ncols = min(64, max(0, my_len - 64 * lane));
     const unsigned slice_byte0 = (unsigned)((size_t)s * p.slice_cols / F::BW * F::BB);
     const unsigned slice_bytes = (unsigned)(my_len / F::BW * F::BB);
-    const int group = blockIdx.x * p.rw + g;
-    const int ngroups = gridDim.x * p.rw;
+    const int group = bid * p.rw + g;
+    const int ngroups = nblk * p.rw;
     const int mats = p.silu_pair ? 2 : 1;
     const int n_my = (p.total_rows > group) ? ((p.total_rows - 1 - group) / ngroups + 1) * mats : 0;
 
@@ -338,6 +338,20 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     }
 }
 
+template <int DT, bool NORM, bool XFAST, bool A16>
+__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
+    gemv_quant_body<DT, NORM, XFAST, A16>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two weight formats in ONE launch (llama.cpp's Q4_K_M stores attn_v as Q6_K / Q5_K next to Q4_K attn_q / attn_k): the first
+// `split` workgroups run format A on its segments, the rest format B on its own -- the two halves share nothing but x.  One
+// launch instead of two for the fused norm + Q|K|V projection of those layers (16 of 32 at 8B, all 80 at 70B).
+template <int DTA, int DTB, bool NORM>
+__global__ __launch_bounds__(512, 4) void gemv_quant_pair_kernel(const GemvParams pa, const GemvParams pb, const int split) {
+    if ((int)blockIdx.x < split) gemv_quant_body<DTA, NORM, true, A16_OK<DTA>>(pa, (int)blockIdx.x, split);
+    else gemv_quant_body<DTB, NORM, true, A16_OK<DTB>>(pb, (int)blockIdx.x - split, (int)gridDim.x - split);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Dense F16 / F32 rows (reference gemm.cu:476-671): one wave per row, 16-byte lane loads when the row
 // is aligned, scalar otherwise (the reference's own F32 test uses in = 3).  Not on any target config.
@@ -389,12 +403,21 @@ static bool is_quant(int dt) {
     return dt == NTK_DT_Q8_0 || dt == NTK_DT_Q4_0 || dt == NTK_DT_Q4_K || dt == NTK_DT_Q5_K || dt == NTK_DT_Q6_K;
 }
 
+struct GemvLaunch {
+    GemvParams p;
+    int grid, nwaves;
+    size_t lds;
+    bool xfast, a16;
+};
+
+// argument checks + geometry of one single-format launch (max_wg workgroups at most)
 template <int DT>
-static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w, float eps,
-                        const float* resid, int silu_pair, hipStream_t st) {
+static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w, float eps,
+                         const float* resid, int silu_pair, int max_wg, GemvLaunch& L) {
     using F = Fmt<DT>;
     if (in <= 0 || in % F::BW != 0) return NTK_E_SHAPE;
-    GemvParams p{};
+    GemvParams& p = L.p;
+    p = GemvParams{};
     long total = 0;
     const size_t row_bytes = (size_t)in / F::BW * F::BB;
     for (int i = 0; i < nseg; ++i) {
@@ -413,7 +436,6 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
         if (nseg != 2 || segs[0].rows != segs[1].rows || resid) return NTK_E_SHAPE;
         total = segs[0].rows;
     }
-    if (total == 0) return NTK_OK;
     p.nseg = nseg;
     p.total_rows = (int)total;
     p.x = x;
@@ -425,7 +447,7 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     // waves per workgroup = ns * rw ~ 8: one x prologue feeds eight row streams
     static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
     p.rw = std::max(1, env_waves / p.ns);   // (6-wave workgroups for the 3-waves/SIMD formats measured 30 % slower)
-    const int nwaves = p.ns * p.rw;
+    L.nwaves = p.ns * p.rw;
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? 1 : 0;
     p.norm_w = norm_w;
@@ -435,28 +457,44 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     p.row_bytes = (unsigned)row_bytes;
     const int mats = silu_pair ? 2 : 1;
     // enough workgroups to fill 256 CUs twice over, but never more row groups than rows
-    static const int max_wg = [] { const char* e = getenv("NTK_GEMV_MAX_WG"); return e ? std::max(1, atoi(e)) : 512; }();
     int grid = (int)std::min<long>((total + p.rw - 1) / p.rw, max_wg);
     grid = std::max(grid, 1);
+    L.grid = grid;
     const long ngroups = (long)grid * p.rw;
     const long rows_per_group = (total + ngroups - 1) / ngroups;
     p.nbatch = (int)((rows_per_group * mats + RB - 1) / RB);
     constexpr int STAGE = F::NL * 1024 + 64;
-    const size_t regionA = (size_t)std::max(nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
-    const size_t lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
+    const size_t regionA = (size_t)std::max(L.nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
+    L.lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
     // fast prologue: aligned x / norm weights, whole float4s, norm weights fit the 4 register slots per thread
-    const bool xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(kAblate & 1) && (!norm_w || in <= 4 * 4 * 64 * nwaves);
+    L.xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(kAblate & 1) && (!norm_w || in <= 4 * 4 * 64 * L.nwaves);
     // A16 (K-quants whose blocks are multiples of 16 bytes): every row slice starts 16-byte aligned -> b128 LDS reads,
     // no v_alignbyte.  True for every GGUF tensor (data offsets are 32-byte aligned); the general form covers the rest.
     bool a16 = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
     for (int i = 0; i < nseg; ++i) a16 = a16 && p.seg[i].delta == 0;
+    L.a16 = a16;
+    return NTK_OK;
+}
+
+static int max_workgroups() {
+    static const int max_wg = [] { const char* e = getenv("NTK_GEMV_MAX_WG"); return e ? std::max(1, atoi(e)) : 512; }();
+    return max_wg;
+}
+
+template <int DT>
+static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w, float eps,
+                        const float* resid, int silu_pair, hipStream_t st) {
+    GemvLaunch L;
+    const int rc = prepare_quant<DT>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, max_workgroups(), L);
+    if (rc != NTK_OK) return rc;
+    if (L.p.total_rows == 0) return NTK_OK;
     using KernelFn = void (*)(const GemvParams);
     static const KernelFn table[2][2][2] = {
         {{gemv_quant_kernel<DT, false, false, false>, gemv_quant_kernel<DT, false, false, A16_OK<DT>>},
          {gemv_quant_kernel<DT, false, true, false>, gemv_quant_kernel<DT, false, true, A16_OK<DT>>}},
         {{gemv_quant_kernel<DT, true, false, false>, gemv_quant_kernel<DT, true, false, A16_OK<DT>>},
          {gemv_quant_kernel<DT, true, true, false>, gemv_quant_kernel<DT, true, true, A16_OK<DT>>}}};
-    if (lds > 64 * 1024) {   // 28672-wide rows: the activation image alone is 119 KiB
+    if (L.lds > 64 * 1024) {   // 28672-wide rows: the activation image alone is 119 KiB
         static bool once = [] {
             bool ok = true;
             for (int a = 0; a < 2; ++a)
@@ -466,10 +504,41 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
                                                        160 * 1024) == hipSuccess;
             return ok;
         }();
+        if (!once || L.lds > 160 * 1024) return NTK_E_SHAPE;
+    }
+    const dim3 g(L.grid), b(64 * L.nwaves);
+    hipLaunchKernelGGL(table[norm_w ? 1 : 0][L.xfast ? 1 : 0][L.a16 ? 1 : 0], g, b, L.lds, st, L.p);
+    return last_launch_status();
+}
+
+// segments of two formats sharing x (no residual / SiLU epilogue): one launch, workgroups split by bytes
+template <int DTA, int DTB>
+static int launch_pair(const ntk_gemv_seg* sa, int na, const ntk_gemv_seg* sb, int nb, const float* x, int in, const float* norm_w,
+                       float eps, hipStream_t st) {
+    const double ba = (double)Fmt<DTA>::BB / Fmt<DTA>::BW, bb = (double)Fmt<DTB>::BB / Fmt<DTB>::BW;
+    long ra = 0, rb = 0;
+    for (int i = 0; i < na; ++i) ra += sa[i].rows;
+    for (int i = 0; i < nb; ++i) rb += sb[i].rows;
+    if (ra <= 0 || rb <= 0) return NTK_E_SHAPE;
+    const int total_wg = max_workgroups();
+    int wa = (int)(total_wg * (ra * ba) / (ra * ba + rb * bb) + 0.5);
+    wa = std::min(std::max(wa, 1), total_wg - 1);
+    GemvLaunch A, B;
+    int rc = prepare_quant<DTA>(sa, na, x, in, norm_w, eps, nullptr, 0, wa, A);
+    if (rc == NTK_OK) rc = prepare_quant<DTB>(sb, nb, x, in, norm_w, eps, nullptr, 0, total_wg - wa, B);
+    if (rc != NTK_OK) return rc;
+    // the pair kernel is the aligned fast form of both formats: anything else goes out as two launches (NTK_E_ALIGN -> caller)
+    if (!A.xfast || !B.xfast || A.nwaves != B.nwaves || A.a16 != A16_OK<DTA> || B.a16 != A16_OK<DTB>) return NTK_E_ALIGN;
+    for (int i = 0; i < na; ++i) if (A.p.seg[i].delta != 0 && A16_OK<DTA>) return NTK_E_ALIGN;
+    const size_t lds = std::max(A.lds, B.lds);
+    using PairFn = void (*)(const GemvParams, const GemvParams, int);
+    static const PairFn table[2] = {gemv_quant_pair_kernel<DTA, DTB, false>, gemv_quant_pair_kernel<DTA, DTB, true>};
+    if (lds > 64 * 1024) {
+        static bool once = hipFuncSetAttribute((const void*)table[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                           hipFuncSetAttribute((const void*)table[1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!once || lds > 160 * 1024) return NTK_E_SHAPE;
     }
-    const dim3 g(grid), b(64 * nwaves);
-    hipLaunchKernelGGL(table[norm_w ? 1 : 0][xfast ? 1 : 0][a16 ? 1 : 0], g, b, lds, st, p);
+    hipLaunchKernelGGL(table[norm_w ? 1 : 0], dim3(A.grid + B.grid), dim3(64 * A.nwaves), lds, st, A.p, B.p, A.grid);
     return last_launch_status();
 }
 
@@ -522,11 +591,24 @@ int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_fe
                    const float* resid, int silu_pair, void* stream) {
     if (!segs || !x) return NTK_E_NULL;
     if (nseg < 1 || nseg > ntk::MAX_SEG) return NTK_E_SHAPE;
-    for (int i = 1; i < nseg; ++i)
-        if (segs[i].dtype != segs[0].dtype) return NTK_E_DTYPE;
-    if (!ntk::is_quant(segs[0].dtype)) return NTK_E_DTYPE;
-    return ntk::dispatch_quant(segs[0].dtype, segs, nseg, x, in_features, norm_w, eps, resid, silu_pair,
-                               ntk::resolve_stream(stream));
+    ntk_gemv_seg a[3], b[3];
+    int na = 0, nb = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!ntk::is_quant(segs[i].dtype)) return NTK_E_DTYPE;
+        if (segs[i].dtype == segs[0].dtype) a[na++] = segs[i];
+        else if (nb == 0 || segs[i].dtype == b[0].dtype) b[nb++] = segs[i];
+        else return NTK_E_DTYPE;   // three formats in one call
+    }
+    hipStream_t st = ntk::resolve_stream(stream);
+    if (nb == 0) return ntk::dispatch_quant(segs[0].dtype, segs, nseg, x, in_features, norm_w, eps, resid, silu_pair, st);
+    // two formats: supported as one launch for the K-quant mixes of llama.cpp's Q4_K_M, plain projections only
+    if (resid || silu_pair) return NTK_E_DTYPE;
+    const int da = a[0].dtype, db = b[0].dtype;
+    if (da == NTK_DT_Q4_K && db == NTK_DT_Q6_K) return ntk::launch_pair<NTK_DT_Q4_K, NTK_DT_Q6_K>(a, na, b, nb, x, in_features, norm_w, eps, st);
+    if (da == NTK_DT_Q6_K && db == NTK_DT_Q4_K) return ntk::launch_pair<NTK_DT_Q4_K, NTK_DT_Q6_K>(b, nb, a, na, x, in_features, norm_w, eps, st);
+    if (da == NTK_DT_Q4_K && db == NTK_DT_Q5_K) return ntk::launch_pair<NTK_DT_Q4_K, NTK_DT_Q5_K>(a, na, b, nb, x, in_features, norm_w, eps, st);
+    if (da == NTK_DT_Q5_K && db == NTK_DT_Q4_K) return ntk::launch_pair<NTK_DT_Q4_K, NTK_DT_Q5_K>(b, nb, a, na, x, in_features, norm_w, eps, st);
+    return NTK_E_DTYPE;
 }
 
 }  // extern "C"

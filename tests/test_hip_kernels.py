@@ -248,6 +248,33 @@ def test_gemv_fused_norm_qkv(qname, in_f, rows):
         assert np.abs(yd[i].numpy() - refs[i]).max() <= 2 * tol_for(refs[i], in_f)
 
 
+@pytest.mark.parametrize("other", ["Q6_K", "Q5_K"])
+@pytest.mark.parametrize("norm", [True, False])
+@pytest.mark.parametrize("in_f,rows", [(256, (64, 32, 32)), (4096, (4096, 1024, 1024)), (8192, (8192, 1024, 1024))])
+def test_gemv_fused_two_formats_one_launch(other, norm, in_f, rows):
+    """llama.cpp's Q4_K_M stores attn_v as Q6_K (or Q5_K at 70B) beside Q4_K attn_q / attn_k: the fused norm + Q|K|V
+    projection of such a layer is still ONE launch (workgroups split between the two decoders).  Same per-row arithmetic
+    as the single-format launches, in both segment orders; checked against the oracle's rmsnorm + gemv."""
+    gts = [G.GGML_Q4_K, G.GGML_Q4_K, QUANT[other]]
+    r = rng(in_f + 977 + len(other))
+    x = (r.standard_normal(in_f) * 3).astype(np.float32)
+    nw = (1 + 0.05 * r.uniform(-1, 1, in_f)).astype(np.float32)
+    Ws = [np.frombuffer(G.synth_tensor(r, gt, n, in_f), np.uint8) for gt, n in zip(gts, rows)]
+    xn = O.rmsnorm(x, nw, 1e-5) if norm else x
+    refs = [O.gemv(W, xn, n, in_f, G.GGML_TO_DT[gt]) for W, n, gt in zip(Ws, rows, gts)]
+    xd, nd = DB.from_numpy(x), DB.from_numpy(nw)
+    Wd = [DB.from_numpy(W) for W in Ws]
+    for order in ([0, 1, 2], [2, 0, 1]):
+        yd = [DB.from_numpy(np.full(n, np.nan, np.float32)) for n in rows]
+        ops.gemv_fused([(Wd[i], yd[i], rows[i], G.GGML_TO_DT[gts[i]]) for i in order], xd, in_f, norm_w=nd if norm else None, eps=1e-5)
+        ops.synchronize()
+        for i in range(3):
+            assert np.abs(yd[i].numpy() - refs[i]).max() <= 2 * tol_for(refs[i], in_f), (order, i)
+    # three formats, or a residual / SiLU epilogue across formats, are refused (the engine then launches per format)
+    with pytest.raises(Exception):
+        ops.gemv_fused([(Wd[0], yd[0], rows[0], G.GGML_TO_DT[gts[0]]), (Wd[2], yd[2], rows[2], G.GGML_TO_DT[gts[2]])], xd, in_f, resid=yd[0])
+
+
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
 @pytest.mark.parametrize("in_f,out_f", [(512, 256), (4096, 4096), (14336, 4096), (28672, 1024)])
 def test_gemv_fused_residual_in_place(qname, in_f, out_f):
