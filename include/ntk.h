@@ -238,6 +238,18 @@ int ntk_embed_rows(float* out, const void* table, const int* tokens, int n_token
  * scratch: device buffer of >= 2*1024 floats. */
 int ntk_argmax(const float* logits, int n, int* d_out_token, int* h_mirror, float* scratch, void* stream);
 
+/* The reference's sampler on the device (reference src/inference/sampler.cpp:30-117), for temperature > 0 and
+ * 0 < top_k <= 64 (NTK_E_SHAPE otherwise: the caller samples on the host): repeat penalty over d_recent[n_recent] (DEVICE
+ * ints, applied in place to `logits`, once per occurrence), logits / temperature, top-k, softmax, top-p cut, and the walk of the
+ * cumulative distribution against `r` -- the uniform draw the caller takes from ITS std::mt19937, one per token, so the token
+ * stream equals the host sampler's for the same seed.  Result to *d_out_token and *h_mirror (pinned, may be NULL).
+ * scratch: ntk_sample_scratch_bytes(n) device bytes.  Vocabularies up to 131 072. */
+size_t ntk_sample_scratch_bytes(int n);
+int ntk_sample_top_k(float* logits, int n, const int* d_recent, int n_recent, float repeat_penalty, float temperature,
+                     int top_k, float top_p, float r, int* d_out_token, int* h_mirror, void* scratch, void* stream);
+/* the repeat penalty alone (greedy decoding with a penalty = this + ntk_argmax) */
+int ntk_repeat_penalty(float* logits, int n, const int* d_recent, int n_recent, float repeat_penalty, void* stream);
+
 /* *d_pos += 1 (one thread); keeps positions on the device across graph replays */
 int ntk_advance_pos(int* d_pos, void* stream);
 

@@ -107,6 +107,8 @@ int   nt_tokenizer_is_gpt2(nt_tokenizer_t t);
 /* n_draws successive Sampler::sample calls on the same logits (penalty applied once per draw over `recent`) */
 int   nt_sampler_draw(const float* logits, int n, const nt_gen_params* p, const int* recent, int n_recent,
                       int n_draws, int* out);
+/* the first n uniform draws a sampler seeded with `seed` consumes (one per sampled token) */
+int   nt_sampler_uniforms(uint64_t seed, int n, float* out);
 
 #ifdef __cplusplus
 }

@@ -288,4 +288,16 @@ int nt_sampler_draw(const float* logits, int n, const nt_gen_params* p, const in
     return n_draws;
 }
 
+// the uniform draws Sampler::sample takes from std::mt19937(seed), in order (one per sampled token): lets a test (or an embedder
+// running ntk_sample_top_k itself) stay in step with the host sampler
+int nt_sampler_uniforms(uint64_t seed, int n, float* out) {
+    if (!out || n < 0) return NTK_E_NULL;
+    nt::Sampler s;
+    nt::SamplerConfig c;
+    c.seed = seed;
+    s.init(c);
+    for (int i = 0; i < n; ++i) out[i] = s.draw();
+    return n;
+}
+
 }  // extern "C"

@@ -47,6 +47,9 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
     const int V = model_.config().vocab_size;
     const int eos = tok_.eos_id();
     const bool dev_greedy = opt_.fused && opt_.device_sampling && sampler.is_pure_greedy();
+    // temperature / top-k / top-p / repeat penalty on the device too (ntk_sample_top_k): the host only draws the uniform number
+    const bool dev_sample = opt_.fused && opt_.device_sampling && !dev_greedy &&
+                            Model::device_sampler_supports(cfg.temperature, cfg.top_k, V);
     stats_.prompt_tokens = (int)tokens.size();
     if (cfg.verbose) fprintf(stderr, "Prompt tokens: %d\n", stats_.prompt_tokens);
 
@@ -87,6 +90,14 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
             if (dev_greedy) {
                 if ((rc = model_.sync()) != NTK_OK) break;
                 next = model_.host_token();                 // first max, same as Sampler::argmax
+            } else if (dev_sample) {
+                const int have = (int)tokens.size(), win = std::min(have, cfg.repeat_window);   // sampler.cpp:34
+                const float r = cfg.temperature > 0.0f ? sampler.draw() : 0.0f;                  // greedy takes no draw
+                rc = model_.sample_on_device(tokens.data() + have - win, win, cfg.repeat_penalty, cfg.temperature, cfg.top_k,
+                                             cfg.top_p, r);
+                if (rc == NTK_OK) rc = model_.sync();
+                if (rc != NTK_OK) break;
+                next = model_.host_token();
             } else {
                 if ((rc = model_.copy_logits(host.data())) != NTK_OK) break;
                 sampler.apply_repeat_penalty(host.data(), V, tokens);

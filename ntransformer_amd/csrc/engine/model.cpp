@@ -36,6 +36,10 @@ void Model::free_all() {
     allocs_.clear();
     if (h_token_) nt_hip_free_host(h_token_);
     h_token_ = nullptr;
+    if (h_recent_) nt_hip_free_host(h_recent_);
+    h_recent_ = nullptr;
+    sample_scratch_ = nullptr;
+    d_recent_ = nullptr;
     layers_.clear();
     // a second load() on the same object starts from a clean slate
     token_embd_ = output_norm_ = output_ = DevTensor();
@@ -210,6 +214,9 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
     attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
+    sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
+    d_recent_ = (int*)dev(kRecentCap * 4, false);
+    h_recent_ = (int*)nt_hip_malloc_host(kRecentCap * 4);
     if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
         !d_pos_ || !d_token_ || !argmax_scratch_ || !h_token_) {
         err_ = "buffer allocation failed";
@@ -338,6 +345,25 @@ int Model::host_token() const { return *h_token_; }
 int Model::copy_logits(float* host) {
     NT_TRY(ntk_memcpy_d2h_async(host, logits_, (size_t)cfg_.vocab_size * 4, stream_));
     return ntk_stream_synchronize(stream_);
+}
+
+int Model::sample_on_device(const int* recent, int n_recent, float repeat_penalty, float temperature, int top_k, float top_p, float r) {
+    if (!sample_scratch_ || !d_recent_ || !h_recent_) return NTK_E_NOMEM;
+    if (n_recent > kRecentCap) { recent += n_recent - kRecentCap; n_recent = kRecentCap; }
+    void* s = stream_;
+    if (repeat_penalty > 1.0f && n_recent > 0) {
+        // the previous token's copy of the window has completed (the host synchronised to read that token)
+        memcpy(h_recent_, recent, (size_t)n_recent * 4);
+        NT_TRY(ntk_memcpy_h2d_async(d_recent_, h_recent_, (size_t)n_recent * 4, s));
+    } else {
+        n_recent = 0;
+    }
+    if (temperature <= 0.0f) {   // greedy with a repeat penalty: Sampler::sample returns argmax of the penalised logits
+        NT_TRY(ntk_repeat_penalty(logits_, cfg_.vocab_size, d_recent_, n_recent, repeat_penalty, s));
+        return ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s);
+    }
+    return ntk_sample_top_k(logits_, cfg_.vocab_size, d_recent_, n_recent, repeat_penalty, temperature, top_k, top_p, r, d_token_,
+                            h_token_, sample_scratch_, s);
 }
 
 int Model::enqueue_token(bool greedy) {

@@ -57,6 +57,12 @@ public:
     int host_token() const;                 // token written by the last device argmax (after sync)
     float* logits_ptr() { return logits_; }
     int copy_logits(float* host);           // D2H of [vocab] floats (blocking)
+    // Sample the next token from the device logits with the reference's sampler (ntk_sample_top_k / penalty + ntk_argmax when
+    // temperature <= 0): result in d_token_ and, after sync(), host_token().  recent: the last tokens (host), r: the host's draw.
+    int sample_on_device(const int* recent, int n_recent, float repeat_penalty, float temperature, int top_k, float top_p, float r);
+    static bool device_sampler_supports(float temperature, int top_k, int vocab) {
+        return temperature <= 0.0f || (top_k > 0 && top_k <= 64 && top_k < vocab && vocab <= 131072);
+    }
 
     const ModelConfig& config() const { return cfg_; }
     const GgufVocab& vocab() const { return vocab_; }
@@ -116,6 +122,10 @@ private:
     int* d_token_ = nullptr;        // device scalar: id of the token being decoded
     int* h_token_ = nullptr;        // pinned mirror of the argmax result
     float* argmax_scratch_ = nullptr;
+    void* sample_scratch_ = nullptr;
+    int* d_recent_ = nullptr;       // device copy of the repeat-penalty window
+    int* h_recent_ = nullptr;       // pinned staging of it
+    static constexpr int kRecentCap = 4096;
     float* rope_inv_freq_ = nullptr; // [hd/2] 1/powf(theta, 2i/hd), computed once on the host (rotary.cu:47)
     void* stream_ = nullptr;
     bool batched_prefill_ = true;

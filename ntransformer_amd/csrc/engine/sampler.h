@@ -26,6 +26,10 @@ public:
     void apply_repeat_penalty(float* logits, int n, const std::vector<int>& recent) const;
     int sample(const float* logits, int n);
     bool is_pure_greedy() const { return cfg_.temperature <= 0.0f && cfg_.repeat_penalty <= 1.0f; }
+    // the uniform draw sample() takes from the generator (sampler.cpp:103-104), for a sampler that runs elsewhere (the device):
+    // exactly one per sampled token, so the generator stays in step with the reference's
+    float draw() { std::uniform_real_distribution<float> uni(0.0f, 1.0f); return uni(rng_); }
+    const SamplerConfig& config() const { return cfg_; }
 
 private:
     SamplerConfig cfg_;

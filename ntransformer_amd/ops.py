@@ -166,6 +166,19 @@ def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resi
                                     stream), "gemv_fused")
 
 
+def sample_top_k(logits, n, recent, n_recent, repeat_penalty, temperature, top_k, top_p, r, d_out, stream=None):
+    """ntk_sample_top_k: the reference sampler on the device; logits are penalised in place; token id to d_out (device int)."""
+    L = _lib.lib()
+    L.ntk_sample_scratch_bytes.restype = C.c_size_t
+    scratch = DeviceBuffer(int(L.ntk_sample_scratch_bytes(C.c_int(n))))
+    L.ntk_sample_top_k.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    st = L.ntk_sample_top_k(_p(logits), n, _p(recent), n_recent, repeat_penalty, temperature, top_k, top_p, r, _p(d_out), None,
+                            _p(scratch), stream)
+    synchronize()
+    return st
+
+
 def gemm_quant(Y, W, X, n_tokens, out_features, in_features, dtype, resid=None, stream=None):
     """Y[t,:] = W . X[t,:] (+ resid[t,:]) for a chunk of prompt tokens: one pass over W per 16 tokens (ntk_gemm_quant)."""
     check(_lib.lib().ntk_gemm_quant(_p(Y), _p(W), _p(X), n_tokens, out_features, in_features, int(dtype), _p(resid),

@@ -411,3 +411,22 @@ def test_persistent_token_kernel_matches_the_launch_path(name, shape, mix, tmp_p
         err = np.abs(outs[mode][0] - outs["launches"][0]).max()
         assert np.isfinite(outs[mode][0]).all() and err <= 2e-4, (name, mode, err)
     assert outs["persistent"][1] == outs["persistent_graph"][1]
+
+
+@pytest.mark.parametrize("cfg", [dict(temperature=0.7, top_k=40, top_p=0.9, repeat_penalty=1.1), dict(temperature=0.0, repeat_penalty=1.3),
+                                 dict(temperature=1.5, top_k=5, top_p=1.0, repeat_penalty=1.0)])
+def test_device_sampling_gives_the_host_samplers_token_stream(cfg, tmp_path):
+    """Engine::generate with the reference's DEFAULT CLI settings (-t 0.7, top-k 40, top-p 0.9, repeat-penalty 1.1;
+    reference src/main.cpp) samples on the device (one pinned int per token instead of a 513 KB logits download and a
+    host partial_sort); the token stream must equal the host sampler's (device_sampling = 0), same seed."""
+    path, z = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)
+    prompt = [int(t) for t in z["prompt"]]
+    outs = []
+    for dev in (1, 0):
+        eng = E.Engine()
+        eng.load(path, 512)
+        eng.set_option("device_sampling", dev)
+        outs.append(eng.generate_tokens(prompt, 40, seed=7, repeat_window=64, stop_at_eos=False, **cfg))
+        eng.close()
+    assert outs[0] == outs[1], outs
+    assert len(set(outs[0])) > 3

@@ -531,3 +531,39 @@ def test_argmax_first_maximum_and_advance_pos():
     ops.advance_pos(p)
     ops.synchronize()
     assert p.numpy(np.int32)[0] == 43
+
+
+# ------------------------------------------------------------------------------- device sampler
+@pytest.mark.parametrize("n,top_k,top_p,temp,pen", [(128256, 40, 0.9, 0.7, 1.1), (128256, 64, 0.5, 1.3, 1.0), (512, 8, 1.0, 0.2, 1.5),
+                                                    (2049, 1, 0.9, 0.7, 1.1), (131072, 33, 0.95, 2.0, 1.2)])
+def test_device_sampler_reproduces_the_host_sampler_stream(n, top_k, top_p, temp, pen):
+    """ntk_sample_top_k (repeat penalty, temperature, top-k, softmax, top-p, cumulative walk on the device) against the
+    engine's host sampler -- itself bit-identical to the reference's Sampler class on the golden draws
+    (tests/test_host_logic.py) -- on the same logits, the same growing window of recent tokens and the same std::mt19937
+    stream: the sampled token ids must be the same, draw for draw (reference src/inference/sampler.cpp:30-117)."""
+    import ctypes as C
+    from ntransformer_amd import engine as E
+    L = E._bind()
+    r = rng(n + top_k)
+    logits = (r.standard_normal(n) * 3).astype(np.float32)
+    logits[r.integers(0, n, 5)] += 6.0                     # a few dominant tokens so that repeats (and the penalty) occur
+    n_draws, seed = 24, 1234
+    p = E.GenParams(0, temp, top_k, top_p, pen, 16, seed, 0)
+    recent0 = [int(t) for t in r.integers(0, n, 7)]
+    want = (C.c_int * n_draws)()
+    L.nt_sampler_draw.argtypes = [C.c_void_p, C.c_int, C.POINTER(E.GenParams), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]
+    assert L.nt_sampler_draw(logits.ctypes.data_as(C.c_void_p), n, C.byref(p), (C.c_int * len(recent0))(*recent0), len(recent0), n_draws, want) == n_draws
+    uni = np.zeros(n_draws, np.float32)
+    L.nt_sampler_uniforms.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
+    assert L.nt_sampler_uniforms(seed, n_draws, uni.ctypes.data_as(C.c_void_p)) == n_draws
+    recent, got = list(recent0), []
+    d_out = DB.zeros(64)
+    for d in range(n_draws):
+        ld = DB.from_numpy(logits)                          # the penalty is applied in place: fresh logits per draw, like the host
+        win = recent[-16:]                                  # repeat_window = 16
+        rd = DB.from_numpy(np.asarray(win, np.int32))
+        assert ops.sample_top_k(ld, n, rd, len(win), pen, temp, top_k, top_p, float(uni[d]), d_out) == 0
+        got.append(int(d_out.numpy().view(np.int32)[0]))
+        recent.append(got[-1])
+    assert got == list(want), (got, list(want))
+    assert len(set(got)) > 1 or top_k == 1
