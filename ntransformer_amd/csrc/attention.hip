@@ -13,6 +13,7 @@
 // from device memory so the launch can be replayed from a hipGraph.
 #include "common.hip.h"
 #include <cfloat>
+#include <cstdlib>
 
 namespace ntk {
 
@@ -461,6 +462,108 @@ __global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prompt attention, flash style (replaces attention_prefill_kernel, reference attention.cu:216-311,
+// whose one-block-per-(head, query) form re-reads every K / V row once per query: 32 x 1024 blocks each walking up
+// to 1024 keys for a 1024-token prompt).  One workgroup per (head, tile of 32 queries): the keys the tile can see go
+// through LDS in tiles of 64 cache rows (K and V, raw halves, 32 KB), every wave owns 8 of the queries and keeps an online
+// softmax state (running max, sum, 8 output dims per lane) per query in registers -- the decode kernel's inner loop with
+// the cache rows coming from LDS and shared by the 32 queries.  K / V traffic per head falls from T^2 / 2 rows to
+// T^2 / 64; no score row in LDS, so no limit on the context.  F32 math on the same half-rounded K / V, causal limit
+// start_pos + query index; only the summation order differs from the reference kernel (|d out| ~1e-6).
+// ---------------------------------------------------------------------------------------------
+constexpr int FA_QT = 32;    // queries per workgroup
+constexpr int FA_KT = 64;    // cache rows per LDS tile
+constexpr int FA_QPW = 8;    // queries per wave (4 waves)
+
+template <int LPR>
+__global__ __launch_bounds__(256) void attention_prefill_tiled_kernel(float* __restrict__ output, const float* __restrict__ Q,
+                                                                     const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+                                                                     int T, int start_pos, int n_heads, int n_kv_heads, float scale) {
+    constexpr int HD = 8 * LPR, PPW = 64 / LPR;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fa_lds[];
+    uint16_t* kt = reinterpret_cast<uint16_t*>(fa_lds);                 // [FA_KT][HD] halves
+    uint16_t* vt = kt + FA_KT * HD;                                     // [FA_KT][HD]
+    float* qt = reinterpret_cast<float*>(vt + FA_KT * HD);              // [FA_QT][HD] queries of the tile
+    const int head = blockIdx.x, q0 = blockIdx.y * FA_QT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kv_head = head / (n_heads / n_kv_heads);
+    const size_t stride = (size_t)n_kv_heads * HD;
+    const int sub = lane / LPR, part_i = lane % LPR;
+    const int nq = min(FA_QT, T - q0);                                  // queries in this tile
+    for (int i = tid; i < nq * HD; i += 256) qt[i] = Q[((size_t)(q0 + i / HD) * n_heads + head) * HD + (i % HD)];
+    float m[FA_QPW], l[FA_QPW], acc[FA_QPW][8];
+#pragma unroll
+    for (int u = 0; u < FA_QPW; ++u) {
+        m[u] = -INFINITY; l[u] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[u][j] = 0.0f;
+    }
+    const int n_keys = start_pos + q0 + nq;                             // keys 0 .. n_keys-1 are visible to the last query of the tile
+    for (int k0 = 0; k0 < n_keys; k0 += FA_KT) {
+        __syncthreads();                                                // the previous tile has been consumed (and qt is written)
+        const int nk = min(FA_KT, n_keys - k0);
+        for (int i = tid; i < nk * LPR; i += 256) {                     // 16-byte pieces, contiguous per cache row
+            const int r = i / LPR, c = i % LPR;
+            const size_t g = (size_t)(k0 + r) * stride + (size_t)kv_head * HD + 8 * c;
+            *reinterpret_cast<u32x4*>(kt + r * HD + 8 * c) = *reinterpret_cast<const u32x4*>(kc + g);
+            *reinterpret_cast<u32x4*>(vt + r * HD + 8 * c) = *reinterpret_cast<const u32x4*>(vc + g);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < FA_QPW; ++u) {
+            const int qi = wave * FA_QPW + u;                           // query of the tile (wave-uniform)
+            if (qi >= nq) continue;
+            const int last = start_pos + q0 + qi;                       // causal limit: keys <= last
+            if (k0 > last) continue;
+            float qreg[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qreg[j] = qt[qi * HD + 8 * part_i + j];
+            const int kend = min(nk, last - k0 + 1);
+            for (int r0 = 0; r0 < kend; r0 += PPW) {
+                const int r = r0 + sub, rr = min(r, kend - 1);          // past the causal limit: a valid row (finite values), weight 0
+                float kf[8], vf[8];
+                unpack8(*reinterpret_cast<const u32x4*>(kt + rr * HD + 8 * part_i), kf);
+                unpack8(*reinterpret_cast<const u32x4*>(vt + rr * HD + 8 * part_i), vf);
+                float sc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
+                sc = group_sum<LPR>(sc);
+                sc = r < kend ? sc * scale : -INFINITY;
+                const float mn = fmaxf(m[u], sc);
+                const float a = (mn == -INFINITY) ? 1.0f : expf(m[u] - mn), pw = (mn == -INFINITY) ? 0.0f : expf(sc - mn);
+                l[u] = fmaf(l[u], a, pw);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[u][j] = fmaf(acc[u][j], a, pw * vf[j]);
+                m[u] = mn;
+            }
+        }
+    }
+    // merge the PPW position groups of the wave per query, normalise, store
+#pragma unroll
+    for (int u = 0; u < FA_QPW; ++u) {
+        const int qi = wave * FA_QPW + u;
+        if (qi >= nq) continue;
+        float mm = m[u], ll = l[u];
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(mm, off, 64), lo = __shfl_xor(ll, off, 64);
+            const float mn = fmaxf(mm, mo);
+            const float wa = (mm == -INFINITY) ? 0.0f : expf(mm - mn), wb = (mo == -INFINITY) ? 0.0f : expf(mo - mn);
+            ll = fmaf(ll, wa, lo * wb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[u][j] = fmaf(acc[u][j], wa, __shfl_xor(acc[u][j], off, 64) * wb);
+            mm = mn;
+        }
+        if (sub == 0) {
+            const float inv = ll > 0.0f ? 1.0f / ll : 0.0f;             // reference attention.cu:293
+            float* o = output + ((size_t)(q0 + qi) * n_heads + head) * HD + 8 * part_i;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = acc[u][j] * inv;
+        }
+    }
+}
+
 __global__ void rope_kernel(float* __restrict__ q, float* __restrict__ k, const int* __restrict__ positions, int seq_len,
                             int n_heads, int n_kv_heads, int head_dim, float theta, float fscale, int interleaved) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -499,11 +602,25 @@ static int launch_attention(float* out, const float* Q, const void* kc, const vo
     if (nh <= 0 || nkv <= 0 || hd <= 0 || nh % nkv != 0 || T < 0) return NTK_E_SHAPE;
     if (T == 0) return NTK_OK;
     const int max_keys = causal ? n_keys_base + T : n_keys_base;
-    const size_t lds = attn_lds(hd, max_keys, 1);
-    if (lds > 160 * 1024) return NTK_E_SHAPE;
     const bool aligned = (reinterpret_cast<uintptr_t>(kc) & 15) == 0 && (reinterpret_cast<uintptr_t>(vc) & 15) == 0;
     const uint16_t* k16 = static_cast<const uint16_t*>(kc);
     const uint16_t* v16 = static_cast<const uint16_t*>(vc);
+    static const bool tiled_off = [] { const char* e = getenv("NTK_PREFILL_ATTENTION_1TO1"); return e && atoi(e) != 0; }();
+    if (causal && T > 1 && aligned && (hd == 64 || hd == 128 || hd == 256) && !tiled_off) {   // prompt: flash-style tiles
+        const size_t fl = (size_t)2 * FA_KT * hd * sizeof(uint16_t) + (size_t)FA_QT * hd * sizeof(float);
+        const dim3 fgrid(nh, (T + FA_QT - 1) / FA_QT);
+        if (hd == 128) hipLaunchKernelGGL(attention_prefill_tiled_kernel<16>, fgrid, dim3(256), fl, st, out, Q, k16, v16, T, n_keys_base, nh, nkv, scale);
+        else if (hd == 64) hipLaunchKernelGGL(attention_prefill_tiled_kernel<8>, fgrid, dim3(256), fl, st, out, Q, k16, v16, T, n_keys_base, nh, nkv, scale);
+        else {
+            static bool once = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_prefill_tiled_kernel<32>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl) == hipSuccess;
+            if (!once) return NTK_E_LAUNCH;
+            hipLaunchKernelGGL(attention_prefill_tiled_kernel<32>, fgrid, dim3(256), fl, st, out, Q, k16, v16, T, n_keys_base, nh, nkv, scale);
+        }
+        return last_launch_status();
+    }
+    const size_t lds = attn_lds(hd, max_keys, 1);
+    if (lds > 160 * 1024) return NTK_E_SHAPE;
     dim3 grid(nh, T), block(256);
     // more than 64 KiB of dynamic LDS (contexts beyond ~15K keys) must be opted into per kernel
 #define NTK_ATT(LPR_)                                                                                                   \

@@ -395,6 +395,26 @@ def test_attention_prefill(T, start):
     assert np.abs(od.numpy() - ref).max() <= 2e-5
 
 
+@pytest.mark.parametrize("T,start,nh,nkv,hd", [(256, 0, 32, 8, 128), (256, 130, 32, 8, 128), (37, 5, 4, 2, 64), (33, 0, 8, 1, 128),
+                                               (96, 1000, 64, 8, 128), (1, 7, 8, 2, 128), (70, 3, 4, 4, 256)])
+def test_attention_prefill_tiled_at_model_shapes(T, start, nh, nkv, hd):
+    """The flash-style prompt attention (32-query tiles, K/V tiles through LDS, online softmax; attention.hip) at the real
+    head counts and prompt lengths where the 1:1 kernel's score rows and (nh, T) grid get large: against the oracle's
+    restatement of the reference's attention_prefill_kernel (attention.cu:216-311), causal limit start_pos + query index,
+    ragged last tile, GQA groups 1 / 2 / 4 / 8, and against the 1:1 launcher on the same inputs."""
+    r = rng(T * 7 + start + nh)
+    max_seq = max(512, start + T)
+    kc, vc = make_cache(r, start + T, max_seq, nkv, hd)
+    Q = r.standard_normal(T * nh * hd).astype(np.float32)
+    scale = float(1 / np.sqrt(hd))
+    ref = O.attention_prefill(Q, kc, vc, T, start, nh, nkv, hd, max_seq, scale)
+    od = DB.from_numpy(np.full(T * nh * hd, np.nan, np.float32))
+    ops.launch_attention_prefill(od, DB.from_numpy(Q), DB.from_numpy(kc), DB.from_numpy(vc), T, start, nh, nkv, hd, max_seq, scale)
+    got = od.numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-5, np.abs(got - ref).max()
+
+
 @pytest.mark.parametrize("pos", [0, 1, 15, 16, 63, 300, 2047])
 @pytest.mark.parametrize("nh,nkv,hd,table", [(32, 8, 128, True), (32, 8, 128, False), (4, 2, 64, True), (64, 8, 128, True), (6, 3, 80, False)])
 def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd, table):
