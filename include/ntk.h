@@ -169,6 +169,16 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale,
                                void* stream);
 
+/* ntk_attention_decode_fused + the Wo projection with residual (ntk_gemv_fused(wo, x = attn_out, resid)) as ONE launch: the first
+ * n_heads workgroups compute their head while every wave's first Wo row is in flight, the attention output crosses workgroups
+ * inside the launch (csrc/gemv.hip, AttnFuse).  attn_out: [n_heads * head_dim] scratch that receives the attention output.
+ * sync3: 4096 DEVICE bytes, zero before the first use (every launch leaves them zero again, except word [2]: != 0 afterwards = a
+ * bounded in-kernel wait gave up).  NTK_E_ALIGN / NTK_E_SHAPE / NTK_E_DTYPE: shapes only the two separate launches take. */
+int ntk_attention_gemv_fused(float* attn_out, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
+                             const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                             float scale, float theta_base, float freq_scale, const ntk_gemv_seg* wo, const float* resid,
+                             unsigned* sync3, void* stream);
+
 /* Long-context form of ntk_attention_decode_fused: `nsplit` workgroups share a head (positions interleaved), partial
  * softmax states go through `scratch` (ntk_attention_split_scratch_bytes) and a second launch merges them.  Same
  * arguments and results (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches. */

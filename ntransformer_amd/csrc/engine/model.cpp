@@ -40,6 +40,7 @@ void Model::free_all() {
     h_recent_ = nullptr;
     sample_scratch_ = nullptr;
     d_recent_ = nullptr;
+    attn_sync_ = nullptr;
     layers_.clear();
     // a second load() on the same object starts from a clean slate
     token_embd_ = output_norm_ = output_ = DevTensor();
@@ -215,6 +216,8 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
     sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
+    attn_sync_ = (unsigned*)dev(4096, true);   // [0] heads done, [1] finished, [2] error, [64 + 64 g] release flags
+    if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
     d_recent_ = (int*)dev(kRecentCap * 4, false);
     h_recent_ = (int*)nt_hip_malloc_host(kRecentCap * 4);
     if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
@@ -471,6 +474,17 @@ int Model::enqueue_token(bool greedy) {
             float* ys[3] = {q_buf, k_buf, v_buf};
             NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
         }
+        if (attn_regime_ == 0 && fuse_attention_ && attn_sync_ && is_quant(L.wo.dtype)) {
+            // attention producers inside the Wo launch: one launch, one boundary and one first-byte latency less per layer
+            ntk_gemv_seg wo = {L.wo.ptr, hidden_, (int)L.wo.out_f, L.wo.dtype};
+            mark(0, true);
+            const int st = ntk_attention_gemv_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
+                                                    cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale, &wo, hidden_,
+                                                    attn_sync_, s);
+            mark(0, false);
+            if (st == NTK_OK) goto ffn;
+            if (st != NTK_E_ALIGN && st != NTK_E_SHAPE && st != NTK_E_DTYPE) return st;   // those: shapes only the two launches take
+        }
         mark(1, true);
         if (attn_regime_ == 0)
             NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
@@ -481,6 +495,7 @@ int Model::enqueue_token(bool greedy) {
                                               attn_regime_ == 1 ? 8 : 16, attn_scratch_, s));
         mark(1, false);
         NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
+    ffn:
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
             ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
             mark(0, true);
@@ -511,6 +526,18 @@ const char* Model::decode_path() const {
 }
 
 int Model::check_persistent() {
+    if (attn_sync_ && fuse_attention_) {   // ntk_attention_gemv_fused: a bounded in-kernel wait that gave up
+        unsigned w[3] = {0, 0, 0};
+        nt_hip_memcpy_d2h(w, attn_sync_, sizeof w);
+        if (w[2] != 0) {
+            fuse_attention_ = false;
+            nt_hip_memset(attn_sync_, 0, 4096);
+            for (auto& row : graphs_) for (auto& gx : row) { if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx)); gx = nullptr; }
+            err_ = "attention + Wo fused launch: the wait for the attention workgroups gave up; falling back to separate launches";
+            fprintf(stderr, "%s\n", err_.c_str());
+            return NTK_E_LAUNCH;
+        }
+    }
     if (!persistent_plan_) return NTK_OK;
     int op = -1;
     const int st = ntk_persistent_error(persistent_plan_, &op);

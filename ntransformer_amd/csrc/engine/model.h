@@ -77,6 +77,7 @@ public:
     // when the model qualifies (quantised matrices, head_dim 64 / 128); short contexts only (single-pass attention regime),
     // longer ones keep the launch path.  Turned off for good if the kernel ever reports a bounded wait that gave up.
     void set_persistent(bool on) { persistent_on_ = on; }
+    void set_fuse_attention(bool on) { fuse_attention_ = on; }
     bool persistent_available() const { return persistent_plan_ != nullptr; }
     void* persistent_plan() const { return persistent_plan_; }
     // which form decode_step_fused(…) emits at the current position: "persistent" / "fused launches"
@@ -138,6 +139,8 @@ private:
     int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
     int attn_regime_ = 0;            // regime enqueue_token() emits
     float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention
+    unsigned* attn_sync_ = nullptr;  // 3 words for ntk_attention_gemv_fused (attention producers inside the Wo launch)
+    bool fuse_attention_ = false;    // attention + Wo projection as one launch: measured SLOWER than two launches (profiles/r02_*): opt-in
     void* persistent_plan_ = nullptr;
     bool persistent_on_ = false;   // opt-in until it beats the launch path on the bench (set_persistent / "persistent" option)
 };

@@ -433,3 +433,32 @@ def test_device_sampling_gives_the_host_samplers_token_stream(cfg, tmp_path):
         eng.close()
     assert outs[0] == outs[1], outs
     assert len(set(outs[0])) > 3
+
+
+@pytest.mark.parametrize("name,shape,mix", [c for c in CASES if c[0] in ("tiny_q8_0", "tiny_q4_k_m", "small_q8_0", "small_q6_k")])
+def test_attention_inside_the_wo_launch_matches_separate_launches(name, shape, mix, tmp_path):
+    """Short contexts: RoPE + KV store + attention run as extra workgroups IN FRONT of the Wo projection's grid
+    (ntk_attention_gemv_fused: the GEMV workgroups request their first weight rows, then wait for the heads), one launch
+    less per layer.  Same arithmetic as ntk_attention_decode_fused + ntk_gemv_fused; compared on the same KV cache, eager and
+    hipGraph replay, across many positions (the sync words must return to zero after every launch)."""
+    path, z = golden_model(name, shape, mix, tmp_path)
+    prompt = [int(t) for t in z["prompt"]]
+    r = np.random.Generator(np.random.Philox(key=[20260925, 31]))
+    fed = [int(t) for t in r.integers(0, 256, 24)]
+    outs = {}
+    for mode in ("separate", "fused", "fused_graph"):
+        eng = E.Engine()
+        eng.load(path, int(z["ctx"]))
+        eng.set_option("fuse_attention", mode != "separate")
+        lg = [eng.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in fed:
+            lg.append(eng.decode_fused(t, pos, mode == "fused_graph"))
+            pos += 1
+        toks = eng.decode_greedy_steps(fed[-1], pos, 16)
+        outs[mode] = (np.stack(lg), toks)
+        eng.close()
+    for mode in ("fused", "fused_graph"):
+        err = np.abs(outs[mode][0] - outs["separate"][0]).max()
+        assert np.isfinite(outs[mode][0]).all() and err <= 2e-4, (name, mode, err)
+    assert outs["fused"][1] == outs["fused_graph"][1]
