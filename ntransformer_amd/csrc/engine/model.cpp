@@ -41,6 +41,7 @@ void Model::free_all() {
     sample_scratch_ = nullptr;
     d_recent_ = nullptr;
     attn_sync_ = nullptr;
+    gemm_ws_ = nullptr;
     layers_.clear();
     // a second load() on the same object starts from a clean slate
     token_embd_ = output_norm_ = output_ = DevTensor();
@@ -216,7 +217,11 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
     sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
-    attn_sync_ = (unsigned*)dev(4096, true);   // [0] heads done, [1] finished, [2] error, [64 + 64 g] release flags
+    attn_sync_ = (unsigned*)dev(4096, true);
+    gemm_ws_bytes_ = ntk_gemm_quant_workspace_bytes(std::max(cfg_.hidden_size, cfg_.intermediate_size),
+                                                    std::max({cfg_.hidden_size, cfg_.intermediate_size, cfg_.n_heads * cfg_.head_dim}));
+    gemm_ws_ = dev(gemm_ws_bytes_, false);
+    if (const char* e = getenv("NTK_BF16_PREFILL")) bf16_prefill_ = atoi(e) != 0;   // [0] heads done, [1] finished, [2] error, [64 + 64 g] release flags
     if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
     d_recent_ = (int*)dev(kRecentCap * 4, false);
     h_recent_ = (int*)nt_hip_malloc_host(kRecentCap * 4);
@@ -284,9 +289,16 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     };
     // Y[t] = W . X[t] for the T tokens: one pass over W per 16 tokens on the matrix cores, or the reference's loop
     const bool batched = batched_prefill_ && T > 1;
+    const float* planes_of = nullptr;   // the x whose BF16 planes sit in gemm_ws_ (Q, K, V and gate, up share one x)
     auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
         if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
-            const int st = ntk_gemm_quant(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s);
+            int st = NTK_E_DTYPE;
+            if (bf16_prefill_ && gemm_ws_)   // BF16 matrix cores, 64 tokens per pass (Q8_0 / Q4_K / Q6_K, aligned shapes)
+                st = ntk_gemm_quant_ws(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
+                                       X == planes_of ? 1 : 0, s);
+            if (st == NTK_OK) planes_of = X;
+            if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)
+                st = ntk_gemm_quant(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s);
             if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }   // those two: shapes only the per-token loop takes
         }
         for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, X + (size_t)t * xstride);
@@ -295,7 +307,12 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     // projection adds the residual in its epilogue, the reference sequence goes through residual_ and launch_add_inplace
     auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
         if (batched && is_quant(w.dtype) && (size_t)w.out_f == (size_t)H && xstride == (size_t)w.in_f) {
-            const int st = ntk_gemm_quant(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s);
+            int st = NTK_E_DTYPE;
+            if (bf16_prefill_ && gemm_ws_)
+                st = ntk_gemm_quant_ws(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, s);
+            planes_of = nullptr;   // (this projection rewrites hidden_, and the next group has a new x)
+            if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)
+                st = ntk_gemm_quant(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s);
             if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }
         }
         project(residual_, w, X, H, xstride);
@@ -306,6 +323,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
         ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.attn_norm.ptr, T, H, cfg_.norm_eps, s));
+        planes_of = nullptr;   // residual_ has new contents
         project(q_buf, L.wq, residual_, qd, H);
         project(k_buf, L.wk, residual_, kvd, H);
         project(v_buf, L.wv, residual_, kvd, H);
@@ -315,6 +333,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         else ok(ntk_attention_prefill(attn_out, q_buf, kc, vc, T, start_pos, nh, nkv, hd, cfg_.max_seq_len, scale, s));
         project_add(L.wo, attn_out, qd);
         ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.ffn_norm.ptr, T, H, cfg_.norm_eps, s));
+        planes_of = nullptr;
         project(gate_buf, L.w_gate, residual_, I, H);
         project(up_buf, L.w_up, residual_, I, H);
         ok(ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s));   // per token in the reference (ffn.cpp:127): same elementwise op

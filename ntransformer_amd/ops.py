@@ -166,6 +166,19 @@ def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resi
                                     stream), "gemv_fused")
 
 
+def gemm_quant_ws(Y, W, X, n_tokens, out_features, in_features, dtype, resid=None, stream=None):
+    """ntk_gemm_quant_ws: BF16-MFMA prompt projection, 64 tokens per pass (workspace allocated here)."""
+    L = _lib.lib()
+    L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+    n = int(L.ntk_gemm_quant_workspace_bytes(C.c_int(in_features), C.c_int(out_features)))
+    ws = DeviceBuffer(n)
+    L.ntk_gemm_quant_ws.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_int, C.c_void_p]
+    st = L.ntk_gemm_quant_ws(_p(Y), _p(W), _p(X), n_tokens, out_features, in_features, int(dtype), _p(resid), _p(ws), n, 0, stream)
+    synchronize()
+    return st
+
+
 def sample_top_k(logits, n, recent, n_recent, repeat_penalty, temperature, top_k, top_p, r, d_out, stream=None):
     """ntk_sample_top_k: the reference sampler on the device; logits are penalised in place; token id to d_out (device int)."""
     L = _lib.lib()

@@ -131,6 +131,56 @@ def test_gemm_quant_matches_per_token_oracle(qname, T, out_f, in_f):
     assert np.abs(Y - ref).max() <= tol_for(ref, in_f), np.abs(Y - ref).max()
 
 
+def gemm_ws_gpu(Wraw, X, out_f, in_f, dt, resid=None):
+    T = X.shape[0]
+    Wd = DB.from_numpy(Wraw)
+    Xd = DB.from_numpy(np.ascontiguousarray(X, np.float32))
+    Yd = DB.from_numpy(np.full((T, out_f), np.nan, np.float32) if resid is None else resid.astype(np.float32))
+    st = ops.gemm_quant_ws(Yd, Wd, Xd, T, out_f, in_f, dt, resid=Yd if resid is not None else None)
+    assert st == 0, st
+    return Yd.numpy(np.float32).reshape(T, out_f)
+
+
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048),
+                                          (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672)])
+def test_gemm_quant_bf16_matches_per_token_oracle(qname, T, out_f, in_f):
+    """ntk_gemm_quant_ws (BF16 matrix cores, integer weights x three exact BF16 pieces of every activation, 64 tokens per
+    pass) against the oracle's GEMV applied token by token -- what the reference's prefill loop computes
+    (attention.cpp:144-162, ffn.cpp:96-133): ragged token counts, 1 / 2 row tiles per wave, both row-tile geometries,
+    K-quant sub-scales and minima, Q6_K's 16-column sub-scales.  Same tolerance as the F32-MFMA path: only the summation order
+    differs."""
+    gt = QUANT[qname]
+    r = rng(T * 1000 + out_f * 7 + in_f + gt + 1)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = (r.standard_normal((T, in_f)) * np.exp(r.uniform(-6, 6, (T, 1)))).astype(np.float32)   # token scales over e^+-6: the split must be exact at every magnitude
+    dt = G.GGML_TO_DT[gt]
+    ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
+    Y = gemm_ws_gpu(W, X, out_f, in_f, dt)
+    assert np.isfinite(Y).all()
+    for t in range(T):
+        assert np.abs(Y[t] - ref[t]).max() <= tol_for(ref[t], in_f), (t, np.abs(Y[t] - ref[t]).max())
+    R = r.standard_normal((T, out_f)).astype(np.float32)
+    Y2 = gemm_ws_gpu(W, X, out_f, in_f, dt, resid=R)                                           # residual epilogue, in place
+    assert np.array_equal(Y2, (R + Y).astype(np.float32)) or np.abs(Y2 - (R + Y)).max() <= 1e-6 * np.abs(Y).max()
+
+
+def test_gemm_quant_bf16_full_size_and_rejections():
+    """8B gate/up-sized matrix (14336 x 4096: the 2-row-tile geometry with 112 workgroups) and what the BF16 path refuses."""
+    gt = G.GGML_Q8_0
+    r = rng(99)
+    out_f, in_f, T = 14336, 4096, 64
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    Y = gemm_ws_gpu(W, X, out_f, in_f, G.GGML_TO_DT[gt])
+    for t in (0, 31, 63):
+        ref = O.gemv(W, X[t], out_f, in_f, G.GGML_TO_DT[gt])
+        assert np.abs(Y[t] - ref).max() <= tol_for(ref, in_f)
+    Wd, Xd, Yd = DB.zeros(1 << 16), DB.zeros(1 << 16), DB.zeros(1 << 16)
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_Q5_K) == -1      # format outside the BF16 path: caller uses ntk_gemm_quant
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 10, 256, G.DT_Q8_0) == -2      # out_features not a multiple of 16
+
+
 @pytest.mark.parametrize("qname", sorted(QUANT))
 @pytest.mark.parametrize("off", [2, 6, 14])
 def test_gemm_quant_unaligned_weights_and_residual(qname, off):

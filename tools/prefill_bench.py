@@ -34,12 +34,18 @@ def main():
     ap.add_argument("--mix", default="Q8_0")
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-engine", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-matrix table")
     a = ap.parse_args()
     ops.init(0)
+    import ctypes as C
+    from ntransformer_amd import _lib
+    L = _lib.lib()
+    L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+    L.ntk_gemm_quant_ws.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     rng = np.random.default_rng(0)
     res = {"gemm": [], "engine": []}
     T = 16
-    for dname, gt in GT.items():
+    for dname, gt in ({} if a.no_kernels else GT).items():
         dt = G.GGML_TO_DT[gt]
         for sname, (out_f, in_f) in SHAPES.items():
             rb = G.row_bytes(gt, in_f)
@@ -47,6 +53,14 @@ def main():
             X = DB.from_numpy(rng.standard_normal((T, in_f)).astype(np.float32))
             Y = DB.zeros(T * out_f * 4)
             t_gemm = timed(lambda: ops.gemm_quant(Y, W, X, T, out_f, in_f, dt), 20)
+            if dname in ("Q8_0", "Q4_K", "Q6_K") and out_f % 16 == 0:   # BF16 matrix cores, 64 tokens per pass
+                X64 = DB.from_numpy(rng.standard_normal((64, in_f)).astype(np.float32))
+                Y64 = DB.zeros(64 * out_f * 4)
+                ws_n = int(L.ntk_gemm_quant_workspace_bytes(in_f, out_f))
+                ws = DB(ws_n)
+                t_bf = timed(lambda: L.ntk_gemm_quant_ws(Y64.ptr, W.ptr, X64.ptr, 64, out_f, in_f, int(dt), None, ws.ptr, ws_n, 0, None), 20)
+                print("%-5s %-12s bf16 gemm(64 tok) %8.1f us = %6.1f TFLOP/s (3 products each: %6.1f TFLOP/s on the matrix cores), %.2f us/token vs %.2f"
+                      % (dname, sname, t_bf * 1e6, 2.0 * 64 * out_f * in_f / t_bf / 1e12, 6.0 * 64 * out_f * in_f / t_bf / 1e12, t_bf * 1e6 / 64, t_gemm * 1e6 / 16), flush=True)
             def loop():
                 for t in range(T): ops.launch_gemv(Y.at(4 * t * out_f), W, X.at(4 * t * in_f), out_f, in_f, dt)
             t_loop = timed(loop, 5)
@@ -61,10 +75,11 @@ def main():
         eng = E.Engine()
         eng.load_synthetic(E.synth_spec("8b", a.mix), 4096)
         r = np.random.Generator(np.random.Philox(key=[20260925, 99]))
-        for T, modes in ((16, (1, 0)), (64, (1, 0)), (256, (1,)), (1024, (1,))):
+        for T, modes in ((16, (2, 1, 0)), (64, (2, 1, 0)), (256, (2, 1)), (1024, (2, 1))):
             prompt = [128000] + [int(t) for t in r.integers(0, 128000, T - 1)]
-            for batched in modes:
-                eng.set_option("batched_prefill", batched)
+            for batched in modes:   # 2: BF16 MFMA, 64 tokens per pass; 1: F32 MFMA, 16 per pass; 0: the reference's per-token loop
+                eng.set_option("batched_prefill", batched > 0)
+                eng.set_option("bf16_prefill", batched == 2)
                 eng.forward(prompt, 0)
                 t0 = time.perf_counter(); eng.forward(prompt, 0); dt_ = time.perf_counter() - t0
                 res["engine"].append({"mix": a.mix, "prompt_tokens": T, "batched": batched, "ms": round(dt_ * 1e3, 2), "tok_s": round(T / dt_, 1)})
