@@ -39,10 +39,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GB_TOK = 64;           // tokens per pass
-constexpr int GB_CH = 2;             // 32-column steps per LDS chunk
 constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
 constexpr int GB_STEP_BYTES = 3 * 4 * GB_PIECE;           // 12 KB of B operands per step
-constexpr int GB_CHUNK_BYTES = GB_CH * GB_STEP_BYTES;      // 24 KB
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {   // upper halves of two floats (exact for our small integers)
     return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
@@ -53,14 +51,14 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return *reinterpret_cast<const u16_a2*>(p); }
 
 // ---- pre-pass: X -> BF16 planes in operand order + per-step sums ----------------------------------------------------------
-// grid = in / 32 steps, block = 256 = 4 token blocks x 64 lanes
+// grid = in / 32 steps + 1 (a record of zeros), block = 256 = 4 token blocks x 64 lanes
 __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ X, int T, int in, u32x4* __restrict__ xb, float* __restrict__ xsum) {
     const int step = blockIdx.x, tb = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4, t = tb * 16 + j;
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = 0.0f;
-    if (t < T) {
+    if (t < T && step * 32 < in) {   // block in/32 writes the all-zero record that K ranges rounded up to whole trips read
         const float* row = X + (size_t)t * in + step * 32 + 4 * g;
         const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 16);
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
@@ -84,28 +82,35 @@ __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ 
     if (g == 0) xsum[(size_t)step * GB_TOK + t] = s;
 }
 
-// ---- per-format A operand: the 8 integer weights of (row, 32-column step, slot group g) as BF16 + the block's scales ------
-// load(): the raw dwords of the slot (issued GB_AD steps ahead of their use: the weights come from HBM); decode(): BF16 + scales
+// ---- per-format weight operand ---------------------------------------------------------------------------------------------
+// The raw GGUF rows travel HBM -> registers -> a per-wave LDS image in UNITS of whole blocks (Q8_0: 4 blocks = 136 B, K-quants:
+// one 256-column super-block), as 16-byte pieces of the 16-byte-aligned window that covers the unit: 16 bytes per lane and
+// NCH consecutive lanes per row, i.e. >= 144 contiguous bytes per row and request (a lane-per-slot gather of 4-byte pieces,
+// 16 bytes per row and request, tops out near 2.4 TB/s in the address coalescer).  Each 32-column step then reads its slot
+// (row i, columns {4g..4g+3, 16+4g..16+4g+3}) out of the image with 2-byte-aligned LDS dword reads.  STRIDE (bytes between row
+// images) = 4 x an odd number of dwords... chosen so that the 16 rows x 4 column groups of one read hit 64 different banks.
 struct AOp {
     u32x4 a;            // 8 BF16 integers
     float s0, s1;       // scale of the slot's low / high 4 columns (equal unless the format scales per 16 columns)
     float mn;           // K-quant minimum term factor (dmin * m), 0 otherwise
 };
+__device__ __forceinline__ uint32_t lds32(const uint8_t* p) { return *reinterpret_cast<const u32_a2*>(p); }   // 2-byte aligned LDS dword
+__device__ __forceinline__ uint32_t lds16(const uint8_t* p) { return *reinterpret_cast<const u16_a2*>(p); }
 template <int DT> struct DeqI;
 
 template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
     static constexpr int BW = 32, BB = 34;
+    static constexpr int SPU = 4, UB = 136, NCH = 10, STRIDE = 176;   // window: shift (0 or 8) + 136 <= 160
     static constexpr bool SPLIT16 = false, HAS_MIN = false;
-    struct Raw { uint32_t lo, hi, d; };
-    __device__ static Raw load(const uint8_t* row, int step, int g) {
-        const uint8_t* p = row + 34 * step;
-        return Raw{ld32(p + 2 + 4 * g), ld32(p + 18 + 4 * g), (uint32_t)ld16(p)};
-    }
-    __device__ static AOp decode(const Raw& r, int /*step*/) {
+    struct Hdr {};
+    __device__ static Hdr header(const uint8_t*) { return Hdr{}; }
+    // row = the row's image + the unit's shift, rowg = row + 4 g; j = step within the unit
+    __device__ static AOp step(const uint8_t* row, const uint8_t* rowg, const Hdr&, int j) {
+        const uint32_t lo = lds32(rowg + 34 * j + 2), hi = lds32(rowg + 34 * j + 18);
         AOp o;
-        o.a = u32x4{pack_bf16(sb2f(r.lo, 0), sb2f(r.lo, 1)), pack_bf16(sb2f(r.lo, 2), sb2f(r.lo, 3)),
-                    pack_bf16(sb2f(r.hi, 0), sb2f(r.hi, 1)), pack_bf16(sb2f(r.hi, 2), sb2f(r.hi, 3))};
-        o.s0 = o.s1 = h2f((uint16_t)r.d);
+        o.a = u32x4{pack_bf16(sb2f(lo, 0), sb2f(lo, 1)), pack_bf16(sb2f(lo, 2), sb2f(lo, 3)),
+                    pack_bf16(sb2f(hi, 0), sb2f(hi, 1)), pack_bf16(sb2f(hi, 2), sb2f(hi, 3))};
+        o.s0 = o.s1 = h2f((uint16_t)lds16(row + 34 * j));
         o.mn = 0.0f;
         return o;
     }
@@ -113,20 +118,17 @@ template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
 
 template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 packed 6-bit (scale, min); 128 bytes of nibbles
     static constexpr int BW = 256, BB = 144;
+    static constexpr int SPU = 8, UB = 144, NCH = 9, STRIDE = 144;     // rows are 16-byte aligned: no shift
     static constexpr bool SPLIT16 = false, HAS_MIN = true;
-    struct Raw { uint32_t h0, s0, s1, s2, lo, hi; };
-    __device__ static Raw load(const uint8_t* row, int step, int g) {
-        const uint8_t* p = row + 144 * (step >> 3);
-        const uint8_t* q = p + 16 + 32 * ((step & 7) >> 1);
-        return Raw{ld32(p), ld32(p + 4), ld32(p + 8), ld32(p + 12), ld32(q + 4 * g), ld32(q + 16 + 4 * g)};
-    }
-    __device__ static AOp decode(const Raw& r, int step) {
-        const int j = step & 7;
+    struct Hdr { u32x4 h; };   // d | dmin, 12 scale bytes
+    __device__ static Hdr header(const uint8_t* row) { return Hdr{*reinterpret_cast<const u32x4*>(row)}; }
+    __device__ static AOp step(const uint8_t* /*row*/, const uint8_t* rowg, const Hdr& hd, int j) {
         float sc, mn;
-        kq_scale_min(r.s0, r.s1, r.s2, j, sc, mn);                            // gemm.cu:206-222
-        const float d = h2f((uint16_t)(r.h0 & 0xFFFFu)), dmin = h2f((uint16_t)(r.h0 >> 16));
+        kq_scale_min(hd.h.y, hd.h.z, hd.h.w, j, sc, mn);                       // gemm.cu:206-222
+        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu)), dmin = h2f((uint16_t)(hd.h.x >> 16));
         const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
-        const uint32_t lo = (r.lo >> sh) & 0x0F0F0F0Fu, hi = (r.hi >> sh) & 0x0F0F0F0Fu;
+        const uint32_t lo = (lds32(rowg + 16 + 32 * (j >> 1)) >> sh) & 0x0F0F0F0Fu;
+        const uint32_t hi = (lds32(rowg + 32 + 32 * (j >> 1)) >> sh) & 0x0F0F0F0Fu;
         AOp o;
         o.a = u32x4{pack_bf16(ub2f(lo, 0), ub2f(lo, 1)), pack_bf16(ub2f(lo, 2), ub2f(lo, 3)),
                     pack_bf16(ub2f(hi, 0), ub2f(hi, 1)), pack_bf16(ub2f(hi, 2), ub2f(hi, 3))};
@@ -138,33 +140,33 @@ template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 pa
 
 template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], int8 scales[16], half d
     static constexpr int BW = 256, BB = 210;
+    static constexpr int SPU = 8, UB = 210, NCH = 14, STRIDE = 240;    // window: shift (even, <= 14) + 210 <= 224
     static constexpr bool SPLIT16 = true, HAS_MIN = false;
-    struct Raw { uint32_t l0, l1, h0, h1, scd; };
-    __device__ static Raw load(const uint8_t* row, int step, int g) {
-        const uint8_t* p = row + 210 * (step >> 3);
-        const int j = step & 7, hf = j >> 2, t = j & 3;
-        const uint8_t* ql = p + 64 * hf + 32 * (t & 1);
-        const uint8_t* qh = p + 128 + 32 * hf;
-        return Raw{ld32(ql + 4 * g), ld32(ql + 16 + 4 * g), ld32(qh + 4 * g), ld32(qh + 16 + 4 * g),
-                   (uint32_t)ld16(p + 192 + 8 * hf + 2 * t) | ((uint32_t)ld16(p + 208) << 16)};   // two int8 sub-scales | half d
-    }
-    __device__ static AOp decode(const Raw& r, int step) {
-        const int t = step & 3;
+    struct Hdr { float d; };
+    __device__ static Hdr header(const uint8_t* row) { return Hdr{h2f((uint16_t)lds16(row + 208))}; }
+    __device__ static AOp step(const uint8_t* row, const uint8_t* rowg, const Hdr& hd, int j) {
+        const int hf = j >> 2, t = j & 3;
+        const uint8_t* ql = rowg + 64 * hf + 32 * (t & 1);
+        const uint8_t* qh = rowg + 128 + 32 * hf;
         const int sl = 4 * (t >> 1), sh = 2 * t;
-        const uint32_t lo = ((r.l0 >> sl) & 0x0F0F0F0Fu) | (((r.h0 >> sh) & 0x03030303u) << 4);   // gemm.cu:421-459
-        const uint32_t hi = ((r.l1 >> sl) & 0x0F0F0F0Fu) | (((r.h1 >> sh) & 0x03030303u) << 4);
+        const uint32_t lo = ((lds32(ql) >> sl) & 0x0F0F0F0Fu) | (((lds32(qh) >> sh) & 0x03030303u) << 4);         // gemm.cu:421-459
+        const uint32_t hi = ((lds32(ql + 16) >> sl) & 0x0F0F0F0Fu) | (((lds32(qh + 16) >> sh) & 0x03030303u) << 4);
         AOp o;   // q - 32: exact small integers
         o.a = u32x4{pack_bf16(ub2f(lo, 0) - 32.0f, ub2f(lo, 1) - 32.0f), pack_bf16(ub2f(lo, 2) - 32.0f, ub2f(lo, 3) - 32.0f),
                     pack_bf16(ub2f(hi, 0) - 32.0f, ub2f(hi, 1) - 32.0f), pack_bf16(ub2f(hi, 2) - 32.0f, ub2f(hi, 3) - 32.0f)};
-        const float d = h2f((uint16_t)(r.scd >> 16));
-        o.s0 = d * (float)(int)(int8_t)(r.scd & 0xFF);
-        o.s1 = d * (float)(int)(int8_t)((r.scd >> 8) & 0xFF);
+        const uint32_t sc = lds16(row + 192 + 8 * hf + 2 * t);   // the two int8 sub-scales of the step's 16-column halves
+        o.s0 = hd.d * (float)(int)(int8_t)(sc & 0xFF);
+        o.s1 = hd.d * (float)(int)(int8_t)(sc >> 8);
         o.mn = 0.0f;
         return o;
     }
 };
 
-constexpr int GB_AD = 4;   // weight slots are requested this many steps ahead of the MFMAs that consume them (2 LDS chunks)
+constexpr int GB_NR = 2;      // weight units in flight per wave (register ring): 8 (Q8_0) / 16 (K-quants) steps ahead of the MFMAs
+constexpr int GB_SLOTS = 4;   // LDS ring of B-operand step records (12 KB each), filled by LDS-DMA GB_SLOTS - 1 steps ahead
+constexpr int GB_XS_OFF = GB_SLOTS * GB_STEP_BYTES;   // then [GB_SLOTS][64] floats: the steps' per-token sums of x (K-quant minimum)
+constexpr int GB_STAGE_OFF = GB_XS_OFF + GB_SLOTS * GB_TOK * 4;   // then the 4 waves' weight images
+template <int DT, int RT> constexpr int gb_lds_bytes() { return GB_STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE; }
 
 struct GemmBParams {
     const uint8_t* W;
@@ -174,162 +176,210 @@ struct GemmBParams {
     const float* resid;     // optional [T][out], may alias Y
     int T, out, in, steps;
     unsigned row_bytes;
+    unsigned w_last;        // out * row_bytes - 16: the last 16-byte piece of the matrix (requests past the end re-read it)
     int nsplit, steps_per_split;   // blockIdx.y = K split; nsplit > 1: partial sums go to `part` [split][T][out], summed by reduce_splits
     float* part;
 };
 
-// block = 256 threads = 4 waves; wave w of workgroup b: rows (4 b + w) * 16 RT ...
+// 16 B per lane, global -> LDS without passing through registers (gfx950 LDS-DMA, b128 form): lane l's 16 bytes land at
+// lds_dst + 16 l.  The compiler does not count these requests: the waits on them are explicit (vmcnt, in order).
+__device__ __forceinline__ void gb_dma16(uint32_t lds_dst, const uint8_t* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// block = 256 threads = 4 waves; wave w of workgroup b owns weight rows (4 b + w) * 16 RT ... + 16 RT and all 64 tokens.
+// MFMA roles: the activation planes are the A operand (M = 16 tokens), the weights the B operand (N = 16 weight rows), so the
+// accumulator of lane (i, g) holds weight row i for tokens 4 g + e -- the row's scale is the one this lane decoded (no
+// cross-lane traffic), and the step's sum of x comes as one float4 from LDS.
+// One loop trip = GB_NR units of SPU steps, straight-line (no exits inside: the s_waitcnt counts are exact).  Per step s:
+//   wait until the DMA of step s has landed | barrier | at a unit's first step: the unit's raw rows go from their ring registers
+//   to the wave's LDS image and the ring slot is re-requested GB_NR units ahead | read + decode the step's weight slot | DMA step
+//   s + GB_SLOTS - 1 into the slot step s - 1 just vacated | 12 RT MFMAs.
 template <int DT, int RT>
 __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBParams p) {
     using D = DeqI<DT>;
+    constexpr int SPU = D::SPU, NCH = D::NCH, STRIDE = D::STRIDE;
+    constexpr int ROWS = 16 * RT, PIECES = ROWS * NCH, NLD = (PIECES + 63) / 64;   // 16-byte pieces of a unit; requests per lane
+    static_assert((GB_NR * SPU) % GB_SLOTS == 0, "a trip must cover whole turns of the B ring");
     extern __shared__ __attribute__((aligned(16))) uint8_t gb_lds[];
-    uint8_t* bbuf = gb_lds;                                             // [2][GB_CHUNK_BYTES]
-    float* xs = reinterpret_cast<float*>(gb_lds + 2 * GB_CHUNK_BYTES);  // [2][GB_CH][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int row0 = ((int)blockIdx.x * 4 + wave) * 16 * RT;
-    const int ntb = (p.T + 15) >> 4;                                    // token blocks in use (wave-uniform)
-    const uint8_t* arow[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) arow[rt] = p.W + (size_t)min(row0 + rt * 16 + i, p.out - 1) * p.row_bytes;
+    const int row0 = ((int)blockIdx.x * 4 + wave) * ROWS;
     f32x4 acc[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) acc[rt][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // this workgroup's K range (split-K: blockIdx.y), in steps of 32 columns; chunks of GB_CH steps counted from its start
+    // this workgroup's K range (split-K: blockIdx.y), in steps of 32 columns; whole trips of GB_NR * SPU steps
     const int step_lo = (int)blockIdx.y * p.steps_per_split, step_hi = min(p.steps, step_lo + p.steps_per_split);
     const int nsteps = step_hi - step_lo;
-    const int nchunks = (nsteps + GB_CH - 1) / GB_CH;
-    // workgroup-cooperative B staging: a chunk is 24 KB contiguous in xb = 6 x 16 B per thread.  Two register sets: the chunk
-    // after next is requested while the next one waits in registers for its LDS buffer (the planes come from L2, ~1 us away:
-    // one chunk of MFMA work does not cover that)
-    u32x4 bq[2][6];
-    float xsq[2] = {0.0f, 0.0f};
-    auto fetch_chunk = [&](int c, auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-        const u32x4* src = reinterpret_cast<const u32x4*>(p.xb + ((size_t)step_lo / GB_CH + c) * GB_CHUNK_BYTES);
-        const int valid = (c < nchunks ? min(GB_CH, nsteps - c * GB_CH) : 0) * (GB_STEP_BYTES / 16);   // 16-byte pieces that exist
-#pragma unroll
-        for (int k = 0; k < 6; ++k) bq[SET][k] = (tid + 256 * k < valid) ? src[tid + 256 * k] : u32x4{0, 0, 0, 0};
-        if (D::HAS_MIN && tid < GB_CH * 64) xsq[SET] = (tid + 0 < valid / (GB_STEP_BYTES / 16) * 64) ? p.xsum[((size_t)step_lo + (size_t)c * GB_CH) * 64 + tid] : 0.0f;
-    };
-    auto store_chunk = [&](int buf, auto set_tag) {
-        constexpr int SET = decltype(set_tag)::value;
-        u32x4* dst = reinterpret_cast<u32x4*>(bbuf + (size_t)buf * GB_CHUNK_BYTES);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dst[tid + 256 * k] = bq[SET][k];
-        if (D::HAS_MIN && tid < GB_CH * 64) xs[buf * GB_CH * 64 + tid] = xsq[SET];
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    fetch_chunk(0, S0{});
-    store_chunk(0, S0{});
-    fetch_chunk(1, S1{});
-    __syncthreads();
+    const int unit_lo = step_lo / SPU, nunits = (nsteps + SPU - 1) / SPU;
 
-    typename D::Raw raw[GB_AD][RT];
+    // weight pieces of this lane: piece q = 64 n + lane of the wave's unit -> row q / NCH, 16-byte piece q % NCH of the 16-byte
+    // aligned window that covers the row's unit (rows need not be 16-byte aligned: every row has its own window start and shift)
+    uint8_t* stage = gb_lds + GB_STAGE_OFF + (size_t)wave * (ROWS * STRIDE);
+    uint32_t w_row[NLD], w_c16[NLD], s_off[NLD];
 #pragma unroll
-    for (int u = 0; u < GB_AD; ++u)
+    for (int n = 0; n < NLD; ++n) {
+        const int q = min(64 * n + lane, PIECES - 1), r = q / NCH, c = q - r * NCH;
+        w_row[n] = (uint32_t)min(row0 + r, p.out - 1) * p.row_bytes;
+        w_c16[n] = 16u * c;
+        s_off[n] = (uint32_t)(r * STRIDE + 16 * c);
+    }
+    u32x4 ring[GB_NR][NLD];
+    auto load_unit = [&](int k, int urel) {   // unit `urel` of this split (past the end: the last one again, multiplied by zeros)
+        const uint32_t uoff = (uint32_t)(unit_lo + min(urel, nunits - 1)) * D::UB;
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) raw[u][rt] = D::load(arow[rt], min(step_lo + u, step_hi - 1), g);
+        for (int n = 0; n < NLD; ++n)
+            ring[k][n] = *reinterpret_cast<const u32x4*>(p.W + min(((w_row[n] + uoff) & ~15u) + w_c16[n], p.w_last));
+    };
+    auto stage_unit = [&](int k) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) *reinterpret_cast<u32x4*>(stage + s_off[n]) = ring[k][n];
+    };
 
-    // steps in groups of GB_AD (= two LDS chunks): slot u of the register ring is consumed at step 4 grp + u and refilled with
-    // the weights of step 4 (grp + 1) + u -- four steps (~one HBM round trip of MFMA work) ahead
-    for (int grp = 0; grp * GB_AD < nsteps; ++grp) {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)gb_lds;   // generic -> LDS address: the low 32 bits
+    const uint8_t* xb_thread = p.xb + (size_t)tid * 16;  // this thread's 16-byte pieces: tid, tid + 256, tid + 512 of a step record
+    constexpr int ND = D::HAS_MIN ? 4 : 3;               // DMA requests per step and wave
+    auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros)
+        const int s = rel < nsteps ? step_lo + rel : p.steps;
+        const uint8_t* src = xb_thread + (size_t)s * GB_STEP_BYTES;
+        const uint32_t dst = lds0 + (uint32_t)slot * GB_STEP_BYTES + (uint32_t)wave * 1024u;
 #pragma unroll
-        for (int u = 0; u < GB_AD; ++u) {
-            const int rel = grp * GB_AD + u;                           // step relative to the split's start
-            if (rel >= nsteps) break;
-            const int step = step_lo + rel;
-            const int c = rel / GB_CH, sc = rel % GB_CH, buf = c & 1;   // (GB_AD = 2 GB_CH: chunk parity == u / GB_CH, compile time)
-            if (sc == 0) {                                             // the chunk after next: requested now, into the set chunk c came from
-                if (u / GB_CH == 0) fetch_chunk(c + 2, S0{}); else fetch_chunk(c + 2, S1{});
-            }
-            AOp a[RT];
+        for (int k = 0; k < 3; ++k) gb_dma16(__builtin_amdgcn_readfirstlane(dst + 4096u * k), src + 4096 * k);
+        if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave
+            gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + GB_XS_OFF + (uint32_t)slot * 256u + (uint32_t)wave * 64u),
+                     reinterpret_cast<const uint8_t*>(p.xsum + (size_t)s * GB_TOK + wave * 16 + lane * 4));
+    };
+    // Prologue in the steady state's request order: the weight ring, then the DMAs of steps 0 .. GB_SLOTS - 2
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                a[rt] = D::decode(raw[u][rt], step);
-                raw[u][rt] = D::load(arow[rt], min(step + GB_AD, step_hi - 1), g);
-            }
-            const u32x4* bs = reinterpret_cast<const u32x4*>(bbuf + (size_t)buf * GB_CHUNK_BYTES + (size_t)sc * GB_STEP_BYTES);
-            // scales of the 4 accumulator rows this lane holds (rows 4g + e of the tile), from the lanes that decoded those rows
-            float s0[RT][4], s1[RT][4], mn[RT][4];
+    for (int k = 0; k < GB_NR; ++k) load_unit(k, k);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+    for (int s = 0; s < GB_SLOTS - 1; ++s) dma_step(s, s);
+
+    const uint8_t* img[RT];      // this lane's row images (row rt*16 + i of the wave's tile)
+    uint32_t my_row[RT];         // and the rows' byte offsets in W: the unit's bytes start `(my_row + unit offset) & 15` into the image
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s0[rt][e] = __shfl(a[rt].s0, 4 * g + e, 64);
-                    if (D::SPLIT16) s1[rt][e] = __shfl(a[rt].s1, 4 * g + e, 64);
-                    if (D::HAS_MIN) mn[rt][e] = __shfl(a[rt].mn, 4 * g + e, 64);
+    for (int rt = 0; rt < RT; ++rt) {
+        img[rt] = stage + (rt * 16 + i) * STRIDE;
+        my_row[rt] = (uint32_t)min(row0 + rt * 16 + i, p.out - 1) * p.row_bytes;
+    }
+    typename D::Hdr hdr[RT];
+    const uint8_t* cur[RT];      // img + the current unit's shift
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) cur[rt] = img[rt];
+
+    for (int trip = 0; trip * (GB_NR * SPU) < nsteps; ++trip) {
+#pragma unroll
+        for (int k = 0; k < GB_NR; ++k) {
+#pragma unroll
+            for (int j = 0; j < SPU; ++j) {
+                const int rel = (trip * GB_NR + k) * SPU + j;        // step relative to the split's start
+                const int slot = (k * SPU + j) % GB_SLOTS;           // its B ring slot (compile time)
+                // requests younger than the DMA of this step: the DMAs of the two steps since, and the unit's weight requests if
+                // they went out in one of those two steps (j = 1, 2; at j = 0 they precede the DMA inside step s - SPU ... )
+                if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND + NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND) : "memory");
+                if (j == 0) {
+                    const int unit = trip * GB_NR + k;
+                    stage_unit(k);
+                    load_unit(k, unit + GB_NR);
+                    const uint32_t uoff = (uint32_t)(unit_lo + min(unit, nunits - 1)) * D::UB;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        cur[rt] = img[rt] + ((my_row[rt] + uoff) & 15u);
+                        hdr[rt] = D::header(cur[rt]);
+                    }
                 }
+                AOp a[RT];
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb) {
-                if (tb >= ntb) break;
-                const u32x4 b0 = bs[(0 * 4 + tb) * 64 + lane], b1 = bs[(1 * 4 + tb) * 64 + lane], b2 = bs[(2 * 4 + tb) * 64 + lane];
-                const float xsum_t = D::HAS_MIN ? xs[(buf * GB_CH + sc) * 64 + tb * 16 + i] : 0.0f;   // token = this lane's column
+                for (int rt = 0; rt < RT; ++rt) a[rt] = D::step(cur[rt], cur[rt] + 4 * g, hdr[rt], j);
+                dma_step(rel + GB_SLOTS - 1, (slot + GB_SLOTS - 1) % GB_SLOTS);
+                __builtin_amdgcn_sched_barrier(0);   // the requests above stay above: they are what the next steps hide
+
+                const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * GB_STEP_BYTES);
+                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + GB_XS_OFF + (size_t)slot * 256);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) {
-                    if constexpr (D::SPLIT16) {   // two 16-column groups with their own scale: K = 16 MFMAs on the operand halves
-                        const s16x4 al = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.x | ((uint64_t)a[rt].a.y << 32));
-                        const s16x4 ah = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.z | ((uint64_t)a[rt].a.w << 32));
-                        f32x4 cl = {0.0f, 0.0f, 0.0f, 0.0f}, ch = {0.0f, 0.0f, 0.0f, 0.0f};
-                        const u32x4 bb[3] = {b0, b1, b2};
+                for (int tb = 0; tb < 4; ++tb) {
+                    const u32x4 b0 = bs[(0 * 4 + tb) * 64 + lane], b1 = bs[(1 * 4 + tb) * 64 + lane], b2 = bs[(2 * 4 + tb) * 64 + lane];
+                    f32x4 xsum_t = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (D::HAS_MIN) xsum_t = xs[tb * 4 + g];   // tokens tb*16 + 4g + e: this lane's accumulator elements
 #pragma unroll
-                        for (int pl = 0; pl < 3; ++pl) {
-                            const s16x4 bl = __builtin_bit_cast(s16x4, (uint64_t)bb[pl].x | ((uint64_t)bb[pl].y << 32));
-                            const s16x4 bh = __builtin_bit_cast(s16x4, (uint64_t)bb[pl].z | ((uint64_t)bb[pl].w << 32));
-                            cl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bl, cl, 0, 0, 0);
-                            ch = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh, ch, 0, 0, 0);
-                        }
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if constexpr (D::SPLIT16) {   // two 16-column groups with their own scale: K = 16 MFMAs on the operand halves
+                            const s16x4 wl = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.x | ((uint64_t)a[rt].a.y << 32));
+                            const s16x4 wh = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.z | ((uint64_t)a[rt].a.w << 32));
+                            f32x4 cl = {0.0f, 0.0f, 0.0f, 0.0f}, ch = {0.0f, 0.0f, 0.0f, 0.0f};
+                            const u32x4 bb[3] = {b0, b1, b2};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[rt][tb][e] = fmaf(s1[rt][e], ch[e], fmaf(s0[rt][e], cl[e], acc[rt][tb][e]));
-                    } else {
-                        const bf16x8 av = __builtin_bit_cast(bf16x8, a[rt].a);
-                        f32x4 cc = {0.0f, 0.0f, 0.0f, 0.0f};
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b0), cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b1), cc, 0, 0, 0);
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, b2), cc, 0, 0, 0);
+                            for (int pl = 0; pl < 3; ++pl) {
+                                const s16x4 xl = __builtin_bit_cast(s16x4, (uint64_t)bb[pl].x | ((uint64_t)bb[pl].y << 32));
+                                const s16x4 xh = __builtin_bit_cast(s16x4, (uint64_t)bb[pl].z | ((uint64_t)bb[pl].w << 32));
+                                cl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xl, wl, cl, 0, 0, 0);
+                                ch = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh, wh, ch, 0, 0, 0);
+                            }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float v = fmaf(s0[rt][e], cc[e], acc[rt][tb][e]);
-                            if (D::HAS_MIN) v = fmaf(-mn[rt][e], xsum_t, v);   // - dmin * m * sum x   (gemm.cu:232-244)
-                            acc[rt][tb][e] = v;
+                            for (int e = 0; e < 4; ++e) acc[rt][tb][e] = fmaf(a[rt].s1, ch[e], fmaf(a[rt].s0, cl[e], acc[rt][tb][e]));
+                        } else {
+                            const bf16x8 wv = __builtin_bit_cast(bf16x8, a[rt].a);
+                            f32x4 cc = {0.0f, 0.0f, 0.0f, 0.0f};
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0), wv, cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1), wv, cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b2), wv, cc, 0, 0, 0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = fmaf(a[rt].s0, cc[e], acc[rt][tb][e]);
+                                if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
+                                acc[rt][tb][e] = v;
+                            }
                         }
                     }
                 }
-            }
-            if (sc == GB_CH - 1 || rel + 1 == nsteps) {
-                // buffer buf^1 was last read during chunk c-1, which every wave left through the barrier below: free to refill
-                // with chunk c+1, which has been waiting in the other register set since the start of chunk c-1
-                if (c + 1 < nchunks) { if (u / GB_CH == 0) store_chunk(buf ^ 1, S1{}); else store_chunk(buf ^ 1, S0{}); }
-                __syncthreads();
+                // the accumulators are complete HERE: without this anchor the instruction selector parks every step's scale-FMAs at
+                // the end of the trip (they have no memory dependence) and the products of 16 steps sit in registers until then
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) asm volatile("" : "+v"(acc[rt][tb]));
+                __builtin_amdgcn_sched_barrier(0);   // no motion of memory requests across steps (the waits count them in order)
             }
         }
     }
-    // ---- epilogue: accumulator element e of lane (i = token column, g) is row 4g + e of the tile -----------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be in flight towards LDS when the workgroup retires
+    // ---- epilogue: accumulator element e of lane (i = weight row of the tile, g) is token tb*16 + 4g + e ------------------
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        const int r = row0 + rt * 16 + 4 * g;
+        const int r = row0 + rt * 16 + i;
         if (r >= p.out) continue;
+        if (p.nsplit > 1) {   // K split: this workgroup's partial sums, combined (fixed order) by reduce_splits_kernel
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
-            const int t = tb * 16 + i;
-            if (t >= p.T) continue;
-            float4 v = {acc[rt][tb][0], acc[rt][tb][1], acc[rt][tb][2], acc[rt][tb][3]};
-            if (p.nsplit > 1) {   // K split: this workgroup's partial sums, combined (fixed order) by reduce_splits_kernel
-                *reinterpret_cast<float4*>(p.part + ((size_t)blockIdx.y * GB_TOK + t) * p.out + r) = v;
-                continue;
-            }
-            float* y = p.Y + (size_t)t * p.out + r;
-            if (p.resid) {
-                const float4 rs = *reinterpret_cast<const float4*>(p.resid + (size_t)t * p.out + r);
-                v.x += rs.x; v.y += rs.y; v.z += rs.z; v.w += rs.w;
-            }
-            *reinterpret_cast<float4*>(y) = v;
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = tb * 16 + 4 * g + e;
+                    if (t < p.T) p.part[((size_t)blockIdx.y * GB_TOK + t) * p.out + r] = acc[rt][tb][e];
+                }
+            continue;
         }
+        float rs[4][4];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = tb * 16 + 4 * g + e;
+                rs[tb][e] = (p.resid && t < p.T) ? p.resid[(size_t)t * p.out + r] : 0.0f;
+            }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = tb * 16 + 4 * g + e;
+                if (t < p.T) p.Y[(size_t)t * p.out + r] = acc[rt][tb][e] + rs[tb][e];
+            }
     }
 }
 
@@ -351,41 +401,50 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(float* __restrict__ 
     *reinterpret_cast<float4*>(Y + idx) = v;
 }
 
-static size_t ws_planes_bytes(int in) { return (size_t)(in / 32) * GB_STEP_BYTES + (size_t)(in / 32) * GB_TOK * sizeof(float) + 256; }
+static size_t ws_planes_bytes(int in) { return (size_t)(in / 32 + 1) * GB_STEP_BYTES + (size_t)(in / 32 + 1) * GB_TOK * sizeof(float) + 256; }   // + the record of zeros
 constexpr int GB_MAX_SPLIT = 8;
 
 template <int DT>
 static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int out, int in, const float* resid, void* ws, int reuse_x,
                             hipStream_t st) {
     using D = DeqI<DT>;
-    if (in % D::BW != 0 || in % 32 != 0 || out % 16 != 0) return NTK_E_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(W) & 1) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
+    constexpr int TRIP = GB_NR * D::SPU;   // steps per loop trip: K ranges are whole trips
+    if (in % D::BW != 0 || out % 16 != 0) return NTK_E_SHAPE;
+    const size_t row_bytes = (size_t)in / D::BW * D::BB;
+    if ((size_t)out * row_bytes > 0xFFFFFF00ull) return NTK_E_SHAPE;   // 32-bit piece offsets
+    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
         (resid && (reinterpret_cast<uintptr_t>(resid) & 15)))
         return NTK_E_ALIGN;
     GemmBParams p{};
     p.W = static_cast<const uint8_t*>(W);
     p.T = T; p.out = out; p.in = in; p.steps = in / 32;
-    p.row_bytes = (unsigned)((size_t)in / D::BW * D::BB);
+    p.row_bytes = (unsigned)row_bytes;
+    p.w_last = (unsigned)((size_t)out * row_bytes - 16);
     uint8_t* wsb = static_cast<uint8_t*>(ws);
     p.xb = wsb;
-    p.xsum = reinterpret_cast<const float*>(wsb + (size_t)p.steps * GB_STEP_BYTES);
+    p.xsum = reinterpret_cast<const float*>(wsb + (size_t)(p.steps + 1) * GB_STEP_BYTES);
     p.part = reinterpret_cast<float*>(wsb + (ws_planes_bytes(in) + 255) / 256 * 256);
     p.Y = Y; p.resid = resid;
     if (!reuse_x)
-        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.xsum));
-    const size_t lds = (size_t)2 * GB_CHUNK_BYTES + (size_t)2 * GB_CH * 64 * sizeof(float);
-    // 32 rows per wave when that still leaves >= 256 workgroups (the B operands are then read from LDS half as often per MFMA)
-    const bool rt2 = out >= 256 * 128 / 2;
-    const int row_wgs = rt2 ? (out + 127) / 128 : (out + 63) / 64;
-    // K split: small matrices leave most CUs idle and a workgroup walks its K range serially (latency-bound): split K until the
-    // grid has ~2 workgroups per CU, in whole groups of GB_AD steps
+        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 1), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.xsum));
+    // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
+    // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) until the grid has about two workgroups per CU.
+    static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
+    static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 512; }();
+    int rt = out >= 2048 ? 2 : 1;
+    if (force_rt == 1 || force_rt == 2) rt = force_rt;
+    const int row_wgs = (out + 64 * rt - 1) / (64 * rt);
+    const int trips = (p.steps + TRIP - 1) / TRIP;
     int nsplit = 1;
-    while (nsplit < GB_MAX_SPLIT && row_wgs * nsplit < 512 && p.steps / (nsplit * 2) >= 4 * GB_AD) nsplit *= 2;
+    while (nsplit < GB_MAX_SPLIT && row_wgs * nsplit < want_wgs && trips / (nsplit * 2) >= 1) nsplit *= 2;
+    const int tps = (trips + nsplit - 1) / nsplit;   // trips per split
+    nsplit = (trips + tps - 1) / tps;                // no empty split
     p.nsplit = nsplit;
-    p.steps_per_split = ((p.steps + nsplit - 1) / nsplit + GB_AD - 1) / GB_AD * GB_AD;
+    p.steps_per_split = tps * TRIP;
     const dim3 grid(row_wgs, nsplit);
-    if (rt2) hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 2>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 1>), grid, dim3(256), lds, st, p);
+    const size_t lds2 = gb_lds_bytes<DT, 2>(), lds1 = gb_lds_bytes<DT, 1>();
+    if (rt == 2) hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 2>), grid, dim3(256), lds2, st, p);
+    else hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 1>), grid, dim3(256), lds1, st, p);
     if (nsplit > 1) {
         const size_t n4 = ((size_t)T * out + 3) / 4;
         hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, Y, (const float*)p.part, resid, T, out, nsplit);

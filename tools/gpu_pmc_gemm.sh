@@ -1,20 +1,29 @@
 #!/bin/bash
-# SQ counters of the batched prompt GEMM (where do the waves wait?) -- PMC pass, kernel-trace only.
+# SQ counters of the BF16 prompt GEMM (gemm_quant_bf16_kernel): what do its waves wait on?  (PMC passes, kernel-trace only)
 TAG=${1:-pmcgemm}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS --output-format csv -d $R/$OUT/pmc -o g -- python $R/tools/prefill_bench.py --no-engine > $R/$OUT/run.log 2> $R/$OUT/run.err ); echo "exit $?"
-F=$(ls $OUT/pmc/*counter_collection.csv | head -1)
-python - "$F" <<'PY'
-import csv, sys, collections
+pass() {  # name counters...
+  local n=$1; shift
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o g -- python $R/tools/prefill_bench.py --no-engine --bf16-only > $R/$OUT/$n.log 2> $R/$OUT/$n.err ); echo "pass $n exit $?"
+}
+pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS
+pass b SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU
+python - $OUT <<'PY' | tee $OUT/summary.txt
+import csv, sys, collections, re, glob
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(sys.argv[1])):
-    k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-    if 'gemm_quant' not in k: continue
-    acc[(k, r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
-for (k, g), c in sorted(acc.items()):
+for f in glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if 'gemm_quant_bf16' not in k: continue
+        m = re.search(r'gemm_quant_bf16_kernel<(\d+), *(\d+)', k)
+        acc[(m.group(1), m.group(2), r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+names = {'2': 'Q8_0', '4': 'Q4_K', '5': 'Q6_K'}
+for (k, rt, g), c in sorted(acc.items()):
     m = {n: sum(v) / len(v) for n, v in c.items()}
     wc = m.get('SQ_WAVE_CYCLES', 1)
-    print(k[-40:], 'grid', g, 'n', len(c['SQ_WAVE_CYCLES']), ' '.join('%s=%.3g' % (n.replace('SQ_', ''), v) for n, v in sorted(m.items())),
-          '| wait_any %.0f%% wait_inst %.0f%% active %.0f%% mfma_busy/busy %.0f%%' % (100 * m.get('SQ_WAIT_ANY', 0) / wc, 100 * m.get('SQ_WAIT_INST_ANY', 0) / wc,
-           100 * m.get('SQ_ACTIVE_INST_ANY', 0) / wc, 100 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(m.get('SQ_BUSY_CYCLES', 1), 1)))
+    print('%-5s RT %s grid %-8s' % (names.get(k, k), rt, g), ' '.join('%s=%.3g' % (n.replace('SQ_', ''), v) for n, v in sorted(m.items())))
+    print('      per wave-cycle: wait_any %.0f%% wait_inst %.0f%% (lds %.0f%%) active %.0f%% (valu %.0f%% lds %.0f%%) mfma_busy/busy %.0f%% bank_conflict/lds_active %.0f%%' % (
+        100 * m.get('SQ_WAIT_ANY', 0) / wc, 100 * m.get('SQ_WAIT_INST_ANY', 0) / wc, 100 * m.get('SQ_WAIT_INST_LDS', 0) / wc,
+        100 * m.get('SQ_ACTIVE_INST_ANY', 0) / wc, 100 * m.get('SQ_ACTIVE_INST_VALU', 0) / wc, 100 * m.get('SQ_ACTIVE_INST_LDS', 0) / wc,
+        100 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, m.get('SQ_BUSY_CYCLES', 1)), 100 * m.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, m.get('SQ_LDS_IDX_ACTIVE', 1))))
 PY
-rm -rf $OUT/pmc
+rm -rf $OUT/a $OUT/b

@@ -1,5 +1,7 @@
 #!/bin/bash
-timeout 300 python -m pytest tests/test_hip_kernels.py -q -x -k "gemm_quant_bf16" 2>&1 | tail -4
-timeout 300 python -m pytest tests/test_engine_gpu.py -q -x -k "batched_prefill or logits_match_reference or 8b_q4_k_m or 70b_width" 2>&1 | tail -3
-timeout 300 python tools/prefill_bench.py --no-engine 2>&1 | grep "bf16" | head -18
-timeout 300 python tools/prefill_bench.py --no-kernels 2>&1 | grep "prompt of" | tail -8
+timeout 600 python -m pytest tests/test_hip_kernels.py -q -x -k "gemm_quant_bf16" 2>&1 | tail -5
+for cfg in "0 512" "1 512" "2 256"; do set -- $cfg
+  echo "== RT=$1 WGS=$2"
+  NTK_GEMM_RT=$1 NTK_GEMM_WGS=$2 timeout 300 python tools/prefill_bench.py --no-engine --bf16-only 2>&1 | grep "bf16" | awk '{print $1, $2, $6, $7}' | tr '\n' ';'; echo
+done
+timeout 300 python tools/prefill_bench.py --no-kernels 2>&1 | grep "prompt of" | grep "=2" | tail -4

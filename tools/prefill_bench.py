@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-engine", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-matrix table")
+    ap.add_argument("--mixes", default="Q8_0,Q4_K,Q6_K", help="per-matrix table: weight formats")
+    ap.add_argument("--bf16-only", action="store_true", help="per-matrix table: only the BF16 GEMM launches (profiling)")
     a = ap.parse_args()
     ops.init(0)
     import ctypes as C
@@ -45,14 +47,14 @@ def main():
     rng = np.random.default_rng(0)
     res = {"gemm": [], "engine": []}
     T = 16
-    for dname, gt in ({} if a.no_kernels else GT).items():
+    for dname, gt in ({} if a.no_kernels else {k: v for k, v in GT.items() if k in a.mixes.split(',')}).items():
         dt = G.GGML_TO_DT[gt]
         for sname, (out_f, in_f) in SHAPES.items():
             rb = G.row_bytes(gt, in_f)
             W = DB.from_numpy(rng.integers(0, 60, out_f * rb, dtype=np.uint8))
             X = DB.from_numpy(rng.standard_normal((T, in_f)).astype(np.float32))
             Y = DB.zeros(T * out_f * 4)
-            t_gemm = timed(lambda: ops.gemm_quant(Y, W, X, T, out_f, in_f, dt), 20)
+            t_gemm = 0.0 if a.bf16_only else timed(lambda: ops.gemm_quant(Y, W, X, T, out_f, in_f, dt), 20)
             if dname in ("Q8_0", "Q4_K", "Q6_K") and out_f % 16 == 0:   # BF16 matrix cores, 64 tokens per pass
                 X64 = DB.from_numpy(rng.standard_normal((64, in_f)).astype(np.float32))
                 Y64 = DB.zeros(64 * out_f * 4)
@@ -61,6 +63,7 @@ def main():
                 t_bf = timed(lambda: L.ntk_gemm_quant_ws(Y64.ptr, W.ptr, X64.ptr, 64, out_f, in_f, int(dt), None, ws.ptr, ws_n, 0, None), 20)
                 print("%-5s %-12s bf16 gemm(64 tok) %8.1f us = %6.1f TFLOP/s (3 products each: %6.1f TFLOP/s on the matrix cores), %.2f us/token vs %.2f"
                       % (dname, sname, t_bf * 1e6, 2.0 * 64 * out_f * in_f / t_bf / 1e12, 6.0 * 64 * out_f * in_f / t_bf / 1e12, t_bf * 1e6 / 64, t_gemm * 1e6 / 16), flush=True)
+            if a.bf16_only: continue
             def loop():
                 for t in range(T): ops.launch_gemv(Y.at(4 * t * out_f), W, X.at(4 * t * in_f), out_f, in_f, dt)
             t_loop = timed(loop, 5)
