@@ -39,6 +39,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GB_TOK = 64;           // tokens per pass
+constexpr int GB_MAX_SPLIT = 8;     // K splits x token chunks of one launch never exceed this (size of the partial-sum area)
+constexpr int GB_MAX_CHUNKS = 4;    // 64-token chunks per launch
 constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
 constexpr int GB_STEP_BYTES = 3 * 4 * GB_PIECE;           // 12 KB of B operands per step
 
@@ -51,10 +53,16 @@ __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret
 __device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return *reinterpret_cast<const u16_a2*>(p); }
 
 // ---- pre-pass: X -> BF16 planes in operand order + per-step sums ----------------------------------------------------------
-// grid = in / 32 steps + 1 (a record of zeros), block = 256 = 4 token blocks x 64 lanes
-__global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ X, int T, int in, u32x4* __restrict__ xb, float* __restrict__ xsum) {
+// grid = (in / 32 steps + 1 (a record of zeros), 64-token chunks), block = 256 = 4 token blocks x 64 lanes
+__global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ X, int T, int in, u32x4* __restrict__ xb, float* __restrict__ xsum,
+                                                      size_t chunk_bytes) {
     const int step = blockIdx.x, tb = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4, t = tb * 16 + j;
+    // blockIdx.y = 64-token chunk: its tokens, its planes
+    X += (size_t)blockIdx.y * GB_TOK * in;
+    T = min(GB_TOK, T - (int)blockIdx.y * GB_TOK);
+    xb = reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(xb) + blockIdx.y * chunk_bytes);
+    xsum = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(xsum) + blockIdx.y * chunk_bytes);
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = 0.0f;
@@ -174,18 +182,26 @@ struct GemmBParams {
     const float* xsum;      // [steps][64]
     float* Y;               // [T][out]
     const float* resid;     // optional [T][out], may alias Y
-    int T, out, in, steps;
+    int T, out, in, steps;  // T = tokens of the launch (<= 64 chunks)
     unsigned row_bytes;
     unsigned w_last;        // out * row_bytes - 16: the last 16-byte piece of the matrix (requests past the end re-read it)
     int nsplit, steps_per_split;   // blockIdx.y = K split; nsplit > 1: partial sums go to `part` [split][T][out], summed by reduce_splits
     float* part;
+    int chunks, row_wgs;    // 64-token chunks of this launch (blockIdx.x enumerates (row tile, chunk), see below); row tiles
+    size_t chunk_bytes;     // between the planes (and sums) of consecutive chunks
 };
 
 // 16 B per lane, global -> LDS without passing through registers (gfx950 LDS-DMA, b128 form): lane l's 16 bytes land at
-// lds_dst + 16 l.  The compiler does not count these requests: the waits on them are explicit (vmcnt, in order).
+// M0 + imm + 16 l, read from gsrc + imm.  The compiler does not count these requests: the waits on them are explicit (vmcnt).
 __device__ __forceinline__ void gb_dma16(uint32_t lds_dst, const uint8_t* gsrc) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void gb_dma16x3(uint32_t lds_dst, const uint8_t* gsrc) {   // 3 KB per wave: +0, +1024, +2048 on both sides
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
@@ -207,7 +223,14 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int row0 = ((int)blockIdx.x * 4 + wave) * ROWS;
+    // blockIdx.x -> (row tile, token chunk).  Workgroups go to the 8 XCDs round-robin; the `chunks` workgroups that share a row
+    // tile's weights get ids 8 apart (same XCD, same L2, dispatched back to back): id = 8 * (chunks * (tile / 8) + chunk) + tile % 8
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int chunk = within % p.chunks, tile = (within / p.chunks) * 8 + xcd;
+    if (tile >= p.row_wgs) return;   // row tiles are padded to a multiple of 8
+    const int Tc = min(GB_TOK, p.T - chunk * GB_TOK);
+    const int row0 = (tile * 4 + wave) * ROWS;
     f32x4 acc[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -243,24 +266,16 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
     };
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)gb_lds;   // generic -> LDS address: the low 32 bits
-    const uint8_t* xb_thread = p.xb + (size_t)tid * 16;  // this thread's 16-byte pieces: tid, tid + 256, tid + 512 of a step record
+    const uint8_t* xb_thread = p.xb + (size_t)chunk * p.chunk_bytes + (size_t)wave * 3072 + (size_t)lane * 16;   // wave w copies bytes [3072 w, 3072 w + 3072) of a step record
     constexpr int ND = D::HAS_MIN ? 4 : 3;               // DMA requests per step and wave
     auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros)
         const int s = rel < nsteps ? step_lo + rel : p.steps;
         const uint8_t* src = xb_thread + (size_t)s * GB_STEP_BYTES;
-        const uint32_t dst = lds0 + (uint32_t)slot * GB_STEP_BYTES + (uint32_t)wave * 1024u;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gb_dma16(__builtin_amdgcn_readfirstlane(dst + 4096u * k), src + 4096 * k);
+        gb_dma16x3(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * GB_STEP_BYTES + (uint32_t)wave * 3072u), src);
         if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave
             gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + GB_XS_OFF + (uint32_t)slot * 256u + (uint32_t)wave * 64u),
-                     reinterpret_cast<const uint8_t*>(p.xsum + (size_t)s * GB_TOK + wave * 16 + lane * 4));
+                     reinterpret_cast<const uint8_t*>(p.xsum) + (size_t)chunk * p.chunk_bytes + ((size_t)s * GB_TOK + wave * 16 + lane * 4) * sizeof(float));
     };
-    // Prologue in the steady state's request order: the weight ring, then the DMAs of steps 0 .. GB_SLOTS - 2
-#pragma unroll
-    for (int k = 0; k < GB_NR; ++k) load_unit(k, k);
-#pragma unroll
-    for (int s = 0; s < GB_SLOTS - 1; ++s) dma_step(s, s);
-
     const uint8_t* img[RT];      // this lane's row images (row rt*16 + i of the wave's tile)
     uint32_t my_row[RT];         // and the rows' byte offsets in W: the unit's bytes start `(my_row + unit offset) & 15` into the image
 #pragma unroll
@@ -269,9 +284,29 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
         my_row[rt] = (uint32_t)min(row0 + rt * 16 + i, p.out - 1) * p.row_bytes;
     }
     typename D::Hdr hdr[RT];
-    const uint8_t* cur[RT];      // img + the current unit's shift
+    const uint8_t* cur[RT];      // img + the staged unit's shift
+    auto enter_unit = [&](int unit) {   // the image now holds `unit`
+        const uint32_t uoff = (uint32_t)(unit_lo + min(unit, nunits - 1)) * D::UB;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) cur[rt] = img[rt];
+        for (int rt = 0; rt < RT; ++rt) {
+            cur[rt] = img[rt] + ((my_row[rt] + uoff) & 15u);
+            hdr[rt] = D::header(cur[rt]);
+        }
+    };
+    // Prologue, in the steady state's request order (the waits below count requests): the ring; DMA 0, 1; unit 0 staged and its
+    // ring slot re-requested; DMA 2; step 0 decoded.
+#pragma unroll
+    for (int k = 0; k < GB_NR; ++k) load_unit(k, k);
+    dma_step(0, 0);
+    dma_step(1, 1);
+    stage_unit(0);
+    load_unit(0, GB_NR);
+    dma_step(2, 2);
+    static_assert(GB_SLOTS == 4, "the prologue is written out for a B ring of 4");
+    enter_unit(0);
+    AOp a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = D::step(cur[rt], cur[rt] + 4 * g, hdr[rt], 0);
 
     for (int trip = 0; trip * (GB_NR * SPU) < nsteps; ++trip) {
 #pragma unroll
@@ -280,77 +315,108 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
             for (int j = 0; j < SPU; ++j) {
                 const int rel = (trip * GB_NR + k) * SPU + j;        // step relative to the split's start
                 const int slot = (k * SPU + j) % GB_SLOTS;           // its B ring slot (compile time)
-                // requests younger than the DMA of this step: the DMAs of the two steps since, and the unit's weight requests if
-                // they went out in one of those two steps (j = 1, 2; at j = 0 they precede the DMA inside step s - SPU ... )
-                if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND + NLD) : "memory");
+                // requests younger than the DMA of this step: the DMAs of the two steps since, and the next unit's weight requests if
+                // they went out in one of those two steps (they go out in a unit's LAST step, ahead of that step's DMA)
+                if (j == 0 || j == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND + NLD) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND) : "memory");
-                if (j == 0) {
-                    const int unit = trip * GB_NR + k;
-                    stage_unit(k);
-                    load_unit(k, unit + GB_NR);
-                    const uint32_t uoff = (uint32_t)(unit_lo + min(unit, nunits - 1)) * D::UB;
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        cur[rt] = img[rt] + ((my_row[rt] + uoff) & 15u);
-                        hdr[rt] = D::header(cur[rt]);
-                    }
+                if (j == SPU - 1) {   // the weights of this step were decoded a step ago: the image is free for the next unit
+                    stage_unit((k + 1) % GB_NR);
+                    load_unit((k + 1) % GB_NR, trip * GB_NR + k + 1 + GB_NR);
+                    enter_unit(trip * GB_NR + k + 1);
                 }
-                AOp a[RT];
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) a[rt] = D::step(cur[rt], cur[rt] + 4 * g, hdr[rt], j);
                 dma_step(rel + GB_SLOTS - 1, (slot + GB_SLOTS - 1) % GB_SLOTS);
-                __builtin_amdgcn_sched_barrier(0);   // the requests above stay above: they are what the next steps hide
+                // one scheduling region from here to the end of the step: the next step's weight slot is read and decoded in the
+                // shadow of this step's MFMAs
+                AOp an[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) an[rt] = D::step(cur[rt], cur[rt] + 4 * g, hdr[rt], (j + 1) % SPU);
 
                 const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * GB_STEP_BYTES);
                 const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + GB_XS_OFF + (size_t)slot * 256);
+                // all B operands of the step up front (48 registers), then 4 RT independent accumulation chains, plane-major: a
+                // chain's next MFMA is 4 RT - 1 issues away, so none waits for its predecessor
+                u32x4 b[3][4];
+                f32x4 xsum_t[4];
 #pragma unroll
-                for (int tb = 0; tb < 4; ++tb) {
-                    const u32x4 b0 = bs[(0 * 4 + tb) * 64 + lane], b1 = bs[(1 * 4 + tb) * 64 + lane], b2 = bs[(2 * 4 + tb) * 64 + lane];
-                    f32x4 xsum_t = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (D::HAS_MIN) xsum_t = xs[tb * 4 + g];   // tokens tb*16 + 4g + e: this lane's accumulator elements
+                for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        if constexpr (D::SPLIT16) {   // two 16-column groups with their own scale: K = 16 MFMAs on the operand halves
-                            const s16x4 wl = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.x | ((uint64_t)a[rt].a.y << 32));
-                            const s16x4 wh = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.z | ((uint64_t)a[rt].a.w << 32));
-                            f32x4 cl = {0.0f, 0.0f, 0.0f, 0.0f}, ch = {0.0f, 0.0f, 0.0f, 0.0f};
-                            const u32x4 bb[3] = {b0, b1, b2};
+                    for (int tb = 0; tb < 4; ++tb) b[pl][tb] = bs[(pl * 4 + tb) * 64 + lane];
 #pragma unroll
-                            for (int pl = 0; pl < 3; ++pl) {
-                                const s16x4 xl = __builtin_bit_cast(s16x4, (uint64_t)bb[pl].x | ((uint64_t)bb[pl].y << 32));
-                                const s16x4 xh = __builtin_bit_cast(s16x4, (uint64_t)bb[pl].z | ((uint64_t)bb[pl].w << 32));
-                                cl = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xl, wl, cl, 0, 0, 0);
-                                ch = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh, wh, ch, 0, 0, 0);
-                            }
+                for (int tb = 0; tb < 4; ++tb) xsum_t[tb] = D::HAS_MIN ? xs[tb * 4 + g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // tokens tb*16 + 4g + e
+                if constexpr (D::SPLIT16) {   // two 16-column groups with their own scale: K = 16 MFMAs on the operand halves
+                    f32x4 cl[RT][4], ch[RT][4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[rt][tb][e] = fmaf(a[rt].s1, ch[e], fmaf(a[rt].s0, cl[e], acc[rt][tb][e]));
-                        } else {
-                            const bf16x8 wv = __builtin_bit_cast(bf16x8, a[rt].a);
-                            f32x4 cc = {0.0f, 0.0f, 0.0f, 0.0f};
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0), wv, cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1), wv, cc, 0, 0, 0);
-                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b2), wv, cc, 0, 0, 0);
+                    for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float v = fmaf(a[rt].s0, cc[e], acc[rt][tb][e]);
-                                if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
-                                acc[rt][tb][e] = v;
+                        for (int tb = 0; tb < 4; ++tb) {
+                            const s16x4 xl = __builtin_bit_cast(s16x4, (uint64_t)b[pl][tb].x | ((uint64_t)b[pl][tb].y << 32));
+                            const s16x4 xh = __builtin_bit_cast(s16x4, (uint64_t)b[pl][tb].z | ((uint64_t)b[pl][tb].w << 32));
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const s16x4 wl = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.x | ((uint64_t)a[rt].a.y << 32));
+                                const s16x4 wh = __builtin_bit_cast(s16x4, (uint64_t)a[rt].a.z | ((uint64_t)a[rt].a.w << 32));
+                                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                                cl[rt][tb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xl, wl, pl ? cl[rt][tb] : z, 0, 0, 0);
+                                ch[rt][tb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh, wh, pl ? ch[rt][tb] : z, 0, 0, 0);
                             }
                         }
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[rt][tb][e] = fmaf(a[rt].s1, ch[rt][tb][e], fmaf(a[rt].s0, cl[rt][tb][e], acc[rt][tb][e]));
+                } else {
+                    f32x4 cc[RT][4];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                                cc[rt][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b[pl][tb]), __builtin_bit_cast(bf16x8, a[rt].a),
+                                                                                     pl ? cc[rt][tb] : z, 0, 0, 0);
+                            }
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = fmaf(a[rt].s0, cc[rt][tb][e], acc[rt][tb][e]);
+                                if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[tb][e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
+                                acc[rt][tb][e] = v;
+                            }
+                }
+                // issue order of the region: every LDS read first, then the MFMAs with the next step's decode (and this step's
+                // scale-FMAs once their chains close) in their shadow
+                if constexpr (!D::SPLIT16) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
+#pragma unroll
+                    for (int n = 0; n < 12 * RT; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                     }
                 }
-                // the accumulators are complete HERE: without this anchor the instruction selector parks every step's scale-FMAs at
-                // the end of the trip (they have no memory dependence) and the products of 16 steps sit in registers until then
+                // the accumulators and the next operands are complete HERE: without this anchor the instruction selector parks every
+                // step's scale-FMAs at the end of the trip (they have no memory dependence) and the products of 16 steps sit in
+                // registers until then
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                     for (int tb = 0; tb < 4; ++tb) asm volatile("" : "+v"(acc[rt][tb]));
+                    a[rt] = an[rt];
+                    asm volatile("" : "+v"(a[rt].a), "+v"(a[rt].s0), "+v"(a[rt].s1), "+v"(a[rt].mn));
+                }
                 __builtin_amdgcn_sched_barrier(0);   // no motion of memory requests across steps (the waits count them in order)
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be in flight towards LDS when the workgroup retires
-    // ---- epilogue: accumulator element e of lane (i = weight row of the tile, g) is token tb*16 + 4g + e ------------------
+    // ---- epilogue: accumulator element e of lane (i = weight row of the tile, g) is token tb*16 + 4g + e of the chunk ------
+    const size_t tok0 = (size_t)chunk * GB_TOK;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int r = row0 + rt * 16 + i;
@@ -361,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int t = tb * 16 + 4 * g + e;
-                    if (t < p.T) p.part[((size_t)blockIdx.y * GB_TOK + t) * p.out + r] = acc[rt][tb][e];
+                    if (t < Tc) p.part[((size_t)blockIdx.y * p.T + tok0 + t) * p.out + r] = acc[rt][tb][e];
                 }
             continue;
         }
@@ -371,14 +437,14 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = tb * 16 + 4 * g + e;
-                rs[tb][e] = (p.resid && t < p.T) ? p.resid[(size_t)t * p.out + r] : 0.0f;
+                rs[tb][e] = (p.resid && t < Tc) ? p.resid[(tok0 + t) * p.out + r] : 0.0f;
             }
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = tb * 16 + 4 * g + e;
-                if (t < p.T) p.Y[(size_t)t * p.out + r] = acc[rt][tb][e] + rs[tb][e];
+                if (t < Tc) p.Y[(tok0 + t) * p.out + r] = acc[rt][tb][e] + rs[tb][e];
             }
     }
 }
@@ -388,10 +454,9 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(float* __restrict__ 
                                                             int T, int out, int nsplit) {
     const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (idx >= (size_t)T * out) return;
-    const size_t t = idx / out, r = idx % out;
-    float4 v = *reinterpret_cast<const float4*>(part + t * out + r);
+    float4 v = *reinterpret_cast<const float4*>(part + idx);
     for (int s = 1; s < nsplit; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(part + ((size_t)s * GB_TOK + t) * out + r);
+        const float4 a = *reinterpret_cast<const float4*>(part + (size_t)s * T * out + idx);
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
     }
     if (resid) {
@@ -401,9 +466,10 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(float* __restrict__ 
     *reinterpret_cast<float4*>(Y + idx) = v;
 }
 
-static size_t ws_planes_bytes(int in) { return (size_t)(in / 32 + 1) * GB_STEP_BYTES + (size_t)(in / 32 + 1) * GB_TOK * sizeof(float) + 256; }   // + the record of zeros
-constexpr int GB_MAX_SPLIT = 8;
+// one chunk's planes + sums (+ the record of zeros), rounded to 256 B
+static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * (GB_STEP_BYTES + GB_TOK * sizeof(float)) + 255) / 256 * 256; }
 
+// T <= GB_MAX_CHUNKS * 64 tokens in one launch
 template <int DT>
 static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int out, int in, const float* resid, void* ws, int reuse_x,
                             hipStream_t st) {
@@ -418,30 +484,33 @@ static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int 
     GemmBParams p{};
     p.W = static_cast<const uint8_t*>(W);
     p.T = T; p.out = out; p.in = in; p.steps = in / 32;
+    p.chunks = (T + GB_TOK - 1) / GB_TOK;
+    p.chunk_bytes = ws_chunk_bytes(in);
     p.row_bytes = (unsigned)row_bytes;
     p.w_last = (unsigned)((size_t)out * row_bytes - 16);
     uint8_t* wsb = static_cast<uint8_t*>(ws);
     p.xb = wsb;
     p.xsum = reinterpret_cast<const float*>(wsb + (size_t)(p.steps + 1) * GB_STEP_BYTES);
-    p.part = reinterpret_cast<float*>(wsb + (ws_planes_bytes(in) + 255) / 256 * 256);
+    p.part = reinterpret_cast<float*>(wsb + (size_t)GB_MAX_CHUNKS * p.chunk_bytes);
     p.Y = Y; p.resid = resid;
     if (!reuse_x)
-        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 1), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.xsum));
+        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 1, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.xsum),
+                           p.chunk_bytes);
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
     // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) until the grid has about two workgroups per CU.
     static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
     static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 512; }();
     int rt = out >= 2048 ? 2 : 1;
     if (force_rt == 1 || force_rt == 2) rt = force_rt;
-    const int row_wgs = (out + 64 * rt - 1) / (64 * rt);
+    p.row_wgs = (out + 64 * rt - 1) / (64 * rt);
     const int trips = (p.steps + TRIP - 1) / TRIP;
     int nsplit = 1;
-    while (nsplit < GB_MAX_SPLIT && row_wgs * nsplit < want_wgs && trips / (nsplit * 2) >= 1) nsplit *= 2;
+    while (nsplit * 2 * p.chunks <= GB_MAX_SPLIT && p.row_wgs * p.chunks * nsplit < want_wgs && trips / (nsplit * 2) >= 1) nsplit *= 2;
     const int tps = (trips + nsplit - 1) / nsplit;   // trips per split
     nsplit = (trips + tps - 1) / tps;                // no empty split
     p.nsplit = nsplit;
     p.steps_per_split = tps * TRIP;
-    const dim3 grid(row_wgs, nsplit);
+    const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
     const size_t lds2 = gb_lds_bytes<DT, 2>(), lds1 = gb_lds_bytes<DT, 1>();
     if (rt == 2) hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 2>), grid, dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 1>), grid, dim3(256), lds1, st, p);
@@ -458,7 +527,7 @@ extern "C" {
 
 size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features) {
     if (in_features <= 0 || out_features < 0) return 0;
-    return (ntk::ws_planes_bytes((in_features + 31) / 32 * 32) + 255) / 256 * 256 +
+    return (size_t)ntk::GB_MAX_CHUNKS * ntk::ws_chunk_bytes((in_features + 31) / 32 * 32) +
            (size_t)ntk::GB_MAX_SPLIT * ntk::GB_TOK * (size_t)out_features * sizeof(float) + 256;
 }
 
@@ -469,10 +538,11 @@ int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
     if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
-    if (n_tokens > ntk::GB_TOK) reuse_x = 0;   // the planes hold one 64-token chunk at a time
+    constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
+    if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (256 tokens) at a time
     hipStream_t st = ntk::resolve_stream(stream);
-    for (int t0 = 0; t0 < n_tokens; t0 += ntk::GB_TOK) {   // 64 tokens per pass over W
-        const int T = std::min(ntk::GB_TOK, n_tokens - t0);
+    for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 4 x 64 tokens per launch: the chunks share the weights in L2
+        const int T = std::min(PASS, n_tokens - t0);
         float* y = Y + (size_t)t0 * out_features;
         const float* x = X + (size_t)t0 * in_features;
         const float* rs = resid ? resid + (size_t)t0 * out_features : nullptr;

@@ -56,13 +56,14 @@ def main():
             Y = DB.zeros(T * out_f * 4)
             t_gemm = 0.0 if a.bf16_only else timed(lambda: ops.gemm_quant(Y, W, X, T, out_f, in_f, dt), 20)
             if dname in ("Q8_0", "Q4_K", "Q6_K") and out_f % 16 == 0:   # BF16 matrix cores, 64 tokens per pass
-                X64 = DB.from_numpy(rng.standard_normal((64, in_f)).astype(np.float32))
-                Y64 = DB.zeros(64 * out_f * 4)
                 ws_n = int(L.ntk_gemm_quant_workspace_bytes(in_f, out_f))
                 ws = DB(ws_n)
-                t_bf = timed(lambda: L.ntk_gemm_quant_ws(Y64.ptr, W.ptr, X64.ptr, 64, out_f, in_f, int(dt), None, ws.ptr, ws_n, 0, None), 20)
-                print("%-5s %-12s bf16 gemm(64 tok) %8.1f us = %6.1f TFLOP/s (3 products each: %6.1f TFLOP/s on the matrix cores), %.2f us/token vs %.2f"
-                      % (dname, sname, t_bf * 1e6, 2.0 * 64 * out_f * in_f / t_bf / 1e12, 6.0 * 64 * out_f * in_f / t_bf / 1e12, t_bf * 1e6 / 64, t_gemm * 1e6 / 16), flush=True)
+                for TT in (64, 256):
+                    XT = DB.from_numpy(rng.standard_normal((TT, in_f)).astype(np.float32))
+                    YT = DB.zeros(TT * out_f * 4)
+                    t_bf = timed(lambda: L.ntk_gemm_quant_ws(YT.ptr, W.ptr, XT.ptr, TT, out_f, in_f, int(dt), None, ws.ptr, ws_n, 0, None), 20)
+                    print("%-5s %-12s bf16 gemm(%d tok) %8.1f us = %6.1f TFLOP/s (3 products each: %6.1f TFLOP/s on the matrix cores), %.2f us/token vs %.2f"
+                          % (dname, sname, TT, t_bf * 1e6, 2.0 * TT * out_f * in_f / t_bf / 1e12, 6.0 * TT * out_f * in_f / t_bf / 1e12, t_bf * 1e6 / TT, t_gemm * 1e6 / 16), flush=True)
             if a.bf16_only: continue
             def loop():
                 for t in range(T): ops.launch_gemv(Y.at(4 * t * out_f), W, X.at(4 * t * in_f), out_f, in_f, dt)
