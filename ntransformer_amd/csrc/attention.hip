@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void attention_decode_fused_v2_kernel(
 // positions p = (sp * G + g) + k * nsplit * G of group g (interleaved, so every split sees the same load), keeps
 // the same online-softmax state and writes its un-normalised (m, l, acc[hd]) to `part`; a second launch merges
 // the nsplit partial states per head.  RoPE + KV store of the new token as in the single-pass kernel (store: split
-// 0 of the first head of each KV group).  The engine picks single-pass / 8 / 32 splits by position (host side,
+// 0 of the first head of each KV group).  The engine picks single-pass / 8 / 16 splits by position (host side,
 // one hipGraph per regime).
 // part layout: [n_heads][nsplit][hd + 2] = acc[hd], m, l
 // ---------------------------------------------------------------------------------------------
