@@ -289,11 +289,13 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     };
     // Y[t] = W . X[t] for the T tokens: one pass over W per 16 tokens on the matrix cores, or the reference's loop
     const bool batched = batched_prefill_ && T > 1;
+    // (a prompt of <= 16 tokens is one pass of the F32-MFMA GEMM, with no operand pre-pass: measured 2 217 vs 1 727 tok/s at 16)
+    const bool bf16_now = bf16_prefill_ && gemm_ws_ && T > 16;
     const float* planes_of = nullptr;   // the x whose BF16 planes sit in gemm_ws_ (Q, K, V and gate, up share one x)
     auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
         if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
-            if (bf16_prefill_ && gemm_ws_)   // BF16 matrix cores, 64 tokens per pass (Q8_0 / Q4_K / Q6_K, aligned shapes)
+            if (bf16_now)   // BF16 matrix cores, 256 tokens per pass (Q8_0 / Q4_K / Q6_K)
                 st = ntk_gemm_quant_ws(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
                                        X == planes_of ? 1 : 0, s);
             if (st == NTK_OK) planes_of = X;
@@ -308,7 +310,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
         if (batched && is_quant(w.dtype) && (size_t)w.out_f == (size_t)H && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
-            if (bf16_prefill_ && gemm_ws_)
+            if (bf16_now)
                 st = ntk_gemm_quant_ws(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, s);
             planes_of = nullptr;   // (this projection rewrites hidden_, and the next group has a new x)
             if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)

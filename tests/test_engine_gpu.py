@@ -313,20 +313,20 @@ def test_full_depth_8b_q8_0_logits_match_oracle():
     engine sits 2.2e-3 from the oracle at 32 layers while the oracle sits 3.4e-3 from ITSELF under a one-ulp input
     perturbation (F16 rounding of K/V is a discontinuity); the north-star 1e-3 holds for the 2- and 8-layer models below.
     The bar here is therefore max(1e-3, 1.5 x the oracle's own measured sensitivity: largest of three perturbed runs); both are logged."""
-    _parity_at_config("8b_q8_0_full_depth", "8b", "Q8_0", 32, 16, 4, conditioned=True)
+    _parity_at_config("8b_q8_0_full_depth", "8b", "Q8_0", 32, 20, 4, conditioned=True)   # > 16 tokens: the BF16 prompt GEMM
 
 
 def test_8b_q4_k_m_mix_logits_match_oracle():
     """BASELINE config 3: the llama.cpp Q4_K_M tensor mix at 8B width, 8 layers -- layers 0, 3, 6, 7 carry the Q6_K attn_v /
     ffn_down (`use_more_bits`), the others Q4_K, so both the single-dtype and the split Q|K + V launches occur."""
-    _parity_at_config("8b_q4_k_m_8_layers", "8b", "Q4_K_M", 8, 16, 4)
+    _parity_at_config("8b_q4_k_m_8_layers", "8b", "Q4_K_M", 8, 20, 4)
 
 
 @pytest.mark.parametrize("mix", ["Q4_K_M", "Q6_K"])
 def test_70b_width_slice_logits_match_oracle(mix):
     """BASELINE configs 4 / 5 at their real width (H=8192, I=28672, 64 heads, 8 KV heads), 2 layers: the 28672-wide down
     projection (7 column slices, two-pass activation image), Q5_K attn_v (layer 0 of the Q4_K_M mix) and Q6_K (layer 1)."""
-    _parity_at_config("70b_width_2_layers_" + mix.lower(), "70b", mix, 2, 8, 3)
+    _parity_at_config("70b_width_2_layers_" + mix.lower(), "70b", mix, 2, 18, 3)
 
 
 def test_cli_binary_generates_and_reports_decode_rate():
