@@ -230,6 +230,23 @@ int  ntk_persistent_grid(void* plan);
 /* debugging aid: per-operator timestamps of two workgroups (see decode_persistent.hip); returns the operator count */
 int  ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int cap_ops);
 
+/* Tensor-parallel exchange (csrc/tp.hip): hidden[0..n) += sum over ranks of their partial vectors, in rank
+ * order, by one kernel that reads the peers' communication buffers (mapped with ntk_ipc_open or shared in-process) -- no RCCL
+ * call, no second stream, hipGraph-capturable.  A communication buffer = ntk_tp_comm_bytes(max_floats) device bytes, reset once
+ * with ntk_tp_comm_reset before the peers map it.  Call k of a forward writes its partial vector to ntk_tp_slot(comm, max_floats,
+ * k) (slot k & 1) with any kernel on the same stream, then runs ntk_tp_allreduce_add(..., k, n, stream); calls per forward must be
+ * even in number and < 1023; ntk_tp_advance_epoch ends the forward.  All ranks must issue the same sequence.  n % 4 == 0,
+ * n <= max_floats, world <= 8.  ntk_tp_error after a synchronise: 0, or non-zero if a bounded wait for a peer gave up. */
+size_t   ntk_tp_comm_bytes(size_t max_floats);
+int      ntk_tp_comm_reset(void* comm, void* stream);
+float*   ntk_tp_slot(void* comm, size_t max_floats, unsigned call_index);
+int      ntk_tp_allreduce_add(float* hidden, void* const* peers, int rank, int world, size_t max_floats, unsigned call_index, int n, void* stream);
+int      ntk_tp_advance_epoch(void* comm, void* stream);
+unsigned ntk_tp_error(void* comm);
+int      ntk_ipc_export(void* devptr, void* handle64);
+int      ntk_ipc_open(const void* handle64, void** devptr);
+int      ntk_ipc_close(void* devptr);
+
 /* Batched prompt projection on the matrix cores (replaces the per-token launch_gemv loops of
  * attention.cpp:144-162,200-210 and ffn.cpp:96-133):  Y[t,:] = W . X[t,:] (+ resid[t,:]) for t < n_tokens.
  * X [n_tokens][in] and Y/resid [n_tokens][out] are F32, token-major; W raw GGUF blocks [out][in] (quantised dtypes

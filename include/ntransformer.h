@@ -86,7 +86,22 @@ uint64_t nt_engine_weight_bytes(nt_engine_t e);
 int  nt_engine_max_context(nt_engine_t e);
 /* which form the fused decode step takes for this model: "persistent (...)" or "fused (5 launches/layer)" */
 const char* nt_engine_decode_path(nt_engine_t e);
-void* nt_engine_persistent_plan(nt_engine_t e);   /* plan handle for ntk_persistent_debug (NULL if the model does not qualify) */
+void* nt_engine_persistent_plan(nt_engine_t e);
+/* Tensor-parallel decoding over `world` GPUs, one engine (normally one process) per rank -- SURVEY 8(f) rank 4, no reference
+ * counterpart.  nt_engine_tp_configure BEFORE load: the engine then keeps rows [rank/world) of Wq/Wk/Wv/gate/up (whole heads) and
+ * the matching columns of Wo/down; n_heads, n_kv_heads and the FFN width must divide by `world`, column slices must be whole
+ * quantisation blocks.  After load: nt_engine_tp_export gives this rank's communication buffer as a 64-byte hipIpc handle
+ * (other processes) and as a raw device pointer (ranks sharing a process); every rank then calls nt_engine_tp_connect with
+ * world x 64 bytes of handles OR world raw pointers, in rank order.  Every rank must then run the same calls with the same
+ * tokens: after Wo and after down the ranks' partial vectors are added in rank order by one kernel that reads the peers'
+ * buffers over xGMI (ntk_tp_allreduce_add), so hidden states, logits and sampled tokens are bit-identical on all ranks.
+ * nt_engine_tp_error after a call: 0, or non-zero if a bounded wait for a peer gave up. */
+int  nt_engine_tp_configure(nt_engine_t e, int rank, int world);
+int  nt_engine_tp_export(nt_engine_t e, void* handle64, void** raw_ptr);
+int  nt_engine_tp_connect(nt_engine_t e, const void* handles, void* const* raw_ptrs);
+unsigned nt_engine_tp_error(nt_engine_t e);
+/* host only: columns [rank * in/world, (rank + 1) * in/world) of every row of a GGUF matrix, re-packed row-major into dst */
+int  nt_tp_slice_columns(void* dst, const void* src, int dtype, int64_t out_features, int64_t in_features, int rank, int world);   /* plan handle for ntk_persistent_debug (NULL if the model does not qualify) */
 /* write a synthetic GGUF v3 file with the same generator (0 = ok) */
 int  nt_synth_write_gguf(const char* path, const nt_synth_spec* spec, int nthreads);
 /* fill one tensor of the synthetic plan into host memory (for CPU baselines); returns bytes or negative */

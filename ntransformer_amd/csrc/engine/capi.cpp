@@ -139,6 +139,21 @@ int nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, flo
 void* nt_engine_persistent_plan(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().persistent_plan() : nullptr; }
 const char* nt_engine_decode_path(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().decode_path() : ""; }
 
+// ---- tensor parallelism (one engine per rank; csrc/tp.hip) ---------------------------------------------------------------
+int nt_engine_tp_configure(nt_engine_t e, int rank, int world) { return e ? E(e)->model().tp_configure(rank, world) : NTK_E_NULL; }
+int nt_engine_tp_export(nt_engine_t e, void* handle64, void** raw) {
+    if (!e || !E(e)->loaded()) return NTK_E_NULL;
+    return E(e)->model().tp_export(handle64, raw);
+}
+int nt_engine_tp_connect(nt_engine_t e, const void* handles, void* const* raws) {
+    if (!e || !E(e)->loaded()) return NTK_E_NULL;
+    return E(e)->model().tp_connect(handles, raws);
+}
+unsigned nt_engine_tp_error(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().tp_error() : 0u; }
+int nt_tp_slice_columns(void* dst, const void* src, int dtype, int64_t out_features, int64_t in_features, int rank, int world) {
+    return nt::Model::slice_columns(dst, src, dtype, out_features, in_features, rank, world);   // host only
+}
+
 int nt_engine_decode_greedy_steps(nt_engine_t e, int token, int pos, int n, int* out) {
     if (!e || !E(e)->loaded()) return NTK_E_NULL;
     return E(e)->decode_greedy_steps(token, pos, n, out);

@@ -32,6 +32,17 @@ void Model::free_all() {
         }
     if (persistent_plan_) ntk_persistent_plan_destroy(persistent_plan_);
     persistent_plan_ = nullptr;
+    for (int r = 0; r < 8; ++r) {   // peers' communication buffers mapped through hipIpc
+        if (tp_peer_opened_[r] && tp_peers_[r]) (void)ntk_ipc_close(tp_peers_[r]);
+        tp_peers_[r] = nullptr;
+        tp_peer_opened_[r] = false;
+    }
+    tp_connected_ = false;
+    tp_comm_ = nullptr;
+    tp_call_ = 0;
+    if (own_stream_ && stream_) (void)hipStreamDestroy(static_cast<hipStream_t>(stream_));
+    own_stream_ = false;
+    stream_ = nullptr;
     for (void* p : allocs_) nt_hip_free(p);
     allocs_.clear();
     if (h_token_) nt_hip_free_host(h_token_);
@@ -66,6 +77,91 @@ int Model::upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int
     return NTK_OK;
 }
 
+// ---- tensor parallelism: slices ---------------------------------------------------------------------------------------------
+int Model::tp_configure(int rank, int world) {
+    if (world < 1 || world > 8 || rank < 0 || rank >= world) { err_ = "bad tensor-parallel rank / world"; return NTK_E_SHAPE; }
+    if (!layers_.empty()) { err_ = "tp_configure must precede load"; return NTK_E_SHAPE; }
+    tp_rank_ = rank;
+    tp_world_ = world;
+    return NTK_OK;
+}
+
+int Model::slice_columns(void* dst, const void* src, int dtype, int64_t out_f, int64_t in_f, int rank, int world) {
+    if (!dst || !src) return NTK_E_NULL;
+    if (world < 1 || rank < 0 || rank >= world || in_f % world != 0) return NTK_E_SHAPE;
+    const int64_t in_l = in_f / world;
+    const size_t rb_full = ntk_row_bytes(dtype, in_f), rb_loc = ntk_row_bytes(dtype, in_l);
+    if (!rb_full || !rb_loc || rb_loc * (size_t)world != rb_full) return NTK_E_SHAPE;   // the slice must be whole blocks
+    const uint8_t* s8 = static_cast<const uint8_t*>(src);
+    uint8_t* d8 = static_cast<uint8_t*>(dst);
+    for (int64_t r = 0; r < out_f; ++r) memcpy(d8 + (size_t)r * rb_loc, s8 + (size_t)r * rb_full + (size_t)rank * rb_loc, rb_loc);
+    return NTK_OK;
+}
+
+int Model::upload_shard(DevTensor& dst, const void* host_full, int dtype, int64_t in_f, int64_t out_f, size_t nbytes_full, Shard how) {
+    if (tp_world_ == 1 || how == WHOLE) return upload(dst, host_full, dtype, in_f, out_f, nbytes_full);
+    if (how == ROWS) {   // rows are contiguous: a byte range
+        const int64_t rows = out_f / tp_world_;
+        const size_t rb = ntk_row_bytes(dtype, in_f);
+        if (out_f % tp_world_ != 0 || !rb) { err_ = "tensor rows do not divide over the tensor-parallel ranks"; return NTK_E_SHAPE; }
+        return upload(dst, static_cast<const uint8_t*>(host_full) + (size_t)tp_rank_ * rows * rb, dtype, in_f, rows, (size_t)rows * rb);
+    }
+    const int64_t in_l = in_f / tp_world_;
+    const size_t rb_loc = ntk_row_bytes(dtype, in_l);
+    std::vector<uint8_t> tmp((size_t)out_f * rb_loc);
+    const int st = slice_columns(tmp.data(), host_full, dtype, out_f, in_f, tp_rank_, tp_world_);
+    if (st != NTK_OK) { err_ = "tensor columns do not divide into whole blocks over the tensor-parallel ranks"; return st; }
+    return upload(dst, tmp.data(), dtype, in_l, out_f, tmp.size());
+}
+
+int Model::tp_check_shapes() {
+    if (tp_world_ == 1) return NTK_OK;
+    if (cfg_.n_heads % tp_world_ || cfg_.n_kv_heads % tp_world_ || cfg_.intermediate_size % tp_world_) {
+        err_ = "heads / KV heads / FFN width do not divide over the tensor-parallel ranks";
+        return NTK_E_SHAPE;
+    }
+    return NTK_OK;
+}
+
+int Model::tp_export(void* handle64, void** raw) {
+    if (!tp_comm_) return NTK_E_NULL;
+    if (raw) *raw = tp_comm_;
+    if (handle64) return ntk_ipc_export(tp_comm_, handle64);
+    return NTK_OK;
+}
+
+int Model::tp_connect(const void* handles, void* const* raws) {
+    if (tp_world_ == 1) { tp_connected_ = true; return NTK_OK; }
+    if (!tp_comm_ || (!handles && !raws)) return NTK_E_NULL;
+    for (int r = 0; r < tp_world_; ++r) {
+        if (r == tp_rank_) { tp_peers_[r] = tp_comm_; continue; }
+        if (raws) { tp_peers_[r] = raws[r]; continue; }
+        void* p = nullptr;
+        const int st = ntk_ipc_open(static_cast<const uint8_t*>(handles) + 64 * r, &p);
+        if (st != NTK_OK) { err_ = "mapping a peer's communication buffer failed (hipIpcOpenMemHandle)"; return st; }
+        tp_peers_[r] = p;
+        tp_peer_opened_[r] = true;
+    }
+    for (int r = 0; r < tp_world_; ++r)
+        if (!tp_peers_[r]) return NTK_E_NULL;
+    tp_connected_ = true;
+    return NTK_OK;
+}
+
+unsigned Model::tp_error() {
+    if (!tp_comm_) return 0u;
+    unsigned v = 0;   // read on the model's own stream (no legacy-stream traffic next to another rank's capture)
+    if (ntk_memcpy_d2h_async(&v, static_cast<uint8_t*>(tp_comm_) + 128, 4, stream_) != NTK_OK || ntk_stream_synchronize(stream_) != NTK_OK) return ~0u;
+    return v;
+}
+float* Model::tp_slot() const { return ntk_tp_slot(tp_comm_, tp_max_floats_, tp_call_); }
+int Model::tp_allreduce(float* hidden, int n) {
+    if (!tp_connected_) { err_ = "tensor-parallel ranks are not connected (tp_connect)"; return NTK_E_NULL; }
+    const int st = ntk_tp_allreduce_add(hidden, tp_peers_, tp_rank_, tp_world_, tp_max_floats_, tp_call_, n, stream_);
+    ++tp_call_;
+    return st;
+}
+
 int Model::load(const std::string& path, int max_context) {
     const int st = load_impl(path, max_context);
     if (st != NTK_OK) free_all();   // nothing stays resident after a failed load
@@ -93,7 +189,8 @@ int Model::load_impl(const std::string& path, int max_context) {
 
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim;
     const int64_t qd = (int64_t)cfg_.n_heads * hd, kvd = (int64_t)cfg_.n_kv_heads * hd;
-    auto take = [&](const std::string& name, DevTensor& dst, int64_t in_f, int64_t out_f, bool vec) -> int {
+    NT_TRY(tp_check_shapes());
+    auto take = [&](const std::string& name, DevTensor& dst, int64_t in_f, int64_t out_f, bool vec, Shard how = WHOLE) -> int {
         const GgufTensor* t = f.find(name);
         if (!t) { err_ = "Tensor not found: " + name; return NTK_E_FORMAT; }
         if (t->numel() != in_f * out_f || (!vec && (t->dims.size() != 2 || t->dims[0] != in_f))) {
@@ -102,7 +199,7 @@ int Model::load_impl(const std::string& path, int max_context) {
         }
         if (vec && t->dtype != NTK_DT_F32) { err_ = name + " must be F32"; return NTK_E_DTYPE; }
         if (t->nbytes == 0 || !t->known_type) { err_ = "Unsupported tensor type for " + name; return NTK_E_DTYPE; }
-        return upload(dst, f.data(*t), t->dtype, in_f, out_f, t->nbytes);
+        return upload_shard(dst, f.data(*t), t->dtype, in_f, out_f, t->nbytes, how);
     };
     NT_TRY(take("token_embd.weight", token_embd_, H, cfg_.vocab_size, false));
     if (f.find("output.weight")) {   // transformer.cpp:92-99
@@ -117,14 +214,14 @@ int Model::load_impl(const std::string& path, int max_context) {
         const std::string p = "blk." + std::to_string(i) + ".";
         LayerWeights& L = layers_[i];
         NT_TRY(take(p + "attn_norm.weight", L.attn_norm, H, 1, true));
-        NT_TRY(take(p + "attn_q.weight", L.wq, H, qd, false));
-        NT_TRY(take(p + "attn_k.weight", L.wk, H, kvd, false));
-        NT_TRY(take(p + "attn_v.weight", L.wv, H, kvd, false));
-        NT_TRY(take(p + "attn_output.weight", L.wo, qd, H, false));
+        NT_TRY(take(p + "attn_q.weight", L.wq, H, qd, false, ROWS));      // whole heads per rank
+        NT_TRY(take(p + "attn_k.weight", L.wk, H, kvd, false, ROWS));
+        NT_TRY(take(p + "attn_v.weight", L.wv, H, kvd, false, ROWS));
+        NT_TRY(take(p + "attn_output.weight", L.wo, qd, H, false, COLS));  // the columns of this rank's heads
         NT_TRY(take(p + "ffn_norm.weight", L.ffn_norm, H, 1, true));
-        NT_TRY(take(p + "ffn_gate.weight", L.w_gate, H, I, false));
-        NT_TRY(take(p + "ffn_up.weight", L.w_up, H, I, false));
-        NT_TRY(take(p + "ffn_down.weight", L.w_down, I, H, false));
+        NT_TRY(take(p + "ffn_gate.weight", L.w_gate, H, I, false, ROWS));
+        NT_TRY(take(p + "ffn_up.weight", L.w_up, H, I, false, ROWS));
+        NT_TRY(take(p + "ffn_down.weight", L.w_down, I, H, false, COLS));
     }
     return finish_load(max_context);
 }
@@ -146,6 +243,7 @@ int Model::load_synthetic(const SynthSpec& spec, int max_context, int nthreads) 
     if (const char* e = getenv("NTK_DEVICE")) dev = atoi(e);
     const int st = ntk_device_init(dev);
     if (st != NTK_OK) { err_ = "no usable GPU (HIP device init failed)"; return st; }
+    { const int ts = tp_check_shapes(); if (ts != NTK_OK) return ts; }
 
     size_t biggest = 0;
     for (const auto& t : plan) biggest = std::max(biggest, t.nbytes);
@@ -169,7 +267,11 @@ int Model::load_synthetic(const SynthSpec& spec, int max_context, int nthreads) 
                 : w == "attn_v.weight" ? &L.wv : w == "attn_output.weight" ? &L.wo : w == "ffn_norm.weight" ? &L.ffn_norm
                 : w == "ffn_gate.weight" ? &L.w_gate : w == "ffn_up.weight" ? &L.w_up : &L.w_down;
         }
-        rc = upload(*dst, stage, ggml_type_to_dtype((uint32_t)t.ggml_type), t.in_f, t.out_f, t.nbytes);
+        Shard how = WHOLE;
+        if (t.name.find("attn_q.") != std::string::npos || t.name.find("attn_k.") != std::string::npos || t.name.find("attn_v.") != std::string::npos ||
+            t.name.find("ffn_gate.") != std::string::npos || t.name.find("ffn_up.") != std::string::npos) how = ROWS;
+        else if (t.name.find("attn_output.") != std::string::npos || t.name.find("ffn_down.") != std::string::npos) how = COLS;
+        rc = upload_shard(*dst, stage, ggml_type_to_dtype((uint32_t)t.ggml_type), t.in_f, t.out_f, t.nbytes, how);
         if (rc != NTK_OK) break;
     }
     nt_hip_free_host(stage);
@@ -179,10 +281,21 @@ int Model::load_synthetic(const SynthSpec& spec, int max_context, int nthreads) 
 }
 
 int Model::finish_load(int /*max_context*/) {
-    stream_ = ntk_stream(0);
+    cfg_full_ = cfg_;
+    if (tp_world_ > 1) {   // from here on this object IS a model with 1/W of the heads and of the FFN width (hidden size unchanged)
+        cfg_.n_heads /= tp_world_;
+        cfg_.n_kv_heads /= tp_world_;
+        cfg_.intermediate_size /= tp_world_;
+        hipStream_t own = nullptr;   // ranks that share a process (tests) must not queue behind each other's waiting kernels
+        if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) { err_ = "stream creation failed"; return NTK_E_LAUNCH; }
+        stream_ = own;
+        own_stream_ = true;
+    } else {
+        stream_ = ntk_stream(0);
+    }
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
-    (void)build_persistent_plan();   // optional fast path: failure only means the launch path is used
+    if (tp_world_ == 1) (void)build_persistent_plan();   // optional fast path: failure only means the launch path is used
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
     fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights)\nFree VRAM: %.1f GB\n",
@@ -223,6 +336,11 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     gemm_ws_ = dev(gemm_ws_bytes_, false);
     if (const char* e = getenv("NTK_BF16_PREFILL")) bf16_prefill_ = atoi(e) != 0;   // [0] heads done, [1] finished, [2] error, [64 + 64 g] release flags
     if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
+    if (tp_world_ > 1) {   // communication buffer: flags + two slots of one prompt's worth of hidden vectors
+        tp_max_floats_ = S * H;
+        tp_comm_ = dev(ntk_tp_comm_bytes(tp_max_floats_), false);
+        if (!tp_comm_ || ntk_tp_comm_reset(tp_comm_, nullptr) != NTK_OK || ntk_device_synchronize() != NTK_OK) { err_ = "communication buffer allocation failed"; return NTK_E_NOMEM; }
+    }
     d_recent_ = (int*)dev(kRecentCap * 4, false);
     h_recent_ = (int*)nt_hip_malloc_host(kRecentCap * 4);
     if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
@@ -262,6 +380,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     void* s = stream_;
+    tp_call_ = 0;
     // embedding rows are dequantised on the device (the reference does it on the host and uploads, :419-599)
     if (ntk_memcpy_h2d_async(tokens_dev_, tokens, (size_t)T * 4, s) != NTK_OK) return nullptr;
     const int est = ntk_embed_rows(hidden_, token_embd_.ptr, tokens_dev_, T, H, token_embd_.dtype, s);
@@ -308,6 +427,12 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     // hidden += W . X (attention.cpp:207 + transformer.cpp:645, ffn.cpp:130 + transformer.cpp:652): the batched
     // projection adds the residual in its epilogue, the reference sequence goes through residual_ and launch_add_inplace
     auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
+        if (tp_world_ > 1) {   // this rank's columns give a PARTIAL sum: into the exchange slot, then hidden += sum over ranks
+            project(tp_slot(), w, X, H, xstride);
+            planes_of = nullptr;
+            ok(tp_allreduce(hidden_, T * H));
+            return;
+        }
         if (batched && is_quant(w.dtype) && (size_t)w.out_f == (size_t)H && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
             if (bf16_now)
@@ -345,6 +470,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     float* last = hidden_ + (size_t)(T - 1) * H;
     ok(ntk_rmsnorm(last, last, (const float*)output_norm_.ptr, 1, H, cfg_.norm_eps, s));   // in place, :658-659
     gemv(logits_, output_, last);
+    if (tp_world_ > 1) ok(ntk_tp_advance_epoch(tp_comm_, s));
     ok(ntk_stream_synchronize(s));
     if (rc != NTK_OK) { err_ = std::string("forward failed: ") + ntk_status_string(rc); return nullptr; }
     return logits_;
@@ -360,9 +486,10 @@ int Model::set_device_token(int token) {
 }
 int Model::set_device_pos(int pos) {
     host_pos_ = pos;
-    // small blocking copy: callers do this once per generation
-    nt_hip_memcpy_h2d(d_pos_, &pos, 4);
-    return NTK_OK;
+    // small copy, once per generation -- on the model's own stream: a blocking copy on the legacy stream would collide with a
+    // hipGraph capture in progress on another thread's stream (tensor-parallel ranks sharing a process)
+    NT_TRY(ntk_memcpy_h2d_async(d_pos_, &pos, 4, stream_));
+    return ntk_stream_synchronize(stream_);
 }
 int Model::sync() { return ntk_stream_synchronize(stream_); }
 int Model::host_token() const { return *h_token_; }
@@ -394,6 +521,7 @@ int Model::enqueue_token(bool greedy) {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     void* s = stream_;
+    tp_call_ = 0;
     // profiling hook (only inside profile_token(), never while capturing).  Fine mode: an event pair around every
     // launch.  Coarse mode: ONE event where the launch class changes -- a run of same-class launches is timed as a
     // whole (its kernels and the boundaries between them), so the cost of the events is paid once per run.
@@ -495,7 +623,7 @@ int Model::enqueue_token(bool greedy) {
             float* ys[3] = {q_buf, k_buf, v_buf};
             NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
         }
-        if (attn_regime_ == 0 && fuse_attention_ && attn_sync_ && is_quant(L.wo.dtype)) {
+        if (attn_regime_ == 0 && fuse_attention_ && attn_sync_ && is_quant(L.wo.dtype) && tp_world_ == 1) {
             // attention producers inside the Wo launch: one launch, one boundary and one first-byte latency less per layer
             ntk_gemv_seg wo = {L.wo.ptr, hidden_, (int)L.wo.out_f, L.wo.dtype};
             mark(0, true);
@@ -515,7 +643,12 @@ int Model::enqueue_token(bool greedy) {
                                               cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale,
                                               attn_regime_ == 1 ? 8 : 16, attn_scratch_, s));
         mark(1, false);
-        NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
+        if (tp_world_ > 1) {   // partial sum over this rank's heads -> exchange slot -> hidden += sum over ranks
+            NT_TRY(project1(L.wo, tp_slot(), attn_out, nullptr, nullptr));
+            NT_TRY(tp_allreduce(hidden_, H));
+        } else {
+            NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
+        }
     ffn:
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
             ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
@@ -528,12 +661,18 @@ int Model::enqueue_token(bool greedy) {
             NT_TRY(project(ws, ys, 2, hidden_, &L.ffn_norm, nullptr));
             NT_TRY(ntk_silu_mul(gate_buf, gate_buf, up_buf, I, s));
         }
-        NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_));
+        if (tp_world_ > 1) {
+            NT_TRY(project1(L.w_down, tp_slot(), gate_buf, nullptr, nullptr));
+            NT_TRY(tp_allreduce(hidden_, H));
+        } else {
+            NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_));
+        }
     }
     NT_TRY(project1(output_, logits_, hidden_, &output_norm_, nullptr));
     mark(2, true);
     if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
     NT_TRY(ntk_advance_pos(d_pos_, s));
+    if (tp_world_ > 1) NT_TRY(ntk_tp_advance_epoch(tp_comm_, s));
     mark(2, false);
     return NTK_OK;
 }
@@ -677,7 +816,8 @@ int Model::decode_step_fused(bool greedy, bool use_graph) {
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
         hipGraph_t g = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return NTK_E_LAUNCH;
+        // (relaxed under tensor parallelism: ranks sharing a process run their own runtime calls on other threads meanwhile)
+        if (hipStreamBeginCapture(st, tp_world_ > 1 ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal) != hipSuccess) return NTK_E_LAUNCH;
         const int rc = enqueue_token(greedy);
         const hipError_t e = hipStreamEndCapture(st, &g);
         if (rc != NTK_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return rc != NTK_OK ? rc : NTK_E_LAUNCH; }

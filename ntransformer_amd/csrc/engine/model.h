@@ -91,11 +91,30 @@ public:
     int profile_token(float ms[4], int calls[4], bool coarse);
     void* stream() const { return stream_; }
 
+    // ---- tensor parallelism (csrc/tp.hip) -------------------------------------------------------------
+    // Call before load(): this model object holds slice `rank` of `world` -- rows [rank/world) of Wq, Wk, Wv, gate, up (whole
+    // heads), columns of Wo and down -- so config() reports the LOCAL head / FFN counts.  After load(): exchange comm()
+    // addresses (tp_export: a hipIpc handle and the raw pointer) and tp_connect() them on every rank before the first forward.
+    int tp_configure(int rank, int world);
+    int tp_rank() const { return tp_rank_; }
+    int tp_world() const { return tp_world_; }
+    int tp_export(void* handle64, void** raw);
+    int tp_connect(const void* handles, void* const* raws);   // world x 64-byte handles (other processes) or raw pointers (same process)
+    unsigned tp_error();                                      // after sync(): 0, or the call that gave up waiting for a peer
+    // the host-side column slice of a GGUF matrix: columns [rank * in/world, (rank+1) * in/world) of every row, re-packed
+    static int slice_columns(void* dst, const void* src, int dtype, int64_t out_f, int64_t in_f, int rank, int world);
+
 private:
     int load_impl(const std::string& gguf_path, int max_context);
     int finish_load(int max_context);
     int alloc_buffers();
     int upload(DevTensor& dst, const void* host, int dtype, int64_t in_f, int64_t out_f, size_t nbytes);
+    enum Shard { WHOLE, ROWS, COLS };
+    // upload this rank's part of a full host tensor [out_f][in_f]: everything, rows [rank * out/world ...), or the column slice
+    int upload_shard(DevTensor& dst, const void* host_full, int dtype, int64_t in_f, int64_t out_f, size_t nbytes_full, Shard how);
+    int tp_check_shapes();            // the head / FFN / block divisibility the slices need
+    int tp_allreduce(float* hidden, int n);   // hidden += sum over ranks of the partial vectors in the current slot
+    float* tp_slot() const;           // where the next partial vector goes
     void free_all();
     int enqueue_token(bool greedy);   // the fused launch sequence for one token
     bool use_persistent_now() const;
@@ -145,6 +164,15 @@ private:
     bool bf16_prefill_ = true;
     unsigned* attn_sync_ = nullptr;  // 3 words for ntk_attention_gemv_fused (attention producers inside the Wo launch)
     bool fuse_attention_ = false;    // attention + Wo projection as one launch: measured SLOWER than two launches (profiles/r02_*): opt-in
+    int tp_rank_ = 0, tp_world_ = 1;
+    void* tp_comm_ = nullptr;        // this rank's communication buffer (flags + two slots of max_seq x H floats)
+    size_t tp_max_floats_ = 0;
+    void* tp_peers_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tp_peer_opened_[8] = {false, false, false, false, false, false, false, false};   // mapped through hipIpc (to be closed)
+    bool tp_connected_ = false;
+    unsigned tp_call_ = 0;           // all-reduce calls of the forward being enqueued (call k uses slot k & 1)
+    bool own_stream_ = false;        // tensor-parallel ranks that share a process need private streams
+    ModelConfig cfg_full_;           // the unsliced configuration (cfg_ holds the local head / FFN counts)
     void* persistent_plan_ = nullptr;
     bool persistent_on_ = false;   // opt-in until it beats the launch path on the bench (set_persistent / "persistent" option)
 };

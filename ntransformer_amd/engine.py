@@ -80,6 +80,12 @@ def _bind():
     L.nt_synth_tensor.restype = C.c_int64
     L.nt_engine_decode_greedy_steps.argtypes = [vp, i, i, i, C.POINTER(i)]
     L.nt_engine_profile_token.argtypes = [vp, i, i, i, C.POINTER(f), C.POINTER(i)]
+    L.nt_engine_tp_configure.argtypes = [vp, i, i]
+    L.nt_engine_tp_export.argtypes = [vp, vp, C.POINTER(vp)]
+    L.nt_engine_tp_connect.argtypes = [vp, vp, C.POINTER(vp)]
+    L.nt_engine_tp_error.argtypes = [vp]
+    L.nt_engine_tp_error.restype = C.c_uint
+    L.nt_tp_slice_columns.argtypes = [vp, vp, i, C.c_int64, C.c_int64, i, i]
     L._engine_bound = True
     return L
 
@@ -121,6 +127,30 @@ class Engine:
     def load_synthetic(self, spec: SynthSpec, max_context: int = 4096):
         self._spec = spec
         self._check(self.L.nt_engine_load_synthetic(self.h, C.byref(spec), max_context), "load_synthetic")
+
+    # ---- tensor parallelism (include/ntransformer.h: nt_engine_tp_*) ----
+    def tp_configure(self, rank: int, world: int) -> None:
+        """before load(): this engine keeps slice `rank` of `world` of every projection"""
+        self._check(self.L.nt_engine_tp_configure(self.h, rank, world), "tp_configure")
+
+    def tp_export(self):
+        """after load(): (64-byte hipIpc handle, raw device pointer) of this rank's communication buffer"""
+        handle = C.create_string_buffer(64)
+        raw = C.c_void_p()
+        self._check(self.L.nt_engine_tp_export(self.h, handle, C.byref(raw)), "tp_export")
+        return handle.raw, raw.value
+
+    def tp_connect(self, handles: Optional[Sequence[bytes]] = None, raws: Optional[Sequence[int]] = None) -> None:
+        """every rank, in rank order: the peers' handles (other processes) or raw pointers (ranks sharing this process)"""
+        if raws is not None:
+            arr = (C.c_void_p * len(raws))(*raws)
+            self._check(self.L.nt_engine_tp_connect(self.h, None, arr), "tp_connect")
+        else:
+            blob = C.create_string_buffer(b"".join(handles), 64 * len(handles))
+            self._check(self.L.nt_engine_tp_connect(self.h, blob, None), "tp_connect")
+
+    def tp_error(self) -> int:
+        return int(self.L.nt_engine_tp_error(self.h))
 
     def set_option(self, key: str, value) -> None:
         self._check(self.L.nt_engine_set_option(self.h, key.encode(), str(int(value)).encode()), "set_option " + key)

@@ -1,0 +1,153 @@
+"""Tensor-parallel decoding on ONE GPU: the ranks share the device (the GPU boxes of this project have a single MI355X), which
+exercises everything except the xGMI link itself -- the sliced weights, the local heads and KV cache, the exchange kernel with
+its flags, slots and epochs, hipGraph replay, the hipIpc mapping across processes.  The result must equal the unsliced engine's
+logits up to summation order, and be bit-identical on all ranks."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from ntransformer_amd import engine as E
+from ntransformer_amd import gguf as G
+from test_oracle_golden import golden_model
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-4   # against the unsliced engine (same kernels, partial sums added in a different order); the logits bar is 1e-3
+
+
+def _run_rank(eng, prompt, fed, graph, out, key):
+    try:
+        lg = [eng.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in fed:
+            lg.append(eng.decode_fused(int(t), pos, graph))
+            pos += 1
+        toks = eng.decode_greedy_steps(int(fed[-1]), pos, 8)
+        out[key] = (np.stack(lg), toks, eng.tp_error())
+    except Exception as e:   # noqa: BLE001 -- reported by the main thread
+        out[key] = e
+
+
+def _single(path, ctx, prompt, fed, graph):
+    eng = E.Engine()
+    eng.load(path, ctx)
+    out = {}
+    _run_rank(eng, prompt, fed, graph, out, 0)
+    eng.close()
+    assert not isinstance(out[0], Exception), out[0]
+    return out[0]
+
+
+@pytest.mark.parametrize("name,shape,mix,world", [("tiny_q8_0", G.TINY, "Q8_0", 2), ("small_q8_0", G.SMALL, "Q8_0", 2),
+                                                  ("small_q4_k_m", G.SMALL, "Q4_K_M", 2), ("small_q6_k", G.SMALL, "Q6_K", 2)])
+@pytest.mark.parametrize("graph", [False, True])
+def test_ranks_sharing_a_process_match_the_unsliced_engine(name, shape, mix, world, graph, tmp_path):
+    path, z = golden_model(name, shape, mix, tmp_path)
+    ctx = int(z["ctx"])
+    r = np.random.Generator(np.random.Philox(key=[20260925, 7]))
+    prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, 20)]   # > 16 tokens: the BF16 prompt GEMM under slices
+    fed = [int(t) for t in r.integers(0, 256, 5)]
+    ref_logits, ref_toks, _ = _single(path, ctx, prompt, fed, graph)
+
+    engines = []
+    for rank in range(world):
+        eng = E.Engine()
+        eng.tp_configure(rank, world)
+        eng.load(path, ctx)
+        engines.append(eng)
+    raws = [eng.tp_export()[1] for eng in engines]
+    for eng in engines:
+        eng.tp_connect(raws=raws)
+    out = {}
+    threads = [threading.Thread(target=_run_rank, args=(engines[k], prompt, fed, graph, out, k)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert all(not t.is_alive() for t in threads), "a rank did not finish"
+    for eng in engines:
+        eng.close()
+    for k in range(world):
+        assert not isinstance(out[k], Exception), out[k]
+        lg, toks, err = out[k]
+        assert err == 0, "rank %d: a wait for a peer gave up (%d)" % (k, err)
+        assert np.isfinite(lg).all()
+        assert np.abs(lg - ref_logits).max() <= TOL, (k, np.abs(lg - ref_logits).max())
+    for k in range(1, world):   # the ranks add the same numbers in the same order
+        assert np.array_equal(out[k][0], out[0][0])
+        assert out[k][1] == out[0][1]
+    assert out[0][1] == ref_toks or np.abs(out[0][0] - ref_logits).max() > 0   # greedy stream: equal unless a near-tie flips
+
+
+def test_a_model_that_does_not_divide_is_refused(tmp_path):
+    path, z = golden_model("tiny_q4_k_m", G.TINY, "Q4_K_M", tmp_path)   # Wo has 256 columns: half a Q4_K super-block per rank
+    eng = E.Engine()
+    eng.tp_configure(0, 2)
+    with pytest.raises(Exception):
+        eng.load(path, int(z["ctx"]))
+    eng.close()
+    eng = E.Engine()
+    eng.tp_configure(0, 4)                                               # 2 KV heads over 4 ranks
+    path8, z8 = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)
+    with pytest.raises(Exception):
+        eng.load(path8, int(z8["ctx"]))
+    eng.close()
+
+
+RANK_SCRIPT = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+from ntransformer_amd import engine as E, tp
+rank, world, path, ctx, d = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), sys.argv[6]
+job = json.load(open(d + "/job.json"))
+eng = E.Engine()
+eng.tp_configure(rank, world)
+eng.load(path, ctx)
+tp.connect_over_files(eng, rank, world, d, timeout_s=100)
+lg = [eng.forward(job["prompt"], 0)]
+pos = len(job["prompt"])
+for t in job["fed"]:
+    lg.append(eng.decode_fused(int(t), pos, True))
+    pos += 1
+np.save(d + "/logits_%d.npy" % rank, np.stack(lg))
+json.dump({"tp_error": eng.tp_error()}, open(d + "/done_%d.json" % rank, "w"))
+eng.close()
+"""
+
+
+def test_two_processes_over_hipipc_match_the_unsliced_engine(tmp_path):
+    """the deployment form: one process per rank, communication buffers mapped with hipIpc handles (exchanged through files)"""
+    path, z = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)
+    ctx = int(z["ctx"])
+    r = np.random.Generator(np.random.Philox(key=[20260925, 8]))
+    prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, 20)]
+    fed = [int(t) for t in r.integers(0, 256, 4)]
+    ref_logits, _, _ = _single(path, ctx, prompt, fed, True)
+    d = str(tmp_path)
+    json.dump({"prompt": prompt, "fed": fed}, open(os.path.join(d, "job.json"), "w"))
+    script = os.path.join(d, "rank.py")
+    open(script, "w").write(RANK_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, script, ROOT, str(k), "2", path, str(ctx), d], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for k in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        outs.append(o.decode(errors="replace"))
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, outs[k][-2000:]
+    lgs = [np.load(os.path.join(d, "logits_%d.npy" % k)) for k in range(2)]
+    for k in range(2):
+        assert json.load(open(os.path.join(d, "done_%d.json" % k)))["tp_error"] == 0
+        assert np.abs(lgs[k] - ref_logits).max() <= TOL, np.abs(lgs[k] - ref_logits).max()
+    assert np.array_equal(lgs[0], lgs[1])
