@@ -85,6 +85,51 @@ def test_ranks_sharing_a_process_match_the_unsliced_engine(name, shape, mix, wor
     assert out[0][1] == ref_toks or np.abs(out[0][0] - ref_logits).max() > 0   # greedy stream: equal unless a near-tie flips
 
 
+@pytest.mark.parametrize("world", [4])
+def test_four_way_slices_of_a_70b_width_layer(world):
+    """Llama-3.1-70B width (H 8192, 64 / 8 heads, FFN 28672), one layer, Q4_K_M, built by the seeded generator, 4 ranks against
+    the unsliced engine.  (8 ranks as 8 threads on ONE GPU oversubscribe its hardware queues: the waiting kernels of some ranks
+    are time-sliced against the producing kernels of others and the bounded waits give up -- an artefact of the emulation, seen
+    once and not kept as a test; on 8 GPUs every rank has its own queues.)"""
+    spec = E.synth_spec("70b", "Q4_K_M", layers=1)
+    r = np.random.Generator(np.random.Philox(key=[20260925, 9]))
+    prompt = [128000] + [int(t) for t in r.integers(0, 128000, 17)]
+    fed = [int(t) for t in r.integers(0, 128000, 3)]
+
+    def single():
+        eng = E.Engine()
+        eng.load_synthetic(spec, 128)
+        out = {}
+        _run_rank(eng, prompt, fed, True, out, 0)
+        eng.close()
+        assert not isinstance(out[0], Exception), out[0]
+        return out[0]
+    ref_logits, _, _ = single()
+    engines = []
+    for rank in range(world):
+        eng = E.Engine()
+        eng.tp_configure(rank, world)
+        eng.load_synthetic(spec, 128)
+        engines.append(eng)
+    raws = [eng.tp_export()[1] for eng in engines]
+    for eng in engines:
+        eng.tp_connect(raws=raws)
+    out = {}
+    threads = [threading.Thread(target=_run_rank, args=(engines[k], prompt, fed, True, out, k)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=180)
+    assert all(not t.is_alive() for t in threads), "a rank did not finish"
+    for eng in engines:
+        eng.close()
+    for k in range(world):
+        assert not isinstance(out[k], Exception), out[k]
+        assert out[k][2] == 0
+        assert np.abs(out[k][0] - ref_logits).max() <= TOL, (k, np.abs(out[k][0] - ref_logits).max())
+        assert np.array_equal(out[k][0], out[0][0])
+
+
 def test_a_model_that_does_not_divide_is_refused(tmp_path):
     path, z = golden_model("tiny_q4_k_m", G.TINY, "Q4_K_M", tmp_path)   # Wo has 256 columns: half a Q4_K super-block per rank
     eng = E.Engine()
