@@ -597,6 +597,9 @@ static size_t attn_lds(int hd, int n_keys, int nvec) {
     return sizeof(float) * ((size_t)nvec * hd + 16 + 4 * (size_t)hd + (size_t)n_keys + 1);
 }
 
+int launch_attention_prefill_mfma(float* out, const float* Q, const uint16_t* kc, const uint16_t* vc, int T, int start_pos, int nh, int nkv,
+                                  int hd, float scale, hipStream_t st);   // attention_mfma.hip
+
 static int launch_attention(float* out, const float* Q, const void* kc, const void* vc, int T, int n_keys_base, int causal,
                             int nh, int nkv, int hd, float scale, hipStream_t st) {
     if (nh <= 0 || nkv <= 0 || hd <= 0 || nh % nkv != 0 || T < 0) return NTK_E_SHAPE;
@@ -606,6 +609,11 @@ static int launch_attention(float* out, const float* Q, const void* kc, const vo
     const uint16_t* k16 = static_cast<const uint16_t*>(kc);
     const uint16_t* v16 = static_cast<const uint16_t*>(vc);
     static const bool tiled_off = [] { const char* e = getenv("NTK_PREFILL_ATTENTION_1TO1"); return e && atoi(e) != 0; }();
+    static const bool mfma_off = [] { const char* e = getenv("NTK_PREFILL_ATTENTION_NO_MFMA"); return e && atoi(e) != 0; }();
+    if (causal && T > 1 && aligned && hd == 128 && !tiled_off && !mfma_off) {   // prompt, head_dim 128: F16 matrix cores (attention_mfma.hip)
+        const int rc = launch_attention_prefill_mfma(out, Q, k16, v16, T, n_keys_base, nh, nkv, hd, scale, st);
+        if (rc != NTK_E_SHAPE && rc != NTK_E_ALIGN) return rc;
+    }
     if (causal && T > 1 && aligned && (hd == 64 || hd == 128 || hd == 256) && !tiled_off) {   // prompt: flash-style tiles
         const size_t fl = (size_t)2 * FA_KT * hd * sizeof(uint16_t) + (size_t)FA_QT * hd * sizeof(float);
         const dim3 fgrid(nh, (T + FA_QT - 1) / FA_QT);

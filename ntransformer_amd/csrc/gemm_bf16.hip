@@ -499,7 +499,7 @@ static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int 
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
     // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) until the grid has about two workgroups per CU.
     static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
-    static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 512; }();
+    static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 256; }();
     int rt = out >= 2048 ? 2 : 1;
     if (force_rt == 1 || force_rt == 2) rt = force_rt;
     p.row_wgs = (out + 64 * rt - 1) / (64 * rt);

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--no-engine", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-matrix table")
     ap.add_argument("--mixes", default="Q8_0,Q4_K,Q6_K", help="per-matrix table: weight formats")
+    ap.add_argument("--tokens", default="16,64,256,1024", help="engine part: prompt lengths")
+    ap.add_argument("--modes", default="2,1,0", help="engine part: 2 = BF16 GEMM, 1 = F32-MFMA GEMM, 0 = per-token loop (<= 64 tokens only)")
     ap.add_argument("--bf16-only", action="store_true", help="per-matrix table: only the BF16 GEMM launches (profiling)")
     a = ap.parse_args()
     ops.init(0)
@@ -79,7 +81,9 @@ def main():
         eng = E.Engine()
         eng.load_synthetic(E.synth_spec("8b", a.mix), 4096)
         r = np.random.Generator(np.random.Philox(key=[20260925, 99]))
-        for T, modes in ((16, (2, 1, 0)), (64, (2, 1, 0)), (256, (2, 1)), (1024, (2, 1))):
+        want_modes = [int(m) for m in a.modes.split(',')]
+        for T in [int(t) for t in a.tokens.split(',')]:
+            modes = [m for m in want_modes if m > 0 or T <= 64]
             prompt = [128000] + [int(t) for t in r.integers(0, 128000, T - 1)]
             for batched in modes:   # 2: BF16 MFMA, 64 tokens per pass; 1: F32 MFMA, 16 per pass; 0: the reference's per-token loop
                 eng.set_option("batched_prefill", batched > 0)
