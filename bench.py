@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-tokens", type=int, default=24, help="-n of the reference CLI run that is the CPU baseline")
     ap.add_argument("--no-also", action="store_true", help="skip BASELINE configs 3 and 4 (8B Q4_K_M, 70B Q4_K_M)")
     ap.add_argument("--no-pmc-note", action="store_true")
+    ap.add_argument("--prompt-bench", type=int, default=1024, help="also time one prompt pass of this many tokens (0 = skip); reported under config.prompt_pass")
     return ap.parse_args()
 
 
@@ -190,6 +191,19 @@ def run_workload(args, model, mix, steps, warmup, timed, sync):
     ms, calls = prof(True)
     ms_fine, calls_fine = prof(False)
     res.update(ms=ms, calls=calls, ms_fine=ms_fine, calls_fine=calls_fine, gemv_bytes_tok=_gemv_bytes_per_token(spec, mix))
+    # ---- prompt pass, outside the timed decode region: one 1024-token prompt through the batched
+    # projections (BF16 matrix cores) and the matrix-core prompt attention; second of two runs, host-timed around the sync
+    res["prompt"] = None
+    if getattr(args, "prompt_bench", 0) and args.ctx >= args.prompt_bench:
+        try:
+            long_prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, args.prompt_bench - 1)]
+            eng.forward(long_prompt, 0)
+            t0 = time.perf_counter()
+            eng.forward(long_prompt, 0)
+            dt = time.perf_counter() - t0
+            res["prompt"] = {"tokens": args.prompt_bench, "ms": round(dt * 1e3, 2), "tokens_per_s": round(args.prompt_bench / dt, 1)}
+        except Exception as e:   # never at the expense of the decode number
+            res["prompt"] = {"tokens": args.prompt_bench, "error": repr(e)}
     eng.close()
     return res
 
@@ -261,7 +275,8 @@ def main():
                        "ctx": args.ctx, "decode_positions": [r["pos"], r["pos_end"]], "replicas": world,
                        "path": "1:1 launchers (15/layer)" if args.no_fuse else (r["path"] or "fused (5 launches/layer)"),
                        "hipgraph": not args.no_graph and not args.no_fuse,
-                       "algorithmic_bytes_per_token": r["b_tok"], "load_seconds": round(r["t_load"], 2)},
+                       "algorithmic_bytes_per_token": r["b_tok"], "load_seconds": round(r["t_load"], 2),
+                       "prompt_pass": r.get("prompt")},
             "hbm_fraction_of_8TBs_end_to_end": round(r["b_tok"] * tok_s / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline_block(args, args.model, args.mix, r),
         }
@@ -279,7 +294,7 @@ def main():
                                  "algorithmic_bytes_per_token": a["b_tok"],
                                  "frac": round(a["b_tok"] * a_tok_s / (HBM_PEAK_GBS * 1e9), 4),
                                  "gemv_launch_frac": rb["frac"], "gemv_avg_launch_us": rb["avg_launch_us"],
-                                 "gemv_launches_per_token": rb["launches_per_token"], "path": a["path"],
+                                 "gemv_launches_per_token": rb["launches_per_token"], "path": a["path"], "prompt_pass": a.get("prompt"),
                                  "load_seconds": round(a["t_load"], 2)})
                 except Exception as e:   # the headline must survive a problem in an extra workload
                     also.append({"workload": "%s %s" % (model, mix), "value": None, "error": repr(e)})
