@@ -446,9 +446,10 @@ def test_attention_prefill(T, start):
 
 
 @pytest.mark.parametrize("T,start,nh,nkv,hd", [(256, 0, 32, 8, 128), (256, 130, 32, 8, 128), (37, 5, 4, 2, 64), (33, 0, 8, 1, 128),
-                                               (96, 1000, 64, 8, 128), (1, 7, 8, 2, 128), (70, 3, 4, 4, 256)])
+                                               (96, 1000, 64, 8, 128), (1, 7, 8, 2, 128), (70, 3, 4, 4, 256), (523, 41, 32, 8, 128)])
 def test_attention_prefill_tiled_at_model_shapes(T, start, nh, nkv, hd):
-    """The flash-style prompt attention (32-query tiles, K/V tiles through LDS, online softmax; attention.hip) at the real
+    """The prompt attention kernels -- head_dim 128: the F16 matrix-core kernel (attention_mfma.hip: 64-query tiles, hi + lo
+    F16 splits of q and p); other head sizes: the flash-style VALU kernel (32-query tiles; attention.hip) -- at the real
     head counts and prompt lengths where the 1:1 kernel's score rows and (nh, T) grid get large: against the oracle's
     restatement of the reference's attention_prefill_kernel (attention.cu:216-311), causal limit start_pos + query index,
     ragged last tile, GQA groups 1 / 2 / 4 / 8, and against the 1:1 launcher on the same inputs."""
