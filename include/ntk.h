@@ -257,7 +257,7 @@ int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int ou
 /* The same projection on the BF16 matrix cores, up to 256 tokens per pass over W (csrc/gemm_bf16.hip): the integer part of every
  * weight is exact in BF16, every F32 activation is split into three exact BF16 pieces, products accumulate in F32 and the block
  * scales / K-quant minima are applied to the F32 block sums -- no operand is rounded, only the summation order differs from ntk_gemv.
- * Limits: Q8_0, Q4_K and Q6_K (NTK_E_DTYPE otherwise: use ntk_gemm_quant); in_features a multiple of the format's block (32 / 256),
+ * Limits: Q8_0, Q4_K, Q5_K and Q6_K (NTK_E_DTYPE otherwise: use ntk_gemm_quant); in_features a multiple of the format's block (32 / 256),
  * out_features % 16 == 0 and out_features * row_bytes < 4 GiB (NTK_E_SHAPE); W, X, Y, resid 16-byte aligned (NTK_E_ALIGN).
  * workspace: ntk_gemm_quant_workspace_bytes(in_features, out_features) device bytes, 16-byte aligned, shared by every call (BF16
  * planes of up to four 64-token chunks of X + the partial sums of the K splits); contents need no initialisation.

@@ -146,6 +146,29 @@ template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 pa
     }
 };
 
+template <> struct DeqI<NTK_DT_Q5_K> {   // types.h:122-128: half d, dmin; 12 packed 6-bit (scale, min); qh[32]; ql[128]
+    static constexpr int BW = 256, BB = 176;
+    static constexpr int SPU = 8, UB = 176, NCH = 11, STRIDE = 176;    // rows are 16-byte aligned: no shift
+    static constexpr bool SPLIT16 = false, HAS_MIN = true;
+    struct Hdr { u32x4 h; };   // d | dmin, 12 scale bytes
+    __device__ static Hdr header(const uint8_t* row) { return Hdr{*reinterpret_cast<const u32x4*>(row)}; }
+    __device__ static AOp step(const uint8_t* /*row*/, const uint8_t* rowg, const Hdr& hd, int j) {
+        float sc, mn;
+        kq_scale_min(hd.h.y, hd.h.z, hd.h.w, j, sc, mn);                       // gemm.cu:206-222 (same packing as Q4_K)
+        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu)), dmin = h2f((uint16_t)(hd.h.x >> 16));
+        const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
+        // fifth bit of column l of sub-block j: bit j of qh[l]   (gemm.cu:297-354: u1 = 1 << 2c, u2 = 2 << 2c)
+        const uint32_t lo = ((lds32(rowg + 48 + 32 * (j >> 1)) >> sh) & 0x0F0F0F0Fu) | (((lds32(rowg + 16) >> j) & 0x01010101u) << 4);
+        const uint32_t hi = ((lds32(rowg + 64 + 32 * (j >> 1)) >> sh) & 0x0F0F0F0Fu) | (((lds32(rowg + 32) >> j) & 0x01010101u) << 4);
+        AOp o;
+        o.a = u32x4{pack_bf16(ub2f(lo, 0), ub2f(lo, 1)), pack_bf16(ub2f(lo, 2), ub2f(lo, 3)),
+                    pack_bf16(ub2f(hi, 0), ub2f(hi, 1)), pack_bf16(ub2f(hi, 2), ub2f(hi, 3))};
+        o.s0 = o.s1 = d * sc;
+        o.mn = dmin * mn;
+        return o;
+    }
+};
+
 template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], int8 scales[16], half d
     static constexpr int BW = 256, BB = 210;
     static constexpr int SPU = 8, UB = 210, NCH = 14, STRIDE = 240;    // window: shift (even, <= 14) + 210 <= 224
@@ -536,7 +559,7 @@ int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int
     if (!Y || !W || !X || !workspace) return NTK_E_NULL;
     if (n_tokens < 0 || out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
-    if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
     constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
     if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (256 tokens) at a time
@@ -550,6 +573,7 @@ int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int
         switch (weight_dtype) {
             case NTK_DT_Q8_0: rc = ntk::launch_gemm_bf16<NTK_DT_Q8_0>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
             case NTK_DT_Q4_K: rc = ntk::launch_gemm_bf16<NTK_DT_Q4_K>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q5_K: rc = ntk::launch_gemm_bf16<NTK_DT_Q5_K>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
             default: rc = ntk::launch_gemm_bf16<NTK_DT_Q6_K>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
         }
         if (rc != NTK_OK) return rc;

@@ -141,7 +141,7 @@ def gemm_ws_gpu(Wraw, X, out_f, in_f, dt, resid=None):
     return Yd.numpy(np.float32).reshape(T, out_f)
 
 
-@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048),
                                           (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672)])
 def test_gemm_quant_bf16_matches_per_token_oracle(qname, T, out_f, in_f):
@@ -177,7 +177,7 @@ def test_gemm_quant_bf16_full_size_and_rejections():
         ref = O.gemv(W, X[t], out_f, in_f, G.GGML_TO_DT[gt])
         assert np.abs(Y[t] - ref).max() <= tol_for(ref, in_f)
     Wd, Xd, Yd = DB.zeros(1 << 16), DB.zeros(1 << 16), DB.zeros(1 << 16)
-    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_Q5_K) == -1      # format outside the BF16 path: caller uses ntk_gemm_quant
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_Q4_0) == -1      # format outside the BF16 path: caller uses ntk_gemm_quant
     assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 10, 256, G.DT_Q8_0) == -2      # out_features not a multiple of 16
 
 
