@@ -40,7 +40,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GB_TOK = 64;           // tokens per pass
 constexpr int GB_MAX_SPLIT = 8;     // K splits x token chunks of one launch never exceed this (size of the partial-sum area)
-constexpr int GB_MAX_CHUNKS = 4;    // 64-token chunks per launch
+constexpr int GB_MAX_CHUNKS = 8;    // 64-token chunks per launch
 constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
 constexpr int GB_STEP_BYTES = 3 * 4 * GB_PIECE;           // 12 KB of B operands per step
 
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(float* __restrict__ 
 // one chunk's planes + sums (+ the record of zeros), rounded to 256 B
 static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * (GB_STEP_BYTES + GB_TOK * sizeof(float)) + 255) / 256 * 256; }
 
-// T <= GB_MAX_CHUNKS * 64 tokens in one launch
+// T <= GB_MAX_CHUNKS * 64 = 512 tokens in one launch
 template <int DT>
 static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int out, int in, const float* resid, void* ws, int reuse_x,
                             hipStream_t st) {
@@ -562,9 +562,9 @@ int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int
     if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
     constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
-    if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (256 tokens) at a time
+    if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (512 tokens) at a time
     hipStream_t st = ntk::resolve_stream(stream);
-    for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 4 x 64 tokens per launch: the chunks share the weights in L2
+    for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 8 x 64 tokens per launch: the chunks share the weights in L2
         const int T = std::min(PASS, n_tokens - t0);
         float* y = Y + (size_t)t0 * out_features;
         const float* x = X + (size_t)t0 * in_features;
