@@ -11,12 +11,12 @@ timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench.err; cat $OU
 timeout 600 python tools/prefill_bench.py > $OUT/prefill_bench.txt 2>&1; grep "prompt of" $OUT/prefill_bench.txt
 timeout 600 python tools/prefill_bench.py --no-kernels --mix Q4_K_M > $OUT/prefill_bench_q4_k_m.txt 2>&1; grep "prompt of" $OUT/prefill_bench_q4_k_m.txt
 prof() { name=$1; shift; ( cd /tmp && timeout 600 rocprofv3 "$@" > $R/$OUT/$name.json 2> $R/$OUT/$name.err ); echo "$name exit $?"; }
-prof trace --kernel-trace --stats -d $R/$OUT/trace -o bench -- python $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-also
+prof trace --kernel-trace --stats -d $R/$OUT/trace -o bench -- python $R/bench.py --steps 32 --warmup 4 --no-cpu-baseline --no-also --prompt-bench 0
 [ -f $OUT/trace/bench_results.db ] && python tools/prof_summary.py $OUT/trace/bench_results.db > $OUT/summary_trace.txt && cat $OUT/summary_trace.txt
-prof pmc_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -o bench -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph
-prof pmc_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -o bench -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph
-prof pmc_fetch_q4km --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch_q4km -o bench -- python $R/bench.py --mix Q4_K_M --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph
-prof pmc_write_q4km --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write_q4km -o bench -- python $R/bench.py --mix Q4_K_M --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph
+prof pmc_fetch --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch -o bench -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph --prompt-bench 0
+prof pmc_write --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write -o bench -- python $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph --prompt-bench 0
+prof pmc_fetch_q4km --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$OUT/pmc_fetch_q4km -o bench -- python $R/bench.py --mix Q4_K_M --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph --prompt-bench 0
+prof pmc_write_q4km --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$OUT/pmc_write_q4km -o bench -- python $R/bench.py --mix Q4_K_M --steps 8 --warmup 2 --no-cpu-baseline --no-also --no-graph --prompt-bench 0
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 F2=$(ls $OUT/pmc_fetch_q4km/*counter_collection.csv 2>/dev/null | head -1); W2=$(ls $OUT/pmc_write_q4km/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$F2" ] && python tools/pmc_summary.py $F2 $W2 --json $OUT/pmc_traffic.json --key 8b_q4_k_m > $OUT/pmc_summary_q4km.txt 2>&1; cat $OUT/pmc_summary_q4km.txt
