@@ -189,7 +189,7 @@ __device__ __forceinline__ u32x4 asm_load16_sc1(const void* base, unsigned off) 
     return v;
 }
 
-template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false>
+template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false, bool XI = false>
 __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int bid, const int nblk) {   // workgroup bid of nblk
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
@@ -270,6 +270,8 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     // ---- prologue: this lane's 64 activations into registers (through a padded LDS image: coalesced
     //      global reads, conflict-free ds_read_b128), optional RMSNorm (reference rmsnorm.cu:16-70) ----
     f32x2 x2[32];   // the lane's 64 activations as 32 (even, odd) pairs
+    XInt xi;         // ... or (XI) as integer byte planes (gemv_core.hip.h)
+    static_assert(!XI || (XFAST && A16 && !ATT && DT == NTK_DT_Q4_K), "integer activations: aligned fast prologue of the Q4_K rows");
     {
         // The activations reach registers through a padded LDS image holding ALL slices: image row (sp*64 + l)
         // = the 64 columns lane l of slice sp owns (pitch 68 floats: conflict-free ds_read_b128).
@@ -353,6 +355,70 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                     xv[i].w = __float_as_uint(__uint_as_float(xv[i].w) * rms_inv * __uint_as_float(wv[i].w));
                 }
             }
+            if constexpr (XI) {
+                // Integer planes instead of floats (host: in <= XIT * step, ns <= GS, so the registers cover the row).  Image row
+                // (same 272-byte pitch as the float image: conflict-free b128 reads) = [plane 0: 64 B][plane 1][plane 2][2^(e-22) of
+                // the row's two sub-blocks, their sums of x].  A thread holds 4 consecutive columns per register quad, 8 consecutive
+                // threads hold a 32-column sub-block: its exponent and sum come from three DPP steps.
+                uint8_t* dimg = smem;
+#pragma unroll
+                for (int i = 0; i < XIT; ++i) {
+                    const int c = tid * 4 + i * step;
+                    const bool live = c < p.in;
+                    const float v0 = live ? __uint_as_float(xv[i].x) : 0.0f, v1 = live ? __uint_as_float(xv[i].y) : 0.0f,
+                                v2 = live ? __uint_as_float(xv[i].z) : 0.0f, v3 = live ? __uint_as_float(xv[i].w) : 0.0f;
+                    float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+                    am = fmaxf(am, dpp_or_self<DPP_QUAD_1032, 0xF>(am));
+                    am = fmaxf(am, dpp_or_self<DPP_QUAD_2301, 0xF>(am));
+                    am = fmaxf(am, dpp_or_self<DPP_ROW_HALF_MIRROR, 0xF>(am));
+                    float sm = (v0 + v1) + (v2 + v3);
+                    sm += dpp_or_zero<DPP_QUAD_1032, 0xF>(sm);
+                    sm += dpp_or_zero<DPP_QUAD_2301, 0xF>(sm);
+                    sm += dpp_or_zero<DPP_ROW_HALF_MIRROR, 0xF>(sm);
+                    const int e = am > 0.0f ? __builtin_amdgcn_frexp_expf(am) : 0;   // am = m * 2^e, 0.5 <= m < 1
+                    const float up = __builtin_ldexpf(1.0f, 22 - e), inv = __builtin_ldexpf(1.0f, e - 22);
+                    // rint through the magic constant 1.5 * 2^23: the low mantissa bits ARE the two's-complement integer
+                    const uint32_t x0 = __float_as_uint(fmaf(v0, up, 12582912.0f)) - 0x4B400000u, x1 = __float_as_uint(fmaf(v1, up, 12582912.0f)) - 0x4B400000u,
+                                   x2i = __float_as_uint(fmaf(v2, up, 12582912.0f)) - 0x4B400000u, x3 = __float_as_uint(fmaf(v3, up, 12582912.0f)) - 0x4B400000u;
+                    // 4 x 3 byte transpose: planes of the four columns
+                    const uint32_t ta = __builtin_amdgcn_perm(x1, x0, 0x05010400u);    // x0.b0 x1.b0 x0.b1 x1.b1
+                    const uint32_t tb = __builtin_amdgcn_perm(x1, x0, 0x07030602u);    // x0.b2 x1.b2 x0.b3 x1.b3
+                    const uint32_t tc = __builtin_amdgcn_perm(x3, x2i, 0x05010400u);
+                    const uint32_t td = __builtin_amdgcn_perm(x3, x2i, 0x07030602u);
+                    const uint32_t p0 = __builtin_amdgcn_perm(tc, ta, 0x05040100u);    // b0 of columns 0..3
+                    const uint32_t p1 = __builtin_amdgcn_perm(tc, ta, 0x07060302u);    // b1
+                    const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u);    // b2 (signed top byte)
+                    if (live) {
+                        const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
+                        uint8_t* row = dimg + (size_t)(sp * 64 + (cc >> 6)) * (XPITCH * 4);
+                        *reinterpret_cast<uint32_t*>(row + (cc & 63)) = p0;
+                        *reinterpret_cast<uint32_t*>(row + 64 + (cc & 63)) = p1;
+                        *reinterpret_cast<uint32_t*>(row + 128 + (cc & 63)) = p2;
+                        if ((cc & 31) == 0) {   // first thread of the sub-block
+                            float* meta = reinterpret_cast<float*>(row + 192);
+                            meta[(cc >> 5) & 1] = inv;
+                            meta[2 + ((cc >> 5) & 1)] = sm;
+                        }
+                    }
+                }
+                __syncthreads();
+                {
+                    const uint8_t* row = dimg + (size_t)(s * 64 + lane) * (XPITCH * 4);
+                    const bool have_lo_ = ncols > 0, have_hi_ = ncols > 32;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(row + 64 * pl + 16 * k4);
+                            const bool have = k4 < 2 ? have_lo_ : have_hi_;
+                            xi.d[pl][4 * k4] = have ? v.x : 0u; xi.d[pl][4 * k4 + 1] = have ? v.y : 0u;
+                            xi.d[pl][4 * k4 + 2] = have ? v.z : 0u; xi.d[pl][4 * k4 + 3] = have ? v.w : 0u;
+                        }
+                    const float4 mt = *reinterpret_cast<const float4*>(row + 192);
+                    xi.inv[0] = have_lo_ ? mt.x : 0.0f; xi.inv[1] = have_hi_ ? mt.y : 0.0f;
+                    xi.sx[0] = have_lo_ ? mt.z : 0.0f; xi.sx[1] = have_hi_ ? mt.w : 0.0f;
+                }
+            } else
             {   // pass 0 (the only one up to 16384 columns): straight-line, the registers die here
                 const int cend = min(p.in, GS * p.slice_cols);
 #pragma unroll
@@ -397,7 +463,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 if (s >= g0 && s < g0 + GS) read_own_row(g0);
             }
         }
-        if (kAblate & 1) {
+        if ((kAblate & 1) || XI) {   // (XI: x2 is not used; give the dead code below defined inputs)
 #pragma unroll
             for (int j = 0; j < 32; ++j) x2[j] = f32x2{1.0f, 1.0f};
         }
@@ -470,7 +536,9 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         }
         __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
         if (q + 1 < n_my) { cursor_advance(); issue(); }   // next row's bytes fly while this one is decoded
-        const float acc = (kAblate & 2) ? x2[0].x + (float)q : Dot<DT, A16>::run(stage, shift, lane, ncols, x2, sx16, sx32);
+        float acc;
+        if constexpr (XI) acc = DotI<DT>::run(stage, lane, ncols, xi);
+        else acc = (kAblate & 2) ? x2[0].x + (float)q : Dot<DT, A16>::run(stage, shift, lane, ncols, x2, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
         const float tot = wave_sum_lane63(acc);   // valid in lane 63
 
@@ -521,6 +589,11 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_att_kernel(cons
 template <int DT, bool NORM, bool XFAST, bool A16>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
     gemv_quant_body<DT, NORM, XFAST, A16>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+// integer-activation form (Q4_K, aligned fast prologue, rows of <= 16384 columns): gemv_core.hip.h XInt / DotI
+template <int DT, bool NORM>
+__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_xi_kernel(const GemvParams p) {
+    gemv_quant_body<DT, NORM, true, true, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Two weight formats in ONE launch (llama.cpp's Q4_K_M stores attn_v as Q6_K / Q5_K next to Q4_K attn_q / attn_k): the first
@@ -656,6 +729,9 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     return NTK_OK;
 }
 
+// smallest launch (bytes of weights) that takes the integer-activation form of the Q4_K GEMV; ntk_gemv_tune_xi_min_bytes moves it
+static size_t g_xi_min_bytes = (size_t)96 << 20;
+
 static int max_workgroups() {
     static const int max_wg = [] { const char* e = getenv("NTK_GEMV_MAX_WG"); return e ? std::max(1, atoi(e)) : 512; }();
     return max_wg;
@@ -687,6 +763,24 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
         if (!once || L.lds > 160 * 1024) return NTK_E_SHAPE;
     }
     const dim3 g(L.grid), b(64 * L.nwaves);
+    if constexpr (DT == NTK_DT_Q4_K) {
+        static const bool xi_off = [] { const char* e = getenv("NTK_GEMV_NO_XI"); return e && atoi(e) != 0; }();
+        // the integer-activation form: registers of the fast prologue cover the row, one image pass
+        // ... and only the launches that are VALU-bound gain: long ones (measured, tools/gemv_bench.py: 70B gate|up 54.7 -> 50.1 us,
+        // Q4_K LM head 58.3 -> 55.4; launches under ~100 MB are latency-bound and only pay the conversion in the prologue)
+        const size_t launch_bytes = (size_t)L.p.total_rows * (silu_pair ? 2 : 1) * L.p.row_bytes;
+        if (!xi_off && L.xfast && L.a16 && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves && launch_bytes >= g_xi_min_bytes) {
+            using XFn = void (*)(const GemvParams);
+            static const XFn xt[2] = {gemv_quant_xi_kernel<DT, false>, gemv_quant_xi_kernel<DT, true>};
+            if (L.lds > 64 * 1024) {
+                static bool once2 = hipFuncSetAttribute((const void*)xt[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                                    hipFuncSetAttribute((const void*)xt[1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                if (!once2) return NTK_E_SHAPE;
+            }
+            hipLaunchKernelGGL(xt[norm_w ? 1 : 0], g, b, L.lds, st, L.p);
+            return last_launch_status();
+        }
+    }
     hipLaunchKernelGGL(table[norm_w ? 1 : 0][L.xfast ? 1 : 0][L.a16 ? 1 : 0], g, b, L.lds, st, L.p);
     return last_launch_status();
 }
@@ -766,6 +860,8 @@ static int launch_dense(float* y, const void* W, const float* x, int out, int in
 }  // namespace ntk
 
 extern "C" {
+
+void ntk_gemv_tune_xi_min_bytes(size_t bytes) { ntk::g_xi_min_bytes = bytes; }
 
 int ntk_gemv(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype, void* stream) {
     if (!y || !W || !x) return NTK_E_NULL;

@@ -227,6 +227,51 @@ template <bool A16> struct Dot<NTK_DT_Q4_K, A16> {   // reference gemm.cu:190-24
     }
 };
 
+// ---- integer activations (round 2): the lane's 64 activations as three byte planes per 32-column sub-block ------------------
+// x_k ~ X_k * 2^(e-22) with X_k = rint(x_k * 2^(22-e)), e = exponent of the sub-block's largest |x| (so |X_k| < 2^22: the error per
+// term, 2^-23 of that maximum, is at the level of the F32 rounding of the sub-block sum it replaces).  X_k in two's complement
+// = b0 + 256 b1 + 65536 s2 with b0, b1 unsigned bytes and s2 the signed top byte: plane p of four consecutive columns is one dword,
+// and sum_k n_k X_k = udot4(n, b0) + 256 udot4(n, b1) + 65536 sdot4(n, s2) -- v_dot4_u32_u8 / v_dot4_i32_i8 issue at the rate of
+// the byte converts (profiles/r02_valu_issue_rates.txt), so 8 weights cost 3 mask operations + 6 dot instructions instead of 2 masks
+// + 8 converts + 4 packed FMAs.  The planes are built once per workgroup in the prologue's LDS image (gemv.hip).
+struct XInt {
+    uint32_t d[3][16];   // [plane][dword j]: columns 4j .. 4j+3 of the lane's 64 (j < 8: first sub-block, j >= 8: second)
+    float inv[2];        // 2^(e-22) of the two sub-blocks
+    float sx[2];         // their sums of x (K-quant minimum term)
+};
+template <int DT> struct DotI;
+
+template <> struct DotI<NTK_DT_Q4_K> {   // reference gemm.cu:190-244 (rows 16-byte aligned: the A16 form)
+    __device__ static float run(const uint8_t* st, int lane, int ncols, const XInt& xi) {
+        if (ncols <= 0) return 0.0f;
+        const int c = lane & 3, ob = 144 * (lane >> 2);
+        float d1, m1, d2, m2;
+        kq_header<true>(st, ob, c, d1, m1, d2, m2);
+        uint32_t q[8];
+        lds_read_q<8, true>(q, st, ob + 16 + 32 * c);
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        int a2 = 0, b2 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t lo = q[i] & 0x0F0F0F0Fu, hi = (q[i] >> 4) & 0x0F0F0F0Fu;   // sub-block 2c / 2c + 1, columns 4i .. 4i+3
+            a0 = __builtin_amdgcn_udot4(lo, xi.d[0][i], a0, false);
+            a1 = __builtin_amdgcn_udot4(lo, xi.d[1][i], a1, false);
+            a2 = __builtin_amdgcn_sdot4((int)lo, (int)xi.d[2][i], a2, false);
+            b0 = __builtin_amdgcn_udot4(hi, xi.d[0][8 + i], b0, false);
+            b1 = __builtin_amdgcn_udot4(hi, xi.d[1][8 + i], b1, false);
+            b2 = __builtin_amdgcn_sdot4((int)hi, (int)xi.d[2][8 + i], b2, false);
+        }
+        // every partial sum is below 2^24: exact as a float; the planes recombine with two FMAs
+        const float fa = fmaf(65536.0f, (float)a2, fmaf(256.0f, (float)a1, (float)a0)) * xi.inv[0];
+        const float fb = fmaf(65536.0f, (float)b2, fmaf(256.0f, (float)b1, (float)b0)) * xi.inv[1];
+        float t = d1 * fa;
+        t = fmaf(-m1, xi.sx[0], t);
+        t = fmaf(d2, fb, t);
+        t = fmaf(-m2, xi.sx[1], t);
+        return t;
+    }
+};
+
 template <bool A16> struct Dot<NTK_DT_Q5_K, A16> {   // reference gemm.cu:297-354
     __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const f32x2 (&x2)[32],
                                 const float (&)[4], const float (&sx32)[2]) {

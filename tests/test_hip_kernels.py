@@ -298,6 +298,45 @@ def test_gemv_fused_norm_qkv(qname, in_f, rows):
         assert np.abs(yd[i].numpy() - refs[i]).max() <= 2 * tol_for(refs[i], in_f)
 
 
+@pytest.mark.parametrize("out_f,in_f,norm,resid,silu", [(64, 256, False, False, False), (300, 4096, True, False, False), (257, 4096, False, True, False),
+                                                       (1024, 8192, True, False, True), (96, 2048, False, False, True), (40, 8192, False, True, False)])
+def test_gemv_q4_k_integer_activation_form(out_f, in_f, norm, resid, silu):
+    """The integer-activation form of the Q4_K GEMV (activations as three int8 digit planes per 32-column sub-block, products on
+    v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 96 MiB -- forced for every eligible launch and
+    compared with the oracle at the GEMV's tolerance: plain, RMSNorm prologue, residual epilogue, gate|up + SiLU."""
+    from ntransformer_amd import _lib
+    L = _lib.lib()
+    L.ntk_gemv_tune_xi_min_bytes.argtypes = [C.c_size_t]
+    L.ntk_gemv_tune_xi_min_bytes.restype = None
+    gt = G.GGML_Q4_K
+    dt = G.GGML_TO_DT[gt]
+    r = rng(out_f + in_f + 3 * norm + 5 * resid + 7 * silu)
+    x = (r.standard_normal(in_f) * np.exp(r.uniform(-3, 3, in_f))).astype(np.float32)   # wide dynamic range inside every sub-block
+    nw = (1.0 + 0.1 * r.standard_normal(in_f)).astype(np.float32)
+    xin = O.rmsnorm(x[None, :], nw, 1e-5)[0] if norm else x
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    W2 = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    R = r.standard_normal(out_f).astype(np.float32)
+    ref = O.gemv(W, xin, out_f, in_f, dt)
+    if silu:
+        up = O.gemv(W2, xin, out_f, in_f, dt)
+        ref = (ref / (1.0 + np.exp(-ref.astype(np.float64))) * up).astype(np.float32)
+    if resid: ref = ref + R
+    L.ntk_gemv_tune_xi_min_bytes(0)
+    try:
+        xd, nwd = DB.from_numpy(x), DB.from_numpy(nw)
+        yd = DB.from_numpy(R.copy() if resid else np.full(out_f, np.nan, np.float32))
+        y2 = DB.zeros(out_f * 4)
+        Wd, W2d = DB.from_numpy(W), DB.from_numpy(W2)
+        segs = [(Wd, yd, out_f, dt)] + ([(W2d, y2, out_f, dt)] if silu else [])
+        ops.gemv_fused(segs, xd, in_f, norm_w=nwd if norm else None, eps=1e-5, resid=yd if resid else None, silu_pair=silu)
+        got = yd.numpy()
+    finally:
+        L.ntk_gemv_tune_xi_min_bytes(96 << 20)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= tol_for(ref, in_f) * (4 if silu else 1), np.abs(got - ref).max()
+
+
 @pytest.mark.parametrize("other", ["Q6_K", "Q5_K"])
 @pytest.mark.parametrize("norm", [True, False])
 @pytest.mark.parametrize("in_f,rows", [(256, (64, 32, 32)), (4096, (4096, 1024, 1024)), (8192, (8192, 1024, 1024))])
