@@ -46,7 +46,6 @@ __global__ __launch_bounds__(256) void tp_allreduce_add_kernel(const TpArgs a) {
     const unsigned slot = a.call_index & 1u;
     uint8_t* mine = a.base[a.rank];
     const unsigned expected = *reinterpret_cast<const unsigned*>(mine + 192) * 1024u + a.call_index + 1u;
-    __shared__ int tp_ok;
     if (threadIdx.x == 0) {
         // this rank's partial vector was written by the previous kernel on this stream: it is in memory.  Publish, then wait.
         if (blockIdx.x == 0) __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 64 * slot), expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -59,9 +58,8 @@ __global__ __launch_bounds__(256) void tp_allreduce_add_kernel(const TpArgs a) {
             if (!budget) ok = 0;
         }
         if (!ok) __hip_atomic_store(reinterpret_cast<unsigned*>(mine + 128), expected, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        tp_ok = ok;
     }
-    __syncthreads();
+    __syncthreads();   // the workgroup proceeds once thread 0 has seen every peer (or given up: the error word says so)
     const size_t data_off = TP_HDR + (size_t)slot * a.max_floats * sizeof(float);
     for (size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; idx < (size_t)a.n; idx += (size_t)gridDim.x * 256 * 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(a.hidden + idx);
