@@ -269,6 +269,10 @@ int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int ou
  * reuse_x != 0: X (same pointer, n_tokens <= 512) has not changed since the previous call with this workspace -- its planes are
  * not rebuilt (Q, K, V / gate, up share x).  Stream ordered, no allocation, no synchronisation. */
 size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features);
+/* ... and several matrices of ONE format that share X (Q | K | V, gate | up) as one launch: segs[i] = {W_i, Y_i [n_tokens][rows_i],
+ * rows_i, dtype}; <= 3 segments, no residual.  workspace sized for (in_features, sum of rows_i). */
+int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                            size_t workspace_bytes, int reuse_x, void* stream);
 int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features,
                       int weight_dtype, const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream);
 

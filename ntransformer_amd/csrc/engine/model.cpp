@@ -331,8 +331,9 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     h_token_ = (int*)nt_hip_malloc_host(64);
     sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
     attn_sync_ = (unsigned*)dev(4096, true);
-    gemm_ws_bytes_ = ntk_gemm_quant_workspace_bytes(std::max(cfg_.hidden_size, cfg_.intermediate_size),
-                                                    std::max({cfg_.hidden_size, cfg_.intermediate_size, cfg_.n_heads * cfg_.head_dim}));
+    gemm_ws_bytes_ = ntk_gemm_quant_workspace_bytes(std::max(cfg_.hidden_size, cfg_.intermediate_size),   // (Q|K|V and gate|up go out as one launch)
+                                                    std::max({cfg_.hidden_size, 2 * cfg_.intermediate_size,
+                                                              (cfg_.n_heads + 2 * cfg_.n_kv_heads) * cfg_.head_dim}));
     gemm_ws_ = dev(gemm_ws_bytes_, false);
     if (const char* e = getenv("NTK_BF16_PREFILL")) bf16_prefill_ = atoi(e) != 0;   // [0] heads done, [1] finished, [2] error, [64 + 64 g] release flags
     if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
@@ -424,6 +425,25 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         }
         for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, X + (size_t)t * xstride);
     };
+    // matrices that share X (Q | K | V, gate | up): those of one format go out as ONE launch of the BF16 GEMM, the rest one by one
+    auto project_many = [&](float* const* Ys, const DevTensor* const* Ws, int n, const float* X) {
+        bool done[3] = {false, false, false};
+        if (batched && bf16_now) {
+            for (int a = 0; a < n; ++a) {
+                if (done[a]) continue;
+                ntk_gemv_seg segs[3];
+                int idx[3], m = 0;
+                for (int b = a; b < n; ++b)
+                    if (!done[b] && Ws[b]->dtype == Ws[a]->dtype && Ws[b]->in_f == Ws[a]->in_f) { segs[m] = {Ws[b]->ptr, Ys[b], (int)Ws[b]->out_f, Ws[b]->dtype}; idx[m++] = b; }
+                if (m < 2) continue;
+                const int st = ntk_gemm_quant_ws_multi(segs, m, X, T, (int)Ws[a]->in_f, gemm_ws_, gemm_ws_bytes_, X == planes_of ? 1 : 0, s);
+                if (st == NTK_OK) { planes_of = X; for (int k = 0; k < m; ++k) done[idx[k]] = true; }
+                else if (st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) { ok(st); return; }
+            }
+        }
+        for (int a = 0; a < n; ++a)
+            if (!done[a]) project(Ys[a], *Ws[a], X, (size_t)Ws[a]->out_f, (size_t)Ws[a]->in_f);
+    };
     // hidden += W . X (attention.cpp:207 + transformer.cpp:645, ffn.cpp:130 + transformer.cpp:652): the batched
     // projection adds the residual in its epilogue, the reference sequence goes through residual_ and launch_add_inplace
     auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
@@ -451,9 +471,11 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
         ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.attn_norm.ptr, T, H, cfg_.norm_eps, s));
         planes_of = nullptr;   // residual_ has new contents
-        project(q_buf, L.wq, residual_, qd, H);
-        project(k_buf, L.wk, residual_, kvd, H);
-        project(v_buf, L.wv, residual_, kvd, H);
+        {
+            float* const ys[3] = {q_buf, k_buf, v_buf};
+            const DevTensor* const ws[3] = {&L.wq, &L.wk, &L.wv};
+            project_many(ys, ws, 3, residual_);
+        }
         ok(ntk_rope(q_buf, k_buf, positions_, 1, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, s));
         ok(ntk_copy_to_kv_cache(kc, vc, k_buf, v_buf, T, nkv, hd, start_pos, cfg_.max_seq_len, s));
         if (T == 1) ok(ntk_attention_decode(attn_out, q_buf, kc, vc, start_pos + T, nh, nkv, hd, cfg_.max_seq_len, scale, s));
@@ -461,8 +483,11 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         project_add(L.wo, attn_out, qd);
         ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.ffn_norm.ptr, T, H, cfg_.norm_eps, s));
         planes_of = nullptr;
-        project(gate_buf, L.w_gate, residual_, I, H);
-        project(up_buf, L.w_up, residual_, I, H);
+        {
+            float* const ys[2] = {gate_buf, up_buf};
+            const DevTensor* const ws[2] = {&L.w_gate, &L.w_up};
+            project_many(ys, ws, 2, residual_);
+        }
         ok(ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s));   // per token in the reference (ffn.cpp:127): same elementwise op
         project_add(L.w_down, gate_buf, I);
         if (rc != NTK_OK) break;

@@ -199,18 +199,24 @@ constexpr int GB_XS_OFF = GB_SLOTS * GB_STEP_BYTES;   // then [GB_SLOTS][64] flo
 constexpr int GB_STAGE_OFF = GB_XS_OFF + GB_SLOTS * GB_TOK * 4;   // then the 4 waves' weight images
 template <int DT, int RT> constexpr int gb_lds_bytes() { return GB_STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE; }
 
-struct GemmBParams {
+constexpr int GB_MAX_SEG = 3;   // matrices sharing X in one launch (Q | K | V, gate | up)
+struct GemmBSeg {
     const uint8_t* W;
+    float* Y;               // [T][out]
+    float* part;            // K split: [split][T][out] partial sums of this matrix
+    int out, tile0;         // rows; first row tile of this matrix in the launch's tile numbering
+    unsigned w_last;        // out * row_bytes - 16: the last 16-byte piece of the matrix (requests past the end re-read it)
+};
+struct GemmBParams {
+    GemmBSeg seg[GB_MAX_SEG];
+    int nseg;
     const uint8_t* xb;      // operand planes [steps][3][4][64] x 16 B
     const float* xsum;      // [steps][64]
-    float* Y;               // [T][out]
-    const float* resid;     // optional [T][out], may alias Y
-    int T, out, in, steps;  // T = tokens of the launch (<= 64 chunks)
+    const float* resid;     // optional [T][out] (single matrix only), may alias Y
+    int T, in, steps;       // T = tokens of the launch (<= 8 chunks of 64)
     unsigned row_bytes;
-    unsigned w_last;        // out * row_bytes - 16: the last 16-byte piece of the matrix (requests past the end re-read it)
-    int nsplit, steps_per_split;   // blockIdx.y = K split; nsplit > 1: partial sums go to `part` [split][T][out], summed by reduce_splits
-    float* part;
-    int chunks, row_wgs;    // 64-token chunks of this launch (blockIdx.x enumerates (row tile, chunk), see below); row tiles
+    int nsplit, steps_per_split;   // blockIdx.y = K split; nsplit > 1: partial sums go to seg.part, summed by reduce_splits
+    int chunks, row_wgs;    // 64-token chunks of this launch (blockIdx.x enumerates (row tile, chunk), see below); row tiles of all matrices
     size_t chunk_bytes;     // between the planes (and sums) of consecutive chunks
 };
 
@@ -252,8 +258,17 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
     const int xcd = bid & 7, within = bid >> 3;
     const int chunk = within % p.chunks, tile = (within / p.chunks) * 8 + xcd;
     if (tile >= p.row_wgs) return;   // row tiles are padded to a multiple of 8
+    // which matrix of the launch this row tile belongs to (workgroup-uniform)
+    int sidx = 0;
+    if (p.nseg > 1 && tile >= p.seg[1].tile0) sidx = 1;
+    if (p.nseg > 2 && tile >= p.seg[2].tile0) sidx = 2;
+    const uint8_t* const segW = p.seg[sidx].W;
+    float* const segY = p.seg[sidx].Y;
+    float* const segPart = p.seg[sidx].part;
+    const int seg_out = p.seg[sidx].out;
+    const unsigned seg_w_last = p.seg[sidx].w_last;
     const int Tc = min(GB_TOK, p.T - chunk * GB_TOK);
-    const int row0 = (tile * 4 + wave) * ROWS;
+    const int row0 = ((tile - p.seg[sidx].tile0) * 4 + wave) * ROWS;
     f32x4 acc[RT][4];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
         const int q = min(64 * n + lane, PIECES - 1), r = q / NCH, c = q - r * NCH;
-        w_row[n] = (uint32_t)min(row0 + r, p.out - 1) * p.row_bytes;
+        w_row[n] = (uint32_t)min(row0 + r, seg_out - 1) * p.row_bytes;
         w_c16[n] = 16u * c;
         s_off[n] = (uint32_t)(r * STRIDE + 16 * c);
     }
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
         const uint32_t uoff = (uint32_t)(unit_lo + min(urel, nunits - 1)) * D::UB;
 #pragma unroll
         for (int n = 0; n < NLD; ++n)
-            ring[k][n] = *reinterpret_cast<const u32x4*>(p.W + min(((w_row[n] + uoff) & ~15u) + w_c16[n], p.w_last));
+            ring[k][n] = *reinterpret_cast<const u32x4*>(segW + min(((w_row[n] + uoff) & ~15u) + w_c16[n], seg_w_last));
     };
     auto stage_unit = [&](int k) {
 #pragma unroll
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         img[rt] = stage + (rt * 16 + i) * STRIDE;
-        my_row[rt] = (uint32_t)min(row0 + rt * 16 + i, p.out - 1) * p.row_bytes;
+        my_row[rt] = (uint32_t)min(row0 + rt * 16 + i, seg_out - 1) * p.row_bytes;
     }
     typename D::Hdr hdr[RT];
     const uint8_t* cur[RT];      // img + the staged unit's shift
@@ -443,14 +458,14 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int r = row0 + rt * 16 + i;
-        if (r >= p.out) continue;
+        if (r >= seg_out) continue;
         if (p.nsplit > 1) {   // K split: this workgroup's partial sums, combined (fixed order) by reduce_splits_kernel
 #pragma unroll
             for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int t = tb * 16 + 4 * g + e;
-                    if (t < Tc) p.part[((size_t)blockIdx.y * p.T + tok0 + t) * p.out + r] = acc[rt][tb][e];
+                    if (t < Tc) segPart[((size_t)blockIdx.y * p.T + tok0 + t) * seg_out + r] = acc[rt][tb][e];
                 }
             continue;
         }
@@ -460,31 +475,43 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_bf16_kernel(const GemmBPara
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = tb * 16 + 4 * g + e;
-                rs[tb][e] = (p.resid && t < Tc) ? p.resid[(tok0 + t) * p.out + r] : 0.0f;
+                rs[tb][e] = (p.resid && t < Tc) ? p.resid[(tok0 + t) * seg_out + r] : 0.0f;
             }
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = tb * 16 + 4 * g + e;
-                if (t < Tc) p.Y[(tok0 + t) * p.out + r] = acc[rt][tb][e] + rs[tb][e];
+                if (t < Tc) segY[(tok0 + t) * seg_out + r] = acc[rt][tb][e] + rs[tb][e];
             }
     }
 }
 
-// Y[t][r] = sum over splits (in order) of part[s][t][r] (+ resid): one float4 per thread
-__global__ __launch_bounds__(256) void reduce_splits_kernel(float* __restrict__ Y, const float* __restrict__ part, const float* __restrict__ resid,
-                                                            int T, int out, int nsplit) {
+// Y[t][r] = sum over splits (in order) of part[s][t][r] (+ resid): one float4 per thread, blockIdx.y = matrix of the launch
+struct ReduceArgs {
+    float* Y[GB_MAX_SEG];
+    const float* part[GB_MAX_SEG];
+    int out[GB_MAX_SEG];
+    const float* resid;
+    int nseg, T, nsplit;
+};
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const ReduceArgs a) {
+    const int sg = blockIdx.y;
+    float* Y = a.Y[0];
+    const float* part = a.part[0];
+    int out = a.out[0];
+    if (sg == 1) { Y = a.Y[1]; part = a.part[1]; out = a.out[1]; }
+    if (sg == 2) { Y = a.Y[2]; part = a.part[2]; out = a.out[2]; }
     const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (idx >= (size_t)T * out) return;
+    if (idx >= (size_t)a.T * out) return;
     float4 v = *reinterpret_cast<const float4*>(part + idx);
-    for (int s = 1; s < nsplit; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(part + (size_t)s * T * out + idx);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    for (int s = 1; s < a.nsplit; ++s) {
+        const float4 q = *reinterpret_cast<const float4*>(part + (size_t)s * a.T * out + idx);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
-    if (resid) {
-        const float4 a = *reinterpret_cast<const float4*>(resid + idx);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    if (a.resid) {
+        const float4 q = *reinterpret_cast<const float4*>(a.resid + idx);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
     }
     *reinterpret_cast<float4*>(Y + idx) = v;
 }
@@ -492,40 +519,53 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(float* __restrict__ 
 // one chunk's planes + sums (+ the record of zeros), rounded to 256 B
 static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * (GB_STEP_BYTES + GB_TOK * sizeof(float)) + 255) / 256 * 256; }
 
-// T <= GB_MAX_CHUNKS * 64 = 512 tokens in one launch
+struct HostSeg { float* Y; const void* W; int out; };
+
+// T <= GB_MAX_CHUNKS * 64 = 512 tokens in one launch; nseg matrices [out_s][in] of one format sharing X
 template <int DT>
-static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int out, int in, const float* resid, void* ws, int reuse_x,
+static int launch_gemm_bf16(const HostSeg* segs, int nseg, const float* X, int T, int in, const float* resid, void* ws, int reuse_x,
                             hipStream_t st) {
     using D = DeqI<DT>;
     constexpr int TRIP = GB_NR * D::SPU;   // steps per loop trip: K ranges are whole trips
-    if (in % D::BW != 0 || out % 16 != 0) return NTK_E_SHAPE;
+    if (nseg < 1 || nseg > GB_MAX_SEG || (resid && nseg != 1) || in % D::BW != 0) return NTK_E_SHAPE;
     const size_t row_bytes = (size_t)in / D::BW * D::BB;
-    if ((size_t)out * row_bytes > 0xFFFFFF00ull) return NTK_E_SHAPE;   // 32-bit piece offsets
-    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
-        (resid && (reinterpret_cast<uintptr_t>(resid) & 15)))
-        return NTK_E_ALIGN;
+    long out_total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].out <= 0 || segs[i].out % 16 != 0 || (size_t)segs[i].out * row_bytes > 0xFFFFFF00ull) return NTK_E_SHAPE;   // 32-bit piece offsets
+        if ((reinterpret_cast<uintptr_t>(segs[i].W) & 15) || (reinterpret_cast<uintptr_t>(segs[i].Y) & 15)) return NTK_E_ALIGN;
+        out_total += segs[i].out;
+    }
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (resid && (reinterpret_cast<uintptr_t>(resid) & 15))) return NTK_E_ALIGN;
     GemmBParams p{};
-    p.W = static_cast<const uint8_t*>(W);
-    p.T = T; p.out = out; p.in = in; p.steps = in / 32;
+    p.nseg = nseg;
+    p.T = T; p.in = in; p.steps = in / 32;
     p.chunks = (T + GB_TOK - 1) / GB_TOK;
     p.chunk_bytes = ws_chunk_bytes(in);
     p.row_bytes = (unsigned)row_bytes;
-    p.w_last = (unsigned)((size_t)out * row_bytes - 16);
     uint8_t* wsb = static_cast<uint8_t*>(ws);
     p.xb = wsb;
     p.xsum = reinterpret_cast<const float*>(wsb + (size_t)(p.steps + 1) * GB_STEP_BYTES);
-    p.part = reinterpret_cast<float*>(wsb + (size_t)GB_MAX_CHUNKS * p.chunk_bytes);
-    p.Y = Y; p.resid = resid;
+    p.resid = resid;
     if (!reuse_x)
         hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 1, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.xsum),
                            p.chunk_bytes);
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
-    // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) until the grid has about two workgroups per CU.
+    // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) while fewer than one workgroup per CU exists.
     static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
     static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 256; }();
-    int rt = out >= 2048 ? 2 : 1;
+    int rt = out_total >= 2048 ? 2 : 1;
     if (force_rt == 1 || force_rt == 2) rt = force_rt;
-    p.row_wgs = (out + 64 * rt - 1) / (64 * rt);
+    int tiles = 0;
+    float* part = reinterpret_cast<float*>(wsb + (size_t)GB_MAX_CHUNKS * p.chunk_bytes);
+    for (int i = 0; i < nseg; ++i) {
+        p.seg[i].W = static_cast<const uint8_t*>(segs[i].W);
+        p.seg[i].Y = segs[i].Y;
+        p.seg[i].out = segs[i].out;
+        p.seg[i].w_last = (unsigned)((size_t)segs[i].out * row_bytes - 16);
+        p.seg[i].tile0 = tiles;
+        tiles += (segs[i].out + 64 * rt - 1) / (64 * rt);
+    }
+    p.row_wgs = tiles;
     const int trips = (p.steps + TRIP - 1) / TRIP;
     int nsplit = 1;
     while (nsplit * 2 * p.chunks <= GB_MAX_SPLIT && p.row_wgs * p.chunks * nsplit < want_wgs && trips / (nsplit * 2) >= 1) nsplit *= 2;
@@ -533,13 +573,23 @@ static int launch_gemm_bf16(float* Y, const void* W, const float* X, int T, int 
     nsplit = (trips + tps - 1) / tps;                // no empty split
     p.nsplit = nsplit;
     p.steps_per_split = tps * TRIP;
+    for (int i = 0; i < nseg; ++i) {                 // partial-sum areas, one after the other: nsplit x T x out_i floats each
+        p.seg[i].part = part;
+        part += (size_t)nsplit * T * segs[i].out;
+    }
     const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
     const size_t lds2 = gb_lds_bytes<DT, 2>(), lds1 = gb_lds_bytes<DT, 1>();
     if (rt == 2) hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 2>), grid, dim3(256), lds2, st, p);
     else hipLaunchKernelGGL((gemm_quant_bf16_kernel<DT, 1>), grid, dim3(256), lds1, st, p);
     if (nsplit > 1) {
-        const size_t n4 = ((size_t)T * out + 3) / 4;
-        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, Y, (const float*)p.part, resid, T, out, nsplit);
+        ReduceArgs ra{};
+        ra.nseg = nseg; ra.T = T; ra.nsplit = nsplit; ra.resid = resid;
+        size_t biggest = 0;
+        for (int i = 0; i < nseg; ++i) {
+            ra.Y[i] = segs[i].Y; ra.part[i] = p.seg[i].part; ra.out[i] = segs[i].out;
+            biggest = std::max(biggest, ((size_t)T * segs[i].out + 3) / 4);
+        }
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((biggest + 255) / 256), nseg), dim3(256), 0, st, ra);
     }
     return last_launch_status();
 }
@@ -554,6 +604,28 @@ size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features) {
            (size_t)ntk::GB_MAX_SPLIT * ntk::GB_TOK * (size_t)out_features * sizeof(float) + 256;
 }
 
+static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, int n_tokens, int in_features, int weight_dtype, const float* resid,
+                            void* workspace, int reuse_x, hipStream_t st) {
+    constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
+    if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (512 tokens) at a time
+    for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 8 x 64 tokens per launch: the chunks share the weights in L2
+        const int T = std::min(PASS, n_tokens - t0);
+        ntk::HostSeg sg[ntk::GB_MAX_SEG];
+        for (int i = 0; i < nseg; ++i) sg[i] = ntk::HostSeg{segs[i].Y + (size_t)t0 * segs[i].out, segs[i].W, segs[i].out};
+        const float* x = X + (size_t)t0 * in_features;
+        const float* rs = resid ? resid + (size_t)t0 * segs[0].out : nullptr;
+        int rc;
+        switch (weight_dtype) {
+            case NTK_DT_Q8_0: rc = ntk::launch_gemm_bf16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q4_K: rc = ntk::launch_gemm_bf16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q5_K: rc = ntk::launch_gemm_bf16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            default: rc = ntk::launch_gemm_bf16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+        }
+        if (rc != NTK_OK) return rc;
+    }
+    return NTK_OK;
+}
+
 int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
                       const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream) {
     if (!Y || !W || !X || !workspace) return NTK_E_NULL;
@@ -561,24 +633,29 @@ int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
     if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
-    constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
-    if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (512 tokens) at a time
-    hipStream_t st = ntk::resolve_stream(stream);
-    for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 8 x 64 tokens per launch: the chunks share the weights in L2
-        const int T = std::min(PASS, n_tokens - t0);
-        float* y = Y + (size_t)t0 * out_features;
-        const float* x = X + (size_t)t0 * in_features;
-        const float* rs = resid ? resid + (size_t)t0 * out_features : nullptr;
-        int rc;
-        switch (weight_dtype) {
-            case NTK_DT_Q8_0: rc = ntk::launch_gemm_bf16<NTK_DT_Q8_0>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
-            case NTK_DT_Q4_K: rc = ntk::launch_gemm_bf16<NTK_DT_Q4_K>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
-            case NTK_DT_Q5_K: rc = ntk::launch_gemm_bf16<NTK_DT_Q5_K>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
-            default: rc = ntk::launch_gemm_bf16<NTK_DT_Q6_K>(y, W, x, T, out_features, in_features, rs, workspace, reuse_x, st); break;
-        }
-        if (rc != NTK_OK) return rc;
+    const ntk::HostSeg sg{Y, W, out_features};
+    return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, ntk::resolve_stream(stream));
+}
+
+// several matrices of one format sharing X (Q | K | V, gate | up) in ONE launch: segs[i] = {Y_i [n_tokens][rows_i], W_i, rows_i}
+// (ntk_gemv_seg: y, W, rows, dtype -- the dtypes must agree).  workspace: ntk_gemm_quant_workspace_bytes(in, sum of rows).
+int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                            size_t workspace_bytes, int reuse_x, void* stream) {
+    if (!segs || !X || !workspace) return NTK_E_NULL;
+    if (nseg < 1 || nseg > ntk::GB_MAX_SEG || n_tokens < 0 || in_features <= 0) return NTK_E_SHAPE;
+    ntk::HostSeg sg[ntk::GB_MAX_SEG];
+    long total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!segs[i].W || !segs[i].y) return NTK_E_NULL;
+        if (segs[i].rows <= 0 || segs[i].dtype != segs[0].dtype) return NTK_E_SHAPE;
+        sg[i] = ntk::HostSeg{segs[i].y, segs[i].W, segs[i].rows};
+        total += segs[i].rows;
     }
-    return NTK_OK;
+    const int dt = segs[0].dtype;
+    if (dt != NTK_DT_Q8_0 && dt != NTK_DT_Q4_K && dt != NTK_DT_Q5_K && dt != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, (int)total) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
+    if (n_tokens == 0) return NTK_OK;
+    return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, ntk::resolve_stream(stream));
 }
 
 }  // extern "C"

@@ -166,6 +166,20 @@ def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resi
                                     stream), "gemv_fused")
 
 
+def gemm_quant_ws_multi(segs, X, n_tokens, in_features, stream=None):
+    """ntk_gemm_quant_ws_multi: segs = [(W, Y, rows, dtype), ...] of one format sharing X, one launch (workspace allocated here)."""
+    L = _lib.lib()
+    L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+    total = sum(r for _, _, r, _ in segs)
+    n = int(L.ntk_gemm_quant_workspace_bytes(in_features, total))
+    ws = DeviceBuffer(n)
+    arr = (GemvSeg * len(segs))()
+    for i, (W, y, rows, dt) in enumerate(segs):
+        arr[i].W, arr[i].y, arr[i].rows, arr[i].dtype = _p(W), _p(y), rows, int(dt)
+    L.ntk_gemm_quant_ws_multi.argtypes = [C.POINTER(GemvSeg), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    return L.ntk_gemm_quant_ws_multi(arr, len(segs), _p(X), n_tokens, in_features, ws.ptr, n, 0, stream)
+
+
 def gemm_quant_ws(Y, W, X, n_tokens, out_features, in_features, dtype, resid=None, stream=None):
     """ntk_gemm_quant_ws: BF16-MFMA prompt projection, 64 tokens per pass (workspace allocated here)."""
     L = _lib.lib()

@@ -165,6 +165,32 @@ def test_gemm_quant_bf16_matches_per_token_oracle(qname, T, out_f, in_f):
     assert np.array_equal(Y2, (R + Y).astype(np.float32)) or np.abs(Y2 - (R + Y)).max() <= 1e-6 * np.abs(Y).max()
 
 
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("T,outs,in_f", [(20, (64, 32, 32), 512), (70, (4096, 1024, 1024), 4096), (300, (208, 208), 2048)])
+def test_gemm_quant_bf16_several_matrices_one_launch(qname, T, outs, in_f):
+    """Q | K | V and gate | up as ONE launch of the BF16 GEMM (ntk_gemm_quant_ws_multi): every matrix against its own
+    single-matrix launch, bit for bit (same tiles, same summation order), and against the oracle."""
+    gt = QUANT[qname]
+    dt = G.GGML_TO_DT[gt]
+    r = rng(T + sum(outs) + in_f + gt)
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    Ws = [np.frombuffer(G.synth_tensor(r, gt, o, in_f), np.uint8) for o in outs]
+    Xd = DB.from_numpy(X)
+    Wd = [DB.from_numpy(w) for w in Ws]
+    Yd = [DB.from_numpy(np.full((T, o), np.nan, np.float32)) for o in outs]
+    st = ops.gemm_quant_ws_multi([(Wd[i], Yd[i], outs[i], dt) for i in range(len(outs))], Xd, T, in_f)
+    assert st == 0, st
+    for i, o in enumerate(outs):
+        got = Yd[i].numpy(np.float32).reshape(T, o)
+        alone = gemm_ws_gpu(Ws[i], X, o, in_f, dt)
+        assert np.isfinite(got).all()
+        for t in (0, T // 2, T - 1):
+            ref = O.gemv(Ws[i], X[t], o, in_f, dt)
+            assert np.abs(got[t] - ref).max() <= tol_for(ref, in_f)
+        assert np.abs(got - alone).max() <= 1e-6 * max(1.0, np.abs(alone).max())   # (K split counts may differ between the two launches)
+    assert ops.gemm_quant_ws_multi([(Wd[0], Yd[0], outs[0], dt), (Wd[1], Yd[1], outs[1], G.DT_Q4_0)], Xd, T, in_f) == -2   # mixed formats
+
+
 def test_gemm_quant_bf16_full_size_and_rejections():
     """8B gate/up-sized matrix (14336 x 4096: the 2-row-tile geometry with 112 workgroups) and what the BF16 path refuses."""
     gt = G.GGML_Q8_0

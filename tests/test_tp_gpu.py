@@ -18,7 +18,7 @@ from test_oracle_golden import golden_model
 
 pytestmark = pytest.mark.gpu
 
-TOL = 3e-4   # against the unsliced engine (same kernels, partial sums added in a different order); the logits bar is 1e-3
+TOL = 5e-4   # against the unsliced engine (same kernels; partial sums added in a different order, other launch geometries); the logits bar is 1e-3
 
 
 def _run_rank(eng, prompt, fed, graph, out, key):
