@@ -259,14 +259,14 @@ int      ntk_ipc_close(void* devptr);
 int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features,
                    int weight_dtype, const float* resid, void* stream);
 
-/* The same projection on the BF16 matrix cores, up to 512 tokens per pass over W (csrc/gemm_bf16.hip): the integer part of every
+/* The same projection on the BF16 matrix cores, up to 1024 tokens per pass over W (csrc/gemm_bf16.hip): the integer part of every
  * weight is exact in BF16, every F32 activation is split into three exact BF16 pieces, products accumulate in F32 and the block
  * scales / K-quant minima are applied to the F32 block sums -- no operand is rounded, only the summation order differs from ntk_gemv.
  * Limits: Q8_0, Q4_K, Q5_K and Q6_K (NTK_E_DTYPE otherwise: use ntk_gemm_quant); in_features a multiple of the format's block (32 / 256),
  * out_features % 16 == 0 and out_features * row_bytes < 4 GiB (NTK_E_SHAPE); W, X, Y, resid 16-byte aligned (NTK_E_ALIGN).
  * workspace: ntk_gemm_quant_workspace_bytes(in_features, out_features) device bytes, 16-byte aligned, shared by every call (BF16
- * planes of up to eight 64-token chunks of X + the partial sums of the K splits); contents need no initialisation.
- * reuse_x != 0: X (same pointer, n_tokens <= 512) has not changed since the previous call with this workspace -- its planes are
+ * planes of up to sixteen 64-token chunks of X + the partial sums of the K splits); contents need no initialisation.
+ * reuse_x != 0: X (same pointer, n_tokens <= 1024) has not changed since the previous call with this workspace -- its planes are
  * not rebuilt (Q, K, V / gate, up share x).  Stream ordered, no allocation, no synchronisation. */
 size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features);
 /* ... and several matrices of ONE format that share X (Q | K | V, gate | up) as one launch: segs[i] = {W_i, Y_i [n_tokens][rows_i],

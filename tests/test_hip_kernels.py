@@ -143,7 +143,7 @@ def gemm_ws_gpu(Wraw, X, out_f, in_f, dt, resid=None):
 
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048),
-                                          (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672), (300, 64, 512), (520, 48, 1024)])
+                                          (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672), (300, 64, 512), (520, 48, 1024), (1100, 32, 256)])
 def test_gemm_quant_bf16_matches_per_token_oracle(qname, T, out_f, in_f):
     """ntk_gemm_quant_ws (BF16 matrix cores, integer weights x three exact BF16 pieces of every activation, 64 tokens per
     pass) against the oracle's GEMV applied token by token -- what the reference's prefill loop computes
