@@ -3,7 +3,7 @@
 TAG=${1:-pmcgemm}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 pass() {  # name counters...
   local n=$1; shift
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o g -- python $R/tools/prefill_bench.py --no-engine --bf16-only > $R/$OUT/$n.log 2> $R/$OUT/$n.err ); echo "pass $n exit $?"
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o g -- python $R/tools/prefill_bench.py --no-kernels --tokens 1024 --modes 2 > $R/$OUT/$n.log 2> $R/$OUT/$n.err ); echo "pass $n exit $?"
 }
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS
 pass b SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU
