@@ -299,7 +299,7 @@ def main():
                 except Exception as e:   # the headline must survive a problem in an extra workload
                     also.append({"workload": "%s %s" % (model, mix), "value": None, "error": repr(e)})
             line["config"]["also"] = also
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (the replicas of an N > 1 run would wait on it)
             try:
                 line["cpu_baseline"] = cpu_baseline_reference_cli(args, r["spec"])
             except Exception as e:   # the GPU number must survive a CPU-side problem
