@@ -271,7 +271,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     //      global reads, conflict-free ds_read_b128), optional RMSNorm (reference rmsnorm.cu:16-70) ----
     f32x2 x2[32];   // the lane's 64 activations as 32 (even, odd) pairs
     XInt xi;         // ... or (XI) as integer byte planes (gemv_core.hip.h)
-    static_assert(!XI || (XFAST && A16 && !ATT && DT == NTK_DT_Q4_K), "integer activations: aligned fast prologue of the Q4_K rows");
+    static_assert(!XI || (XFAST && !ATT && ((DT == NTK_DT_Q4_K && A16) || DT == NTK_DT_Q6_K)), "integer activations: fast prologue, Q4_K (aligned rows) / Q6_K");
     {
         // The activations reach registers through a padded LDS image holding ALL slices: image row (sp*64 + l)
         // = the 64 columns lane l of slice sp owns (pitch 68 floats: conflict-free ds_read_b128).
@@ -358,7 +358,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             if constexpr (XI) {
                 // Integer planes instead of floats (host: in <= XIT * step, ns <= GS, so the registers cover the row).  Image row
                 // (same 272-byte pitch as the float image: conflict-free b128 reads) = [plane 0: 64 B][plane 1][plane 2][2^(e-22) of
-                // the row's two sub-blocks, their sums of x].  A thread holds 4 consecutive columns per register quad, 8 consecutive
+                // the row's two 32-column groups, the sums of x of its four 16-column runs].  A thread holds 4 consecutive columns per register quad, 8 consecutive
                 // threads hold a 32-column sub-block: its exponent and sum come from three DPP steps.
                 uint8_t* dimg = smem;
 #pragma unroll
@@ -371,10 +371,9 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                     am = fmaxf(am, dpp_or_self<DPP_QUAD_1032, 0xF>(am));
                     am = fmaxf(am, dpp_or_self<DPP_QUAD_2301, 0xF>(am));
                     am = fmaxf(am, dpp_or_self<DPP_ROW_HALF_MIRROR, 0xF>(am));
-                    float sm = (v0 + v1) + (v2 + v3);
+                    float sm = (v0 + v1) + (v2 + v3);   // -> sum of the 16-column run (the thread's quad of lanes)
                     sm += dpp_or_zero<DPP_QUAD_1032, 0xF>(sm);
                     sm += dpp_or_zero<DPP_QUAD_2301, 0xF>(sm);
-                    sm += dpp_or_zero<DPP_ROW_HALF_MIRROR, 0xF>(sm);
                     const int e = am > 0.0f ? __builtin_amdgcn_frexp_expf(am) : 0;   // am = m * 2^e, 0.5 <= m < 1
                     const float up = __builtin_ldexpf(1.0f, 22 - e), inv = __builtin_ldexpf(1.0f, e - 22);
                     // rint through the magic constant 1.5 * 2^23: the low mantissa bits ARE the two's-complement integer
@@ -394,29 +393,40 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                         *reinterpret_cast<uint32_t*>(row + (cc & 63)) = p0;
                         *reinterpret_cast<uint32_t*>(row + 64 + (cc & 63)) = p1;
                         *reinterpret_cast<uint32_t*>(row + 128 + (cc & 63)) = p2;
-                        if ((cc & 31) == 0) {   // first thread of the sub-block
-                            float* meta = reinterpret_cast<float*>(row + 192);
-                            meta[(cc >> 5) & 1] = inv;
-                            meta[2 + ((cc >> 5) & 1)] = sm;
-                        }
+                        float* meta = reinterpret_cast<float*>(row + 192);   // [2^(e-22) x 2][run sums x 4]
+                        if ((cc & 31) == 0) meta[(cc >> 5) & 1] = inv;          // first thread of the 32-column group
+                        if ((cc & 15) == 0) meta[2 + ((cc >> 4) & 3)] = sm;     // first thread of the 16-column run
                     }
                 }
                 __syncthreads();
                 {
-                    const uint8_t* row = dimg + (size_t)(s * 64 + lane) * (XPITCH * 4);
+                    // a lane's two 32-column groups: Q4_K -- both halves of image row `lane`; Q6_K -- half t of rows (lane & ~1) and
+                    // (lane | 1) (columns 32 t + [0, 32) of each: see Dot<Q6_K>)
                     const bool have_lo_ = ncols > 0, have_hi_ = ncols > 32;
+                    const uint8_t* rowA = dimg + (size_t)(s * 64 + lane) * (XPITCH * 4);
+                    const uint8_t* rowB = rowA;
+                    int offA = 0, offB = 32;
+                    if constexpr (DT == NTK_DT_Q6_K) {
+                        rowA = dimg + (size_t)(s * 64 + (lane & ~1)) * (XPITCH * 4);
+                        rowB = rowA + XPITCH * 4;
+                        offA = offB = 32 * (lane & 1);
+                    }
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                         for (int k4 = 0; k4 < 4; ++k4) {
-                            const u32x4 v = *reinterpret_cast<const u32x4*>(row + 64 * pl + 16 * k4);
+                            const uint8_t* src = (k4 < 2 ? rowA + offA : rowB + offB) + 64 * pl + 16 * (k4 & 1);
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(src);
                             const bool have = k4 < 2 ? have_lo_ : have_hi_;
                             xi.d[pl][4 * k4] = have ? v.x : 0u; xi.d[pl][4 * k4 + 1] = have ? v.y : 0u;
                             xi.d[pl][4 * k4 + 2] = have ? v.z : 0u; xi.d[pl][4 * k4 + 3] = have ? v.w : 0u;
                         }
-                    const float4 mt = *reinterpret_cast<const float4*>(row + 192);
-                    xi.inv[0] = have_lo_ ? mt.x : 0.0f; xi.inv[1] = have_hi_ ? mt.y : 0.0f;
-                    xi.sx[0] = have_lo_ ? mt.z : 0.0f; xi.sx[1] = have_hi_ ? mt.w : 0.0f;
+                    const float* mA = reinterpret_cast<const float*>(rowA + 192);
+                    const float* mB = reinterpret_cast<const float*>(rowB + 192);
+                    xi.inv[0] = have_lo_ ? mA[offA >> 5] : 0.0f;
+                    xi.inv[1] = have_hi_ ? mB[offB >> 5] : 0.0f;
+                    xi.sx[0] = have_lo_ ? mA[2 + (offA >> 4)] : 0.0f; xi.sx[1] = have_lo_ ? mA[3 + (offA >> 4)] : 0.0f;
+                    xi.sx[2] = have_hi_ ? mB[2 + (offB >> 4)] : 0.0f; xi.sx[3] = have_hi_ ? mB[3 + (offB >> 4)] : 0.0f;
                 }
             } else
             {   // pass 0 (the only one up to 16384 columns): straight-line, the registers die here
@@ -537,7 +547,8 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
         if (q + 1 < n_my) { cursor_advance(); issue(); }   // next row's bytes fly while this one is decoded
         float acc;
-        if constexpr (XI) acc = DotI<DT>::run(stage, lane, ncols, xi);
+        if constexpr (XI && DT == NTK_DT_Q6_K) acc = DotI<DT>::run(stage, shift, lane, ncols, xi);
+        else if constexpr (XI) acc = DotI<DT>::run(stage, lane, ncols, xi);
         else acc = (kAblate & 2) ? x2[0].x + (float)q : Dot<DT, A16>::run(stage, shift, lane, ncols, x2, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
         const float tot = wave_sum_lane63(acc);   // valid in lane 63
@@ -593,7 +604,7 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
 // integer-activation form (Q4_K, aligned fast prologue, rows of <= 16384 columns): gemv_core.hip.h XInt / DotI
 template <int DT, bool NORM>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_xi_kernel(const GemvParams p) {
-    gemv_quant_body<DT, NORM, true, true, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
+    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Two weight formats in ONE launch (llama.cpp's Q4_K_M stores attn_v as Q6_K / Q5_K next to Q4_K attn_q / attn_k): the first
@@ -763,13 +774,13 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
         if (!once || L.lds > 160 * 1024) return NTK_E_SHAPE;
     }
     const dim3 g(L.grid), b(64 * L.nwaves);
-    if constexpr (DT == NTK_DT_Q4_K) {
+    if constexpr (DT == NTK_DT_Q4_K || DT == NTK_DT_Q6_K) {
         static const bool xi_off = [] { const char* e = getenv("NTK_GEMV_NO_XI"); return e && atoi(e) != 0; }();
         // the integer-activation form: registers of the fast prologue cover the row, one image pass
         // ... and only the launches that are VALU-bound gain: long ones (measured, tools/gemv_bench.py: 70B gate|up 54.7 -> 50.1 us,
         // Q4_K LM head 58.3 -> 55.4; launches under ~100 MB are latency-bound and only pay the conversion in the prologue)
         const size_t launch_bytes = (size_t)L.p.total_rows * (silu_pair ? 2 : 1) * L.p.row_bytes;
-        if (!xi_off && L.xfast && L.a16 && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves && launch_bytes >= g_xi_min_bytes) {
+        if (!xi_off && L.xfast && (L.a16 || DT == NTK_DT_Q6_K) && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves && launch_bytes >= g_xi_min_bytes) {
             using XFn = void (*)(const GemvParams);
             static const XFn xt[2] = {gemv_quant_xi_kernel<DT, false>, gemv_quant_xi_kernel<DT, true>};
             if (L.lds > 64 * 1024) {

@@ -235,9 +235,9 @@ template <bool A16> struct Dot<NTK_DT_Q4_K, A16> {   // reference gemm.cu:190-24
 // the byte converts (profiles/r02_valu_issue_rates.txt), so 8 weights cost 3 mask operations + 6 dot instructions instead of 2 masks
 // + 8 converts + 4 packed FMAs.  The planes are built once per workgroup in the prologue's LDS image (gemv.hip).
 struct XInt {
-    uint32_t d[3][16];   // [plane][dword j]: columns 4j .. 4j+3 of the lane's 64 (j < 8: first sub-block, j >= 8: second)
-    float inv[2];        // 2^(e-22) of the two sub-blocks
-    float sx[2];         // their sums of x (K-quant minimum term)
+    uint32_t d[3][16];   // [plane][dword j]: columns 4j .. 4j+3 of the lane's 64 (j < 8: first 32-column group, j >= 8: second)
+    float inv[2];        // 2^(e-22) of the two groups
+    float sx[4];         // sums of x of the four 16-column runs (K-quant minimum term / Q6_K's -32 offset)
 };
 template <int DT> struct DotI;
 
@@ -265,10 +265,49 @@ template <> struct DotI<NTK_DT_Q4_K> {   // reference gemm.cu:190-244 (rows 16-b
         const float fa = fmaf(65536.0f, (float)a2, fmaf(256.0f, (float)a1, (float)a0)) * xi.inv[0];
         const float fb = fmaf(65536.0f, (float)b2, fmaf(256.0f, (float)b1, (float)b0)) * xi.inv[1];
         float t = d1 * fa;
-        t = fmaf(-m1, xi.sx[0], t);
+        t = fmaf(-m1, xi.sx[0] + xi.sx[1], t);
         t = fmaf(d2, fb, t);
-        t = fmaf(-m2, xi.sx[1], t);
+        t = fmaf(-m2, xi.sx[2] + xi.sx[3], t);
         return t;
+    }
+};
+
+template <> struct DotI<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (block, half hf, t) as Dot<Q6_K>, any even alignment
+    __device__ static float run(const uint8_t* st, int shift, int lane, int ncols, const XInt& xi) {
+        if (ncols <= 0) return 0.0f;
+        const int t = lane & 1, hf = (lane >> 1) & 1, ob = shift + 210 * (lane >> 2);
+        uint32_t scd[2];
+        lds_read_dwords<2>(scd, st, ob + 192 + 8 * hf);                    // the half's 8 int8 sub-scales
+        const uint32_t sc_lo = scd[0] >> (16 * t), sc_hi = scd[1] >> (16 * t);
+        const float d = h2f(lds_u16_at(st, ob + 208));
+        float S[4];   // [type * 2 + is]
+#pragma unroll
+        for (int is = 0; is < 2; ++is) {   // the two 16-column runs of each type
+            uint32_t A[4], H[4];
+            lds_read_dwords<4>(A, st, ob + 64 * hf + 32 * t + 16 * is);
+            lds_read_dwords<4>(H, st, ob + 128 + 32 * hf + 16 * is);
+            uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            int a2 = 0, b2 = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t hs = H[i] >> (2 * t);
+                const uint32_t qa = (A[i] & 0x0F0F0F0Fu) | ((hs & 0x03030303u) << 4);      // q in 0..63 (the -32 leaves through sx)
+                const uint32_t qb = ((A[i] >> 4) & 0x0F0F0F0Fu) | (hs & 0x30303030u);
+                a0 = __builtin_amdgcn_udot4(qa, xi.d[0][4 * is + i], a0, false);
+                a1 = __builtin_amdgcn_udot4(qa, xi.d[1][4 * is + i], a1, false);
+                a2 = __builtin_amdgcn_sdot4((int)qa, (int)xi.d[2][4 * is + i], a2, false);
+                b0 = __builtin_amdgcn_udot4(qb, xi.d[0][8 + 4 * is + i], b0, false);
+                b1 = __builtin_amdgcn_udot4(qb, xi.d[1][8 + 4 * is + i], b1, false);
+                b2 = __builtin_amdgcn_sdot4((int)qb, (int)xi.d[2][8 + 4 * is + i], b2, false);
+            }
+            S[is] = fmaf(65536.0f, (float)a2, fmaf(256.0f, (float)a1, (float)a0)) * xi.inv[0];
+            S[2 + is] = fmaf(65536.0f, (float)b2, fmaf(256.0f, (float)b1, (float)b0)) * xi.inv[1];
+        }
+        float bs = sb2f(sc_lo, 0) * fmaf(-32.0f, xi.sx[0], S[0]);
+        bs = fmaf(sb2f(sc_lo, 1), fmaf(-32.0f, xi.sx[1], S[1]), bs);
+        bs = fmaf(sb2f(sc_hi, 0), fmaf(-32.0f, xi.sx[2], S[2]), bs);
+        bs = fmaf(sb2f(sc_hi, 1), fmaf(-32.0f, xi.sx[3], S[3]), bs);
+        return d * bs;
     }
 };
 
