@@ -230,7 +230,7 @@ int  ntk_persistent_grid(void* plan);
 /* debugging aid: per-operator timestamps of two workgroups (see decode_persistent.hip); returns the operator count */
 int  ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int cap_ops);
 
-/* Tuning knob: Q4_K launches of at least this many weight bytes (default 96 MiB) take the integer-activation form of the GEMV
+/* Tuning knob: Q4_K / Q6_K launches of at least this many weight bytes (default 48 MiB) take the integer-activation form of the GEMV
  * (three int8 digit planes per 32-column sub-block on v_dot4: csrc/gemv_core.hip.h XInt).  0 = every eligible launch (the parity
  * tests), SIZE_MAX = never. */
 void     ntk_gemv_tune_xi_min_bytes(size_t bytes);

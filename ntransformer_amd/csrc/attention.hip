@@ -210,22 +210,37 @@ __global__ __launch_bounds__(256) void attention_decode_fused_kernel(
 // Decode attention, single pass (engine path).  The reference kernel (attention.cu:108-202) and `attend` above make
 // three passes over LDS scores with ~8 workgroup barriers; at decode lengths the launch is pure latency, so here
 // every (wave, 16-lane group) streams its own positions with an online softmax (running max m, sum l, 8 output
-// dims per lane), K/V of the next position in flight while the current one is reduced, and the 16 partial states
-// merge once through LDS: two barriers in total.  Same F32 math on the same half-rounded K/V; the summation order
-// differs (|d out| ~1e-6).  The token being decoded comes from LDS (kx/vx), not from the cache row another
-// workgroup is writing.
+// dims per lane) and the 16 partial states merge once through LDS.  Same F32 math on the same half-rounded K/V; the
+// summation order differs (|d out| ~1e-6).  The token being decoded comes from LDS (kx/vx), not from the cache row
+// another workgroup is writing.
+// The launch is a chain of memory round trips (position -> cache rows -> next rows ...), and the walk is arranged around it
+// (round 2, "v3": 6.7 -> 5.1 us per layer at position 128, 11.8 -> 7.4 at 320, 97 -> 49 at 4095; with 8 splits 21.7 -> 15.9):
+//   * nothing that can be requested without the position waits for it: q, k, v, the frequencies and the first four cache
+//     rows of every position group (row indices clamped to the cache, validity applied later) are in flight before *d_pos
+//     is consumed;
+//   * four positions per group are in flight instead of one (the next four are requested as soon as the current four are
+//     unpacked, under a uniform branch; rows past the position are fetched and ignored, so no load is predicated per lane);
+//   * the token being decoded is taken by its group after the loop (its place in that group's order);
+//   * RoPE of q, RoPE of k and the conversion of v run on different waves, sin and cos share one argument reduction, and the
+//     new cache row is stored at the very end (a store in front of the walk sits in the same in-order counter as the row loads);
+//   * the merge computes each group's weight once.
+// SPLIT: workgroup (head, sp) of nsplit takes the positions sp * G + g + j * nsplit * G of group g and leaves its un-normalised
+// state (acc[hd], m, l) in `output` = part[head][sp] for attention_split_combine_kernel; otherwise nsplit = 1 and `output` is the
+// head's normalised result.
 // ---------------------------------------------------------------------------------------------
-template <int LPR>
-__global__ __launch_bounds__(256) void attention_decode_fused_v2_kernel(
+template <int LPR, int D, bool SPLIT>
+__device__ __forceinline__ void attention_decode_walk(
     float* __restrict__ output, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
-    int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale) {
-    constexpr int PPW = 64 / LPR, NW = 4, G = NW * PPW;
+    const int n_heads, const int n_kv_heads, const int hd, const int max_seq, const float scale, const float theta, const float fscale,
+    const int head, const int sp, const int nsplit) {
+    constexpr int PPW = 64 / LPR, NW = 4, G = NW * PPW;   // D: positions in flight per group
+    constexpr float EMPTY = -3.0e38f;   // running maximum of a group that has seen nothing (finite: exp(EMPTY - x) = 0, EMPTY - EMPTY = 0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int head = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int group = n_heads / n_kv_heads, kv_head = head / group;
-    const int pos = *d_pos;
-    float* qs = lds;              // [hd] post-RoPE query
+    const int stepG = nsplit * G, first = sp * G;   // this workgroup's positions: first + g + j * stepG
+    float* qs = lds;              // [hd] post-RoPE query; after the walk: [G] merge weights
     float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
     float* vx = kx + hd;          // [hd] value of this token, rounded through half
     float* ms = vx + hd;          // [G] running maxima
@@ -233,215 +248,183 @@ __global__ __launch_bounds__(256) void attention_decode_fused_v2_kernel(
     float* accs = ls + G;         // [G][hd]
     const int half_dim = hd / 2;
     const size_t stride = (size_t)n_kv_heads * hd;
-    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
-    const bool writer = (head % group == 0) && pos < max_seq;
     const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
     const uint16_t* kbase = kc + (size_t)kv_head * hd + 8 * part_i;
     const uint16_t* vbase = vc + (size_t)kv_head * hd + 8 * part_i;
+    const int pmax = max_seq - 1;
 
-    // first cache rows in flight before the RoPE math
-    int p = g;
-    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
-    if (p < pos) {
-        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
-        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
+    // this thread's share of the new token: wave 0 rotates q, wave 1 rotates and stores k, waves 2-3 store v (hd <= 256)
+    const int ri = tid & 63, role = tid >> 6;
+    float in_a = 0.0f, in_b = 0.0f, in_c = 0.0f, in_d = 0.0f, freq = 0.0f;
+    const bool rot = role < 2 && ri < half_dim;
+    if (rot) {   // pairs (ri, ri + hd/2) and, for hd = 256, (ri + 64, ri + 64 + hd/2)
+        const float* src = role == 0 ? q + (size_t)head * hd : k + (size_t)kv_head * hd;
+        in_a = src[ri]; in_b = src[ri + half_dim];
+        freq = inv_freq ? inv_freq[ri] : 1.0f / (float)pow((double)theta, (double)((2.0f * ri) / hd));
+        if (half_dim > 64) { in_c = src[ri + 64]; in_d = src[ri + 64 + half_dim]; }
     }
-    for (int i = tid; i < half_dim; i += blockDim.x) {
-        float a = q[(size_t)head * hd + i], b = q[(size_t)head * hd + i + half_dim];
-        float ka = k[(size_t)kv_head * hd + i], kb = k[(size_t)kv_head * hd + i + half_dim];
+    float vin0 = 0.0f, vin1 = 0.0f;
+    const int vi = tid - 128;
+    if (role >= 2) {
+        if (vi < hd) vin0 = v[(size_t)kv_head * hd + vi];
+        if (vi + 128 < hd) vin1 = v[(size_t)kv_head * hd + vi + 128];
+    }
+
+    // (after the loads RoPE waits for: a CU serves its requests roughly in order)
+    u32x4 kraw[D], vraw[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const size_t row = (size_t)min(first + g + stepG * d, pmax) * stride;
+        kraw[d] = *reinterpret_cast<const u32x4*>(kbase + row);
+        vraw[d] = *reinterpret_cast<const u32x4*>(vbase + row);
+    }
+    const int pos = *d_pos;
+    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
+    const bool writer = (head % group == 0) && sp == 0 && pos < max_seq;
+    // the new cache row is stored at the very END of the kernel (values kept in registers): a store in front of the walk would
+    // sit in the same in-order counter as the row loads and make the first wait of the walk a wait for its acknowledgement
+    uint16_t st_h[4] = {0, 0, 0, 0};
+    if (rot) {
         // reference rotary.cu:46-60; inv_freq (engine) holds 1/powf(theta, 2i/hd) computed once on the host
-        const float freq = inv_freq ? inv_freq[i] : 1.0f / (float)pow((double)theta, (double)((2.0f * i) / hd));
-        const float angle = pos * freq * fscale;
-        const float c = cosf(angle), sn = sinf(angle);
-        qs[i] = a * c - b * sn; qs[i + half_dim] = b * c + a * sn;
-        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
-        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
-        if (writer) { kc[cache_row + i] = ha; kc[cache_row + i + half_dim] = hb; }
+        auto rotate = [&](const int i, const float a, const float b, const float f, uint16_t& ha, uint16_t& hb) {
+            const float angle = pos * f * fscale;
+            float c, sn;
+            sincosf(angle, &sn, &c);   // one argument reduction; bit-identical to sinf / cosf on gfx950 (tools/micro/sincos_check.hip)
+            const float ra = a * c - b * sn, rb = b * c + a * sn;
+            if (role == 0) { qs[i] = ra; qs[i + half_dim] = rb; }
+            else {
+                ha = f2h(ra); hb = f2h(rb);   // attention.cu:338 (__float2half, RNE)
+                kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
+            }
+        };
+        rotate(ri, in_a, in_b, freq, st_h[0], st_h[1]);
+        if (half_dim > 64) {
+            const int i2 = ri + 64;
+            const float f2 = inv_freq ? inv_freq[i2] : 1.0f / (float)pow((double)theta, (double)((2.0f * i2) / hd));
+            rotate(i2, in_c, in_d, f2, st_h[2], st_h[3]);
+        }
     }
-    for (int i = tid; i < hd; i += blockDim.x) {
-        const uint16_t hv = f2h(v[(size_t)kv_head * hd + i]);
-        vx[i] = h2f(hv);
-        if (writer) vc[cache_row + i] = hv;
+    if (role >= 2) {
+        if (vi < hd) { st_h[0] = f2h(vin0); vx[vi] = h2f(st_h[0]); }
+        if (vi + 128 < hd) { st_h[1] = f2h(vin1); vx[vi + 128] = h2f(st_h[1]); }
     }
     __syncthreads();
 
     float qreg[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
-    float m = -INFINITY, l = 0.0f, acc[8];
+    float m = EMPTY, l = 0.0f, acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-    for (; p <= pos; p += G) {
-        float kf[8], vf[8];
-        if (p < pos) {
-            unpack8(kraw, kf);
-            unpack8(vraw, vf);
-        } else {   // the token being decoded
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
-        }
-        const int pn = p + G;
-        if (pn < pos) {   // next position's rows fly during the reduction below
-            kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
-            vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
-        }
+    auto step = [&](const float* kf, const float* vf, const bool valid) {   // one position of the online softmax; an exact no-op when !valid
         float sc = 0.0f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
         sc = group_sum<LPR>(sc);
         sc *= scale;
-        const float mn = fmaxf(m, sc);
-        const float a = expf(m - mn), pw = expf(sc - mn);
+        const float s_ = valid ? sc : m;
+        const float mn = fmaxf(m, s_);
+        const float a = expf(m - mn), pw = valid ? expf(s_ - mn) : 0.0f;
         l = fmaf(l, a, pw);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, pw * vf[j]);
         m = mn;
+    };
+    for (int base = first; base < pos; base += stepG * D) {   // uniform trip count
+        float kf[D][8], vf[D][8];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            u32x4 vr = vraw[d];
+            if (base + g + stepG * d >= pos) vr = u32x4{0u, 0u, 0u, 0u};   // rows past the position hold anything (0 * NaN)
+            unpack8(kraw[d], kf[d]);
+            unpack8(vr, vf[d]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the ring registers are free: the next batch may land in them
+        if (base + stepG * D < pos) {   // uniform: another batch follows
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const size_t row = (size_t)min(base + stepG * D + g + stepG * d, pmax) * stride;
+                kraw[d] = *reinterpret_cast<const u32x4*>(kbase + row);
+                vraw[d] = *reinterpret_cast<const u32x4*>(vbase + row);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) step(kf[d], vf[d], base + g + stepG * d < pos);
+    }
+    {   // the token being decoded: from LDS (another workgroup is writing its cache row), by the group whose turn it is
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
+        step(kf, vf, first + g == pos % stepG);
     }
     if (part_i == 0) { ms[g] = m; ls[g] = l; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) accs[g * hd + 8 * part_i + j] = acc[j];
     __syncthreads();
+    float M = ms[0];
+    for (int i = 1; i < G; ++i) M = fmaxf(M, ms[i]);
+    if (tid < G) qs[tid] = expf(ms[tid] - M);   // 0 for groups that saw no position
+    __syncthreads();
     for (int d = tid; d < hd; d += blockDim.x) {
-        float M = ms[0];
-        for (int i = 1; i < G; ++i) M = fmaxf(M, ms[i]);
         float L = 0.0f, o = 0.0f;
         for (int i = 0; i < G; ++i) {
-            const float w = expf(ms[i] - M);   // exp(-inf) = 0 for groups that saw no position
+            const float w = qs[i];
             L = fmaf(w, ls[i], L);
             o = fmaf(w, accs[i * hd + d], o);
         }
-        output[(size_t)head * hd + d] = o / L;
+        if constexpr (SPLIT) {
+            output[d] = o;
+            if (d == 0) { output[hd] = M; output[hd + 1] = L; }
+        } else {
+            output[(size_t)head * hd + d] = o / L;
+        }
+    }
+    if (writer) {
+        if (role == 1 && rot) {
+            kc[cache_row + ri] = st_h[0]; kc[cache_row + ri + half_dim] = st_h[1];
+            if (half_dim > 64) { kc[cache_row + ri + 64] = st_h[2]; kc[cache_row + ri + 64 + half_dim] = st_h[3]; }
+        }
+        if (role >= 2) {
+            if (vi < hd) vc[cache_row + vi] = st_h[0];
+            if (vi + 128 < hd) vc[cache_row + vi + 128] = st_h[1];
+        }
     }
 }
 
+
+template <int LPR, int D>
+__global__ __launch_bounds__(256) void attention_decode_fused_v3_kernel(
+    float* __restrict__ output, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
+    int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale) {
+    attention_decode_walk<LPR, D, false>(output, q, k, v, kc, vc, d_pos, inv_freq, n_heads, n_kv_heads, hd, max_seq, scale, theta, fscale,
+                                         (int)blockIdx.x, 0, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Split-KV decode attention for long contexts.  One workgroup per head walks the cache
-// serially, so the single-pass kernel above grows with the context (98 us per layer at position 4095, where the
-// whole layer's KV is only 16.8 MB).  Here `nsplit` workgroups share a head: workgroup (head, sp) takes the
-// positions p = (sp * G + g) + k * nsplit * G of group g (interleaved, so every split sees the same load), keeps
-// the same online-softmax state and writes its un-normalised (m, l, acc[hd]) to `part`; a second launch merges
-// the nsplit partial states per head.  RoPE + KV store of the new token as in the single-pass kernel (store: split
-// 0 of the first head of each KV group).  The engine picks single-pass / 8 / 16 splits by position (host side,
-// one hipGraph per regime).
+// Split-KV decode attention for long contexts.  One workgroup per head walks the cache serially, so the
+// single-pass launch grows with the context (49 us per layer at position 4095, where the whole layer's KV is only 16.8 MB).
+// Here `nsplit` workgroups share a head -- grid (n_heads, nsplit), positions interleaved so every split sees the same load --
+// and a second launch (attention_split_combine_kernel) merges the nsplit partial states per head.  RoPE + KV store of the new
+// token as in the single pass (store: split 0 of the first head of each KV group).  The engine picks single pass / 8 / 16
+// splits by position (host side, one hipGraph per regime).
+// XCD-aware head order: workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.
+// blockIdx.x = i -> kv head i % n_kv_heads: with 8 KV heads (every Llama-3 size) all query heads of a KV head, in all splits,
+// run on ONE XCD, so its cache rows leave HBM once instead of once per query head (measured: 4x HBM traffic, 23.6 us per layer
+// at position 4095 with the plain order).
 // part layout: [n_heads][nsplit][hd + 2] = acc[hd], m, l
 // ---------------------------------------------------------------------------------------------
-template <int LPR>
+template <int LPR, int D>
 __global__ __launch_bounds__(256) void attention_decode_split_kernel(
     float* __restrict__ part, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
     int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale) {
-    constexpr int PPW = 64 / LPR, NW = 4, G = NW * PPW;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    // XCD-aware head order: workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2.
-    // blockIdx.x = i -> kv head i % n_kv_heads: with 8 KV heads (every Llama-3 size) all query heads of a KV head, in
-    // all splits, run on ONE XCD, so its cache rows leave HBM once instead of once per query head (measured: 4x HBM
-    // traffic, 23.6 us per layer at position 4095 with the plain order).
     const int group = n_heads / n_kv_heads;
     const int kv_head = blockIdx.x % n_kv_heads, head = kv_head * group + blockIdx.x / n_kv_heads;
     const int sp = blockIdx.y, nsplit = gridDim.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pos = *d_pos;
-    float* qs = lds;              // [hd] post-RoPE query
-    float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
-    float* vx = kx + hd;          // [hd] value of this token, rounded through half
-    float* ms = vx + hd;          // [G] running maxima
-    float* ls = ms + G;           // [G] running sums
-    float* accs = ls + G;         // [G][hd]
-    const int half_dim = hd / 2;
-    const size_t stride = (size_t)n_kv_heads * hd;
-    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
-    const bool writer = (head % group == 0) && sp == 0 && pos < max_seq;
-    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
-    const uint16_t* kbase = kc + (size_t)kv_head * hd + 8 * part_i;
-    const uint16_t* vbase = vc + (size_t)kv_head * hd + 8 * part_i;
-    const int step = nsplit * G;
-
-    // the walk is latency-bound (each step jumps nsplit * G cache rows): two positions per step, both prefetched a
-    // step ahead -> four 16-byte rows in flight per lane
-    int p = sp * G + g;
-    u32x4 kraw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, vraw[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (p + u * step < pos) {
-            kraw[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(p + u * step) * stride);
-            vraw[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)(p + u * step) * stride);
-        }
-    }
-    for (int i = tid; i < half_dim; i += blockDim.x) {
-        float a = q[(size_t)head * hd + i], b = q[(size_t)head * hd + i + half_dim];
-        float ka = k[(size_t)kv_head * hd + i], kb = k[(size_t)kv_head * hd + i + half_dim];
-        const float freq = inv_freq ? inv_freq[i] : 1.0f / (float)pow((double)theta, (double)((2.0f * i) / hd));
-        const float angle = pos * freq * fscale;
-        const float c = cosf(angle), sn = sinf(angle);
-        qs[i] = a * c - b * sn; qs[i + half_dim] = b * c + a * sn;
-        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);
-        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
-        if (writer) { kc[cache_row + i] = ha; kc[cache_row + i + half_dim] = hb; }
-    }
-    for (int i = tid; i < hd; i += blockDim.x) {
-        const uint16_t hv = f2h(v[(size_t)kv_head * hd + i]);
-        vx[i] = h2f(hv);
-        if (writer) vc[cache_row + i] = hv;
-    }
-    __syncthreads();
-
-    float qreg[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
-    float m = -INFINITY, l = 0.0f, acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-    for (; p <= pos; p += 2 * step) {
-        float kf[2][8], vf[2][8];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int pu = p + u * step;
-            if (pu < pos) {
-                unpack8(kraw[u], kf[u]);
-                unpack8(vraw[u], vf[u]);
-            } else {   // the token being decoded (pu == pos), or past the end (masked below)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { kf[u][j] = kx[8 * part_i + j]; vf[u][j] = vx[8 * part_i + j]; }
-            }
-            const int pn = pu + 2 * step;
-            if (pn < pos) {
-                kraw[u] = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
-                vraw[u] = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
-            }
-        }
-        float sc[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float t = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t = fmaf(qreg[j], kf[u][j], t);
-            sc[u] = group_sum<LPR>(t) * scale;
-        }
-        if (p + step > pos) sc[1] = -INFINITY;   // no second position in this step
-        const float mn = fmaxf(m, fmaxf(sc[0], sc[1]));
-        const float a = expf(m - mn), pw0 = expf(sc[0] - mn), pw1 = expf(sc[1] - mn);
-        l = fmaf(l, a, pw0 + pw1);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, fmaf(pw0, vf[0][j], pw1 * vf[1][j]));
-        m = mn;
-    }
-    if (part_i == 0) { ms[g] = m; ls[g] = l; }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) accs[g * hd + 8 * part_i + j] = acc[j];
-    __syncthreads();
-    float* out = part + ((size_t)head * nsplit + sp) * (hd + 2);
-    float M = ms[0];
-    for (int i = 1; i < G; ++i) M = fmaxf(M, ms[i]);
-    for (int d = tid; d < hd + 1; d += blockDim.x) {
-        float L = 0.0f, o = 0.0f;
-        for (int i = 0; i < G; ++i) {
-            const float w = (ms[i] == -INFINITY) ? 0.0f : expf(ms[i] - M);   // groups (or a whole split) without positions
-            L = fmaf(w, ls[i], L);
-            if (d < hd) o = fmaf(w, accs[i * hd + d], o);
-        }
-        if (d < hd) out[d] = o;
-        else { out[hd] = M; out[hd + 1] = L; }
-    }
+    attention_decode_walk<LPR, D, true>(part + ((size_t)head * nsplit + sp) * (hd + 2), q, k, v, kc, vc, d_pos, inv_freq, n_heads,
+                                        n_kv_heads, hd, max_seq, scale, theta, fscale, head, sp, nsplit);
 }
 
 __global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __restrict__ output, const float* __restrict__ part,
@@ -701,12 +684,12 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
     if (aligned && (head_dim == 128 || head_dim == 64 || head_dim == 256)) {   // single-pass kernel
         const int G = 4 * (64 / (head_dim / 8));
         const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
-#define NTK_ATTV2(LPR_) hipLaunchKernelGGL(ntk::attention_decode_fused_v2_kernel<LPR_>, dim3(n_heads), dim3(256), lds, st, output, q, k, v, \
+#define NTK_ATTV(...) hipLaunchKernelGGL((ntk::attention_decode_fused_v3_kernel<__VA_ARGS__>), dim3(n_heads), dim3(256), lds, st, output, q, k, v, \
                                            k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
-        if (head_dim == 128) NTK_ATTV2(16);
-        else if (head_dim == 64) NTK_ATTV2(8);
-        else NTK_ATTV2(32);
-#undef NTK_ATTV2
+        if (head_dim == 128) NTK_ATTV(16, 4);
+        else if (head_dim == 64) NTK_ATTV(8, 4);
+        else NTK_ATTV(32, 4);
+#undef NTK_ATTV
         return ntk::last_launch_status();
     }
     const size_t lds = ntk::attn_lds(head_dim, max_seq, 3);
@@ -736,11 +719,11 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     uint16_t* v16 = static_cast<uint16_t*>(v_cache);
     const int G = 4 * (64 / (head_dim / 8));
     const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
-#define NTK_ATTSP(LPR_) hipLaunchKernelGGL(ntk::attention_decode_split_kernel<LPR_>, dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \
+#define NTK_ATTSP(...) hipLaunchKernelGGL((ntk::attention_decode_split_kernel<__VA_ARGS__>), dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \
                                            v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
-    if (head_dim == 128) NTK_ATTSP(16);
-    else if (head_dim == 64) NTK_ATTSP(8);
-    else NTK_ATTSP(32);
+    if (head_dim == 128) NTK_ATTSP(16, 4);
+    else if (head_dim == 64) NTK_ATTSP(8, 4);
+    else NTK_ATTSP(32, 4);
 #undef NTK_ATTSP
     if (ntk::last_launch_status() != NTK_OK) return NTK_E_LAUNCH;
     hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit);

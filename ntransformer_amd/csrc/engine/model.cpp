@@ -707,7 +707,7 @@ bool Model::use_persistent_now() const {
 }
 
 const char* Model::decode_path() const {
-    return (persistent_plan_ && persistent_on_) ? "persistent (1 launch per token while pos < 320, fused launches beyond)" : "fused (5 launches/layer)";
+    return (persistent_plan_ && persistent_on_) ? "persistent (1 launch per token in the single-pass attention regime, fused launches beyond)" : "fused (5 launches/layer)";
 }
 
 int Model::check_persistent() {

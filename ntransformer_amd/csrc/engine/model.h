@@ -47,11 +47,11 @@ public:
     int decode_step_fused(bool greedy, bool use_graph);
     int set_device_token(int token);
     int set_device_pos(int pos);
-    // attention regime by context length: the single-pass kernel walks a head's cache serially (98 us per layer at 4095),
-    // so long contexts split each head over 8 / 32 workgroups (ntk_attention_decode_split)
-    // (measured, tools/attn_bench.py: single pass 9.2 us at 255 / 16.3 at 512 / 97 at 4095; 8 splits 9.3 / 11.5 / 21.8;
-    //  16 splits only pay beyond the 4096-token contexts this engine caps at)
-    static int attention_regime(int pos) { return pos < 320 ? 0 : pos < 8192 ? 1 : 2; }
+    // attention regime by context length: the single-pass kernel walks a head's cache serially (49 us per layer at 4095),
+    // so long contexts split each head over 8 / 16 workgroups (ntk_attention_decode_split)
+    // (measured, tools/attn_bench.py: single pass 6.7 us at 255 / 9.5 at 512 / 15.2 at 1024 / 49 at 4095; 8 splits 9.9 / 9.9 /
+    //  10.9 / 15.9; 16 splits only pay beyond the 4096-token contexts this engine caps at)
+    static int attention_regime(int pos) { return pos < 576 ? 0 : pos < 8192 ? 1 : 2; }
     void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)

@@ -291,6 +291,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         };
         constexpr int XIT = 8, WIT = 4;
         const int step = (int)blockDim.x * 4;
+        const bool xskip = p.x_vec > 1;
         const int dummy = (int)(lds_floats_total - 16);   // 16 spare floats at the end of the allocation
         const bool have_lo = ncols > 0, have_hi = ncols > 32;   // ncols is 0, 32 or 64: two masks, not 64 compares
         auto read_own_row = [&](int g0) {
@@ -321,11 +322,19 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 for (int i = 0; i < XIT; ++i) xv[i] = asm_load16_sc1(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
             } else {
+            // register quads past the row's end are skipped by a uniform branch (4096 columns use 2 of the 8: the dead loads
+            // would queue in front of the first weight row)
 #pragma unroll
-            for (int i = 0; i < XIT; ++i) xv[i] = asm_load16(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
+            for (int i = 0; i < XIT; ++i) {
+                xv[i] = u32x4{0u, 0u, 0u, 0u};
+                if (!xskip || i * step < p.in) xv[i] = asm_load16(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
+            }
             if constexpr (NORM) {
 #pragma unroll
-                for (int i = 0; i < WIT; ++i) wv[i] = asm_load16(p.norm_w, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
+                for (int i = 0; i < WIT; ++i) {
+                    wv[i] = u32x4{0u, 0u, 0u, 0u};
+                    if (!xskip || i * step < p.in) wv[i] = asm_load16(p.norm_w, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
+                }
             }
             issue();   // unconditional (a wave without rows re-reads row 0): keeps this block free of branches
             asm volatile("s_waitcnt vmcnt(%c8)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]) : "i"(NL));
@@ -356,17 +365,14 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 }
             }
             if constexpr (XI) {
-                // Integer planes instead of floats (host: in <= XIT * step, ns <= GS, so the registers cover the row).  Image row
-                // (same 272-byte pitch as the float image: conflict-free b128 reads) = [plane 0: 64 B][plane 1][plane 2][2^(e-22) of
-                // the row's two 32-column groups, the sums of x of its four 16-column runs].  A thread holds 4 consecutive columns per register quad, 8 consecutive
-                // threads hold a 32-column sub-block: its exponent and sum come from three DPP steps.
+                // Integer planes instead of floats.  Image row (same 272-byte pitch as the float image: conflict-free b128 reads) =
+                // [plane 0: 64 B][plane 1][plane 2][2^(e-22) of the row's two 32-column groups, the sums of x of its four 16-column
+                // runs].  A thread converts 4 consecutive columns, 8 consecutive threads hold a 32-column sub-block: its exponent and
+                // sum come from three DPP steps (every caller below keeps those 8 threads together: column bases are multiples of 256).
                 uint8_t* dimg = smem;
-#pragma unroll
-                for (int i = 0; i < XIT; ++i) {
-                    const int c = tid * 4 + i * step;
-                    const bool live = c < p.in;
-                    const float v0 = live ? __uint_as_float(xv[i].x) : 0.0f, v1 = live ? __uint_as_float(xv[i].y) : 0.0f,
-                                v2 = live ? __uint_as_float(xv[i].z) : 0.0f, v3 = live ? __uint_as_float(xv[i].w) : 0.0f;
+                auto xi_store = [&](const u32x4 q, const int c, const bool live, const int g0) {
+                    const float v0 = live ? __uint_as_float(q.x) : 0.0f, v1 = live ? __uint_as_float(q.y) : 0.0f,
+                                v2 = live ? __uint_as_float(q.z) : 0.0f, v3 = live ? __uint_as_float(q.w) : 0.0f;
                     float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
                     am = fmaxf(am, dpp_or_self<DPP_QUAD_1032, 0xF>(am));
                     am = fmaxf(am, dpp_or_self<DPP_QUAD_2301, 0xF>(am));
@@ -389,7 +395,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                     const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u);    // b2 (signed top byte)
                     if (live) {
                         const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
-                        uint8_t* row = dimg + (size_t)(sp * 64 + (cc >> 6)) * (XPITCH * 4);
+                        uint8_t* row = dimg + (size_t)((sp - g0) * 64 + (cc >> 6)) * (XPITCH * 4);
                         *reinterpret_cast<uint32_t*>(row + (cc & 63)) = p0;
                         *reinterpret_cast<uint32_t*>(row + 64 + (cc & 63)) = p1;
                         *reinterpret_cast<uint32_t*>(row + 128 + (cc & 63)) = p2;
@@ -397,17 +403,16 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                         if ((cc & 31) == 0) meta[(cc >> 5) & 1] = inv;          // first thread of the 32-column group
                         if ((cc & 15) == 0) meta[2 + ((cc >> 4) & 3)] = sm;     // first thread of the 16-column run
                     }
-                }
-                __syncthreads();
-                {
+                };
+                auto xi_read = [&](const int g0) {
                     // a lane's two 32-column groups: Q4_K -- both halves of image row `lane`; Q6_K -- half t of rows (lane & ~1) and
                     // (lane | 1) (columns 32 t + [0, 32) of each: see Dot<Q6_K>)
                     const bool have_lo_ = ncols > 0, have_hi_ = ncols > 32;
-                    const uint8_t* rowA = dimg + (size_t)(s * 64 + lane) * (XPITCH * 4);
+                    const uint8_t* rowA = dimg + (size_t)((s - g0) * 64 + lane) * (XPITCH * 4);
                     const uint8_t* rowB = rowA;
                     int offA = 0, offB = 32;
                     if constexpr (DT == NTK_DT_Q6_K) {
-                        rowA = dimg + (size_t)(s * 64 + (lane & ~1)) * (XPITCH * 4);
+                        rowA = dimg + (size_t)((s - g0) * 64 + (lane & ~1)) * (XPITCH * 4);
                         rowB = rowA + XPITCH * 4;
                         offA = offB = 32 * (lane & 1);
                     }
@@ -427,12 +432,24 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                     xi.inv[1] = have_hi_ ? mB[offB >> 5] : 0.0f;
                     xi.sx[0] = have_lo_ ? mA[2 + (offA >> 4)] : 0.0f; xi.sx[1] = have_lo_ ? mA[3 + (offA >> 4)] : 0.0f;
                     xi.sx[2] = have_hi_ ? mB[2 + (offB >> 4)] : 0.0f; xi.sx[3] = have_hi_ ? mB[3 + (offB >> 4)] : 0.0f;
+                };
+                // (host: in <= XIT * step and ns <= 2, so the register quads cover the row and one image pass holds it.  Rows of
+                // several slices -- the 14336 / 28672-column down projections -- were tried with a second pass from memory: correct,
+                // and slower than the float form, 70B Q4_K down 33.4 -> 37.1 us: a workgroup converts the whole row for only 16 rows)
+#pragma unroll
+                for (int i = 0; i < XIT; ++i) {
+                    if (xskip && i * step >= p.in) continue;   // uniform
+                    const int c = tid * 4 + i * step;
+                    xi_store(xv[i], c, c < p.in, 0);
                 }
+                __syncthreads();
+                xi_read(0);
             } else
             {   // pass 0 (the only one up to 16384 columns): straight-line, the registers die here
                 const int cend = min(p.in, GS * p.slice_cols);
 #pragma unroll
                 for (int i = 0; i < XIT; ++i) {
+                    if (xskip && i * step >= cend) continue;   // uniform
                     const int c = tid * 4 + i * step;
                     *reinterpret_cast<u32x4*>(ximg + (c < cend ? img_index(c, 0) : dummy)) = xv[i];
                 }
@@ -441,6 +458,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 __syncthreads();
                 if (s < GS) read_own_row(0);
             }
+            if constexpr (!XI)
             for (int g0 = GS; g0 < p.ns; g0 += GS) {   // 28672-wide rows: slices 4..6 in a second pass (weights already in flight)
                 const int cbeg = g0 * p.slice_cols, cend = min(p.in, (g0 + GS) * p.slice_cols);
                 __syncthreads();   // the previous pass has been read
@@ -712,8 +730,9 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
     p.rw = std::max(1, env_waves / p.ns);   // (6-wave workgroups for the 3-waves/SIMD formats measured 30 % slower)
     L.nwaves = p.ns * p.rw;
+    static const int xskip = [] { const char* e = getenv("NTK_GEMV_NO_XSKIP"); return (e && atoi(e) != 0) ? 1 : 2; }();
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-               (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? 1 : 0;
+               (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? xskip : 0;
     p.norm_w = norm_w;
     p.eps = eps;
     p.resid = resid;
@@ -741,7 +760,7 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
 }
 
 // smallest launch (bytes of weights) that takes the integer-activation form of the Q4_K GEMV; ntk_gemv_tune_xi_min_bytes moves it
-static size_t g_xi_min_bytes = (size_t)96 << 20;
+static size_t g_xi_min_bytes = [] { const char* e = getenv("NTK_GEMV_XI_MIN_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 48) << 20; }();
 
 static int max_workgroups() {
     static const int max_wg = [] { const char* e = getenv("NTK_GEMV_MAX_WG"); return e ? std::max(1, atoi(e)) : 512; }();
@@ -777,8 +796,9 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     if constexpr (DT == NTK_DT_Q4_K || DT == NTK_DT_Q6_K) {
         static const bool xi_off = [] { const char* e = getenv("NTK_GEMV_NO_XI"); return e && atoi(e) != 0; }();
         // the integer-activation form: registers of the fast prologue cover the row, one image pass
-        // ... and only the launches that are VALU-bound gain: long ones (measured, tools/gemv_bench.py: 70B gate|up 54.7 -> 50.1 us,
-        // Q4_K LM head 58.3 -> 55.4; launches under ~100 MB are latency-bound and only pay the conversion in the prologue)
+        // ... and only the launches that are VALU-bound gain: long ones (measured, tools/gemv_bench.py: 70B gate|up 53.0 -> 49.1 us,
+        // Q4_K LM head 56.6 -> 54.0, 8B gate|up 20.0 -> 17.1-18.8; under ~48 MiB -- 70B Q|K|V, the 8B down projection -- nothing is
+        // gained or the conversion in the prologue costs more than the decode saves)
         const size_t launch_bytes = (size_t)L.p.total_rows * (silu_pair ? 2 : 1) * L.p.row_bytes;
         if (!xi_off && L.xfast && (L.a16 || DT == NTK_DT_Q6_K) && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves && launch_bytes >= g_xi_min_bytes) {
             using XFn = void (*)(const GemvParams);

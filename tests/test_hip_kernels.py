@@ -329,7 +329,7 @@ def test_gemv_fused_norm_qkv(qname, in_f, rows):
                                                        (1024, 8192, True, False, True), (96, 2048, False, False, True), (40, 8192, False, True, False)])
 def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu):
     """The integer-activation form of the Q4_K / Q6_K GEMV (activations as three int8 digit planes per 32-column sub-block, products on
-    v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 96 MiB -- forced for every eligible launch and
+    v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 48 MiB -- forced for every eligible launch and
     compared with the oracle at the GEMV's tolerance: plain, RMSNorm prologue, residual epilogue, gate|up + SiLU."""
     from ntransformer_amd import _lib
     L = _lib.lib()
@@ -359,7 +359,7 @@ def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu):
         ops.gemv_fused(segs, xd, in_f, norm_w=nwd if norm else None, eps=1e-5, resid=yd if resid else None, silu_pair=silu)
         got = yd.numpy()
     finally:
-        L.ntk_gemv_tune_xi_min_bytes(96 << 20)
+        L.ntk_gemv_tune_xi_min_bytes(48 << 20)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= tol_for(ref, in_f) * (4 if silu else 1), np.abs(got - ref).max()
 
