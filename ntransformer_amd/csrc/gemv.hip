@@ -195,8 +195,44 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     constexpr int NL = F::NL;
     constexpr int STAGE = NL * 1024 + 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef NTK_GEMV_TRACE
+    unsigned long long gv_t[GT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    GV_STAMP(0);   // entry
+    {
+        // The kernel arguments are 5 cache lines; hipcc fetches them piecemeal, each piece right before its first use, so the
+        // prologue used to pay a scalar-cache miss per line one after the other before the first weight row could be requested.
+        // Touch every line at once: the later loads hit the scalar cache.
+        const auto* ka = __builtin_amdgcn_kernarg_segment_ptr();
+        unsigned d0, d1, d2, d3, d4;
+        asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\ts_load_dword %3, %5, 0xc0\n\t"
+                     "s_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(ka) : "memory");
+        __builtin_amdgcn_sched_barrier(0);   // ... before the compiler's own argument loads
+    }
 
     const int tid = threadIdx.x;
+    // The activations (and the norm weights) are requested before anything else is computed (fast prologue, see below): the row
+    // bookkeeping that follows runs under their latency.  Register quads past the row's end are skipped by a uniform branch
+    // (4096 columns use 2 of the 8; the dead loads alone cost 4 % of the token: they queue in front of the first weight row).
+    constexpr int XIT = 8, WIT = 4;
+    u32x4 xv[XIT], wv[WIT];
+    if constexpr (XFAST && !ATT) {
+        const int step0 = (int)blockDim.x * 4;
+#pragma unroll
+        for (int i = 0; i < XIT; ++i) {
+            xv[i] = u32x4{0u, 0u, 0u, 0u};
+            if (i * step0 < p.in) xv[i] = *reinterpret_cast<const u32x4*>(p.x + min(tid * 4 + i * step0, p.in - 4));
+        }
+        if constexpr (NORM) {
+#pragma unroll
+            for (int i = 0; i < WIT; ++i) {
+                wv[i] = u32x4{0u, 0u, 0u, 0u};
+                if (i * step0 < p.in) wv[i] = *reinterpret_cast<const u32x4*>(p.norm_w + min(tid * 4 + i * step0, p.in - 4));
+            }
+        }
+        GV_STAMP(7);   // x requested
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = p.ns * p.rw;
@@ -275,11 +311,8 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     {
         // The activations reach registers through a padded LDS image holding ALL slices: image row (sp*64 + l)
         // = the 64 columns lane l of slice sp owns (pitch 68 floats: conflict-free ds_read_b128).
-        //   * x (and the norm weights) are requested BEFORE the first weight prefetch: a CU serves its memory
-        //     requests roughly in order, and x queued behind 80 KB of weight loads cost 3 us per launch;
-        //   * those loads are inline asm so that hipcc does not count them: the wait can then say exactly
-        //     "everything older than the NL prefetch loads has landed" (s_waitcnt vmcnt(NL)) -- left to the
-        //     compiler the image stores wait with vmcnt(0), i.e. for the first weight row from HBM;
+        //   * x (and the norm weights) are requested, and have landed, BEFORE the first weight prefetch: a CU serves its
+        //     memory requests roughly in order, and x queued behind weight rows comes back with their HBM latency (see below);
         //   * RMSNorm is applied by the thread that loaded the element (x * rms_inv * w, rmsnorm.cu:68) and the
         //     image holds normalised values: the transposing read needs no second image and no extra registers
         //     (a weight image made hipcc spill the in-flight prefetch registers to scratch).
@@ -289,9 +322,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
             return ((sp - g0) * 64 + (cc >> 6)) * XPITCH + (cc & 63);
         };
-        constexpr int XIT = 8, WIT = 4;
         const int step = (int)blockDim.x * 4;
-        const bool xskip = p.x_vec > 1;
         const int dummy = (int)(lds_floats_total - 16);   // 16 spare floats at the end of the allocation
         const bool have_lo = ncols > 0, have_hi = ncols > 32;   // ncols is 0, 32 or 64: two masks, not 64 compares
         auto read_own_row = [&](int g0) {
@@ -312,7 +343,6 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             }
         };
         if constexpr (XFAST) {   // host guarantees: x (and norm_w) 16-byte aligned, in % 4 == 0, (!NORM || in <= WIT * step)
-            u32x4 xv[XIT], wv[WIT];
             if constexpr (ATT) {
                 // x is produced INSIDE this launch: weights first (they depend on nothing), then the attention heads and the
                 // grid-wide hand-off, then x through cache-bypassing loads (the first weight row has landed long before)
@@ -322,25 +352,19 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 for (int i = 0; i < XIT; ++i) xv[i] = asm_load16_sc1(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
             } else {
-            // register quads past the row's end are skipped by a uniform branch (4096 columns use 2 of the 8: the dead loads
-            // would queue in front of the first weight row)
-#pragma unroll
-            for (int i = 0; i < XIT; ++i) {
-                xv[i] = u32x4{0u, 0u, 0u, 0u};
-                if (!xskip || i * step < p.in) xv[i] = asm_load16(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
+            // x (and the norm weights) were requested at the top and have LANDED before the first weight row is requested: a CU
+            // returns its loads in request order, so an x request queued behind weight rows (this wave's, or those of the waves of
+            // the workgroup that started earlier) comes back with HBM latency, and the prologue's barrier waits for the slowest
+            // wave (tools/gemv_trace.py: x landed 0.25 us after its request in wave 0, activations in registers 2 us later; round 1
+            // had already moved a wave's own x request in front of its weights, worth 3 us per launch).  Ordinary loads: the empty
+            // asm "uses" them, so the compiler's own wait sits in front of it.
+            asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
+            if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
+            issue();   // unconditional (a wave without rows re-reads row 0)
+            GV_STAMP(8);   // first weight row requested
             }
-            if constexpr (NORM) {
-#pragma unroll
-                for (int i = 0; i < WIT; ++i) {
-                    wv[i] = u32x4{0u, 0u, 0u, 0u};
-                    if (!xskip || i * step < p.in) wv[i] = asm_load16(p.norm_w, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
-                }
-            }
-            issue();   // unconditional (a wave without rows re-reads row 0): keeps this block free of branches
-            asm volatile("s_waitcnt vmcnt(%c8)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]) : "i"(NL));
-            }
-            if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));   // older than the wait above: landed too
             __builtin_amdgcn_sched_barrier(0);
+            GV_STAMP(1);   // x (and the norm weights) have landed
             float rms_inv = 1.0f;
             if constexpr (NORM) {   // sum x^2 over the row: every column is loaded by exactly one thread (i < WIT covers the row)
                 float ssq = 0.0f;
@@ -438,7 +462,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 // and slower than the float form, 70B Q4_K down 33.4 -> 37.1 us: a workgroup converts the whole row for only 16 rows)
 #pragma unroll
                 for (int i = 0; i < XIT; ++i) {
-                    if (xskip && i * step >= p.in) continue;   // uniform
+                    if (i * step >= p.in) continue;   // uniform
                     const int c = tid * 4 + i * step;
                     xi_store(xv[i], c, c < p.in, 0);
                 }
@@ -449,7 +473,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 const int cend = min(p.in, GS * p.slice_cols);
 #pragma unroll
                 for (int i = 0; i < XIT; ++i) {
-                    if (xskip && i * step >= cend) continue;   // uniform
+                    if (i * step >= cend) continue;   // uniform
                     const int c = tid * 4 + i * step;
                     *reinterpret_cast<u32x4*>(ximg + (c < cend ? img_index(c, 0) : dummy)) = xv[i];
                 }
@@ -496,6 +520,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             for (int j = 0; j < 32; ++j) x2[j] = f32x2{1.0f, 1.0f};
         }
         __syncthreads();   // LDS region A becomes the staging area
+        GV_STAMP(2);   // activations in registers
     }
     float sx16[4], sx32[2];
 #pragma unroll
@@ -563,6 +588,10 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             *reinterpret_cast<u32x4*>(stage + 16 * (lane + 64 * j)) = pf[j];
         }
         __builtin_amdgcn_wave_barrier();   // DS ops of one wave execute in order: the image is visible below
+#ifdef NTK_GEMV_TRACE
+        if (q == 0) GV_STAMP(3);            // first row has landed
+        if (q == n_my - 1) GV_STAMP(5);     // last row has landed
+#endif
         if (q + 1 < n_my) { cursor_advance(); issue(); }   // next row's bytes fly while this one is decoded
         float acc;
         if constexpr (XI && DT == NTK_DT_Q6_K) acc = DotI<DT>::run(stage, shift, lane, ncols, xi);
@@ -570,6 +599,9 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         else acc = (kAblate & 2) ? x2[0].x + (float)q : Dot<DT, A16>::run(stage, shift, lane, ncols, x2, sx16, sx32);
         __builtin_amdgcn_wave_barrier();   // all reads of the image precede the next overwrite
         const float tot = wave_sum_lane63(acc);   // valid in lane 63
+#ifdef NTK_GEMV_TRACE
+        if (q == 0) { asm volatile("" :: "v"(tot)); GV_STAMP(4); }   // first row decoded and reduced
+#endif
 
         if (p.ns == 1) {
             if (lane == 63) {
@@ -601,6 +633,13 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         for (; done < p.nbatch; ++done) __syncthreads();
     }
     if constexpr (ATT) att_finish(p.att, nblk);
+#ifdef NTK_GEMV_TRACE
+    GV_STAMP(6);   // end
+    if (tid == 0 && bid < GT_WG) {
+        gv_t[9] = (unsigned long long)n_my;
+        for (int e = 0; e < GT_EV; ++e) g_gemv_trace[p.trace_slot & (GT_SLOTS - 1)][bid][e] = gv_t[e];
+    }
+#endif
 }
 
 // the Wo projection with the attention pre-phase (AttnFuse): aligned fast prologue, no norm
@@ -730,9 +769,8 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
     p.rw = std::max(1, env_waves / p.ns);   // (6-wave workgroups for the 3-waves/SIMD formats measured 30 % slower)
     L.nwaves = p.ns * p.rw;
-    static const int xskip = [] { const char* e = getenv("NTK_GEMV_NO_XSKIP"); return (e && atoi(e) != 0) ? 1 : 2; }();
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
-               (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? xskip : 0;
+               (!norm_w || (reinterpret_cast<uintptr_t>(norm_w) & 15) == 0) && (p.slice_cols % 4 == 0)) ? 1 : 0;
     p.norm_w = norm_w;
     p.eps = eps;
     p.resid = resid;
@@ -793,6 +831,10 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
         if (!once || L.lds > 160 * 1024) return NTK_E_SHAPE;
     }
     const dim3 g(L.grid), b(64 * L.nwaves);
+#ifdef NTK_GEMV_TRACE
+    static int trace_counter = 0;
+    L.p.trace_slot = trace_counter++;
+#endif
     if constexpr (DT == NTK_DT_Q4_K || DT == NTK_DT_Q6_K) {
         static const bool xi_off = [] { const char* e = getenv("NTK_GEMV_NO_XI"); return e && atoi(e) != 0; }();
         // the integer-activation form: registers of the fast prologue cover the row, one image pass
@@ -893,6 +935,11 @@ static int launch_dense(float* y, const void* W, const float* x, int out, int in
 extern "C" {
 
 void ntk_gemv_tune_xi_min_bytes(size_t bytes) { ntk::g_xi_min_bytes = bytes; }
+#ifdef NTK_GEMV_TRACE
+int ntk_debug_gemv_trace(unsigned long long* out, size_t n) {   // n <= GT_SLOTS * GT_WG * GT_EV
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemv_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int ntk_gemv(float* y, const void* W, const float* x, int out_features, int in_features, int weight_dtype, void* stream) {
     if (!y || !W || !x) return NTK_E_NULL;

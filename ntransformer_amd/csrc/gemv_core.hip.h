@@ -28,6 +28,16 @@ constexpr int MAX_SEG = 3;
 #endif
 constexpr int kAblate = NTK_GEMV_ABLATE;
 
+// Launch timeline (tuning builds only: make HIPFLAGS+=-DNTK_GEMV_TRACE): thread 0 of every workgroup records the constant
+// 100 MHz clock at the phase boundaries of its launch; read back with ntk_debug_gemv_trace(), printed by tools/gemv_trace.py.
+#ifdef NTK_GEMV_TRACE
+constexpr int GT_SLOTS = 64, GT_WG = 512, GT_EV = 10;
+__device__ unsigned long long g_gemv_trace[GT_SLOTS][GT_WG][GT_EV];
+#define GV_STAMP(ev) do { asm volatile("" ::: "memory"); gv_t[ev] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define GV_STAMP(ev) do {} while (0)
+#endif
+
 template <int DT> struct Fmt;
 // BW/BB: weights / bytes per GGUF block; NL: 1 KiB chunks per <=4096-column slice (+15 alignment bytes);
 // MINW: waves per SIMD the register allocator must leave room for (4 -> <=128 VGPRs, 3 -> <=168: the 5/6-bit
@@ -85,6 +95,9 @@ struct GemvParams {
     int silu_pair;
     unsigned row_bytes;
     AttnFuse att;       // used by the ATT instantiations only
+#ifdef NTK_GEMV_TRACE
+    int trace_slot;     // tuning builds: which record of g_gemv_trace this launch fills
+#endif
 };
 
 // ------------------------------------------------------------------------------------------------
