@@ -30,7 +30,8 @@ namespace ntk {
 
 // ------------------------------------------------------------------------------------------------
 // The kernel.  blockDim.x = 64 * ns * rw.  Dynamic LDS:
-//   [0, A)   prologue x (+ norm weight) image, afterwards nwaves * STAGE wave-private byte images
+//   [0, A)   the activation image of the prologue and nwaves * STAGE wave-private images of row bytes (side by side for rows of
+//            one column slice, the staging areas over the image -- behind a barrier -- for wider rows)
 //   [A, ..)  partial sums [2][rw][ns][RB] + 16 floats reduction scratch
 // ------------------------------------------------------------------------------------------------
 // ---- attention pre-phase (AttnFuse): attention.hip's single-pass decode kernel on the 8 waves of a GEMV workgroup ----
@@ -196,7 +197,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     constexpr int STAGE = NL * 1024 + 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef NTK_GEMV_TRACE
-    unsigned long long gv_t[GT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long gv_t[GT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     GV_STAMP(0);   // entry
     {
@@ -240,13 +241,18 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     const int g = wave / p.ns;        // row group of this wave
     constexpr bool norm = NORM;   // compile-time: the norm-weight loads/stores must not sit behind a runtime branch
 
-    const size_t regionA = (size_t)std::max(nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
+    // LDS: [activation image][per-wave staging of row bytes][partials].  Single-slice rows (<= 4096 columns) keep the image and
+    // the staging areas apart, so a wave enters the row loop as soon as it has read its own activations; wider rows (image 35-70 KB)
+    // reuse the image as staging area behind one more barrier.
+    const size_t image_bytes = (size_t)std::min(p.ns, 4) * 64 * XPITCH * 4;
+    const size_t stage0 = p.ns == 1 ? image_bytes : 0;
+    const size_t regionA = p.ns == 1 ? image_bytes + (size_t)nwaves * STAGE : std::max((size_t)nwaves * STAGE, image_bytes);
     float* part = reinterpret_cast<float*>(smem + regionA);
     float* red = part + 2 * p.rw * p.ns * RB;
     const size_t lds_floats_total = regionA / 4 + (size_t)(2 * p.rw * p.ns * RB + 16 + 16);   // ... + red[16] + 16 spare
 
     // ---- item bookkeeping + first prefetch (issued before the prologue so HBM latency overlaps it) ----
-    uint8_t* stage = smem + (size_t)wave * STAGE;
+    uint8_t* stage = smem + stage0 + (size_t)wave * STAGE;
     const int my_len = min(p.slice_cols, p.in - s * p.slice_cols);
     const int ncols = min(64, max(0, my_len - 64 * lane));
     const unsigned slice_byte0 = (unsigned)((size_t)s * p.slice_cols / F::BW * F::BB);
@@ -319,6 +325,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         float* ximg = reinterpret_cast<float*>(smem);
         constexpr int GS = 4;   // slices per image pass: 28672-wide rows (7 slices) take two passes, keeping LDS at 68 KB
         auto img_index = [&](int c, int g0) {
+            if (p.ns == 1) return (c >> 6) * XPITCH + (c & 63);   // (uniform; spares the division)
             const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
             return ((sp - g0) * 64 + (cc >> 6)) * XPITCH + (cc & 63);
         };
@@ -418,7 +425,8 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                     const uint32_t p1 = __builtin_amdgcn_perm(tc, ta, 0x07060302u);    // b1
                     const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u);    // b2 (signed top byte)
                     if (live) {
-                        const int sp = c / p.slice_cols, cc = c - sp * p.slice_cols;
+                        int sp = 0, cc = c;
+                        if (p.ns > 1) { sp = c / p.slice_cols; cc = c - sp * p.slice_cols; }   // (uniform)
                         uint8_t* row = dimg + (size_t)((sp - g0) * 64 + (cc >> 6)) * (XPITCH * 4);
                         *reinterpret_cast<uint32_t*>(row + (cc & 63)) = p0;
                         *reinterpret_cast<uint32_t*>(row + 64 + (cc & 63)) = p1;
@@ -479,8 +487,14 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 }
                 for (int c = XIT * step + tid * 4; c < cend; c += step)   // columns the registers do not cover
                     *reinterpret_cast<float4*>(ximg + img_index(c, 0)) = *reinterpret_cast<const float4*>(p.x + c);
+                GV_STAMP(9);    // image stores issued
                 __syncthreads();
+                GV_STAMP(10);   // image complete (barrier)
                 if (s < GS) read_own_row(0);
+#ifdef NTK_GEMV_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                GV_STAMP(11);   // own row read
+#endif
             }
             if constexpr (!XI)
             for (int g0 = GS; g0 < p.ns; g0 += GS) {   // 28672-wide rows: slices 4..6 in a second pass (weights already in flight)
@@ -519,7 +533,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
 #pragma unroll
             for (int j = 0; j < 32; ++j) x2[j] = f32x2{1.0f, 1.0f};
         }
-        __syncthreads();   // LDS region A becomes the staging area
+        if (p.ns > 1) __syncthreads();   // the image becomes the staging area
         GV_STAMP(2);   // activations in registers
     }
     float sx16[4], sx32[2];
@@ -636,7 +650,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
 #ifdef NTK_GEMV_TRACE
     GV_STAMP(6);   // end
     if (tid == 0 && bid < GT_WG) {
-        gv_t[9] = (unsigned long long)n_my;
+        gv_t[13] = (unsigned long long)n_my;
         for (int e = 0; e < GT_EV; ++e) g_gemv_trace[p.trace_slot & (GT_SLOTS - 1)][bid][e] = gv_t[e];
     }
 #endif
@@ -785,7 +799,8 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     const long rows_per_group = (total + ngroups - 1) / ngroups;
     p.nbatch = (int)((rows_per_group * mats + RB - 1) / RB);
     constexpr int STAGE = F::NL * 1024 + 64;
-    const size_t regionA = (size_t)std::max(L.nwaves * STAGE, std::min(p.ns, 4) * 64 * XPITCH * 4);
+    const size_t image_bytes = (size_t)std::min(p.ns, 4) * 64 * XPITCH * 4;   // same layout as gemv_quant_body
+    const size_t regionA = p.ns == 1 ? image_bytes + (size_t)L.nwaves * STAGE : std::max((size_t)L.nwaves * STAGE, image_bytes);
     L.lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
     // fast prologue: aligned x / norm weights, whole float4s, norm weights fit the 4 register slots per thread
     L.xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(kAblate & 1) && (!norm_w || in <= 4 * 4 * 64 * L.nwaves);

@@ -31,7 +31,7 @@ constexpr int kAblate = NTK_GEMV_ABLATE;
 // Launch timeline (tuning builds only: make HIPFLAGS+=-DNTK_GEMV_TRACE): thread 0 of every workgroup records the constant
 // 100 MHz clock at the phase boundaries of its launch; read back with ntk_debug_gemv_trace(), printed by tools/gemv_trace.py.
 #ifdef NTK_GEMV_TRACE
-constexpr int GT_SLOTS = 64, GT_WG = 512, GT_EV = 10;
+constexpr int GT_SLOTS = 64, GT_WG = 512, GT_EV = 14;
 __device__ unsigned long long g_gemv_trace[GT_SLOTS][GT_WG][GT_EV];
 #define GV_STAMP(ev) do { asm volatile("" ::: "memory"); gv_t[ev] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); } while (0)
 #else

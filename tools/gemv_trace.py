@@ -24,8 +24,8 @@ SHAPES = {
     "8b.gate|up+silu": ("silu", 14336, 4096), "8b.down+res": ("resid", 4096, 14336),
 }
 GT = {"Q8_0": G.GGML_Q8_0, "Q4_K": G.GGML_Q4_K, "Q6_K": G.GGML_Q6_K}
-SLOTS, WG, EV = 64, 512, 10
-NAMES = ["entry", "x landed", "x in regs", "row0 landed", "row0 done", "last landed", "end", "x requested", "row0 requested"]
+SLOTS, WG, EV = 64, 512, 14
+NAMES = ["entry", "x landed", "x in regs", "row0 landed", "row0 done", "last landed", "end", "x requested", "row0 requested", "image stored", "image barrier", "own row read"]
 
 
 def main():
@@ -90,7 +90,7 @@ def main():
             HIP.hipGraphExecDestroy(gexec); HIP.hipGraphDestroy(graph)
             print("== %s %s: %.2f MB per launch, chain of %d (10 ns clock; us relative to the launch's first workgroup entry)" % (dname, sname, per_launch / 1e6, n))
             gaps, totals, rows_ = [], [], []
-            agg = {k: [] for k in range(1, 9)}
+            agg = {k: [] for k in range(1, 12)}
             for j in range(8, n - 2):   # middle of the chain
                 cur, prev = t[(first + j) % SLOTS], t[(first + j - 1) % SLOTS]
                 live = cur[:, 0] > 0
@@ -98,14 +98,14 @@ def main():
                 t0 = cur[live, 0].min()
                 gaps.append((t0 - prev[prev[:, 6] > 0, 6].max()) / 100.0)
                 totals.append((cur[live, 6].max() - t0) / 100.0)
-                for k in range(1, 9):
+                for k in range(1, 12):
                     v = cur[live, k]
                     v = v[v > 0]
                     if len(v): agg[k].append(((v.min() - t0) / 100.0, (np.median(v) - t0) / 100.0, (v.max() - t0) / 100.0))
-                rows_.append((nwg, (cur[live, 0].max() - t0) / 100.0, cur[live, 9].min(), cur[live, 9].max()))
+                rows_.append((nwg, (cur[live, 0].max() - t0) / 100.0, cur[live, 13].min(), cur[live, 13].max()))
             print("   workgroups %d, rows per wave %d..%d; gap from the previous launch's last end to the first entry: %.2f us (median); entries spread over %.2f us"
                   % (rows_[0][0], rows_[0][2], rows_[0][3], np.median(gaps), np.median([r[1] for r in rows_])))
-            for k in (7, 8, 1, 2, 3, 4, 5, 6):
+            for k in (7, 8, 1, 9, 10, 11, 2, 3, 4, 5, 6):
                 if agg[k]:
                     m = np.median(np.array(agg[k]), axis=0)
                     print("   %-14s min %6.2f  median %6.2f  max %6.2f us" % (NAMES[k], m[0], m[1], m[2]))
