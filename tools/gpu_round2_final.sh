@@ -23,6 +23,10 @@ F2=$(ls $OUT/pmc_fetch_q4km/*counter_collection.csv 2>/dev/null | head -1); W2=$
 F=$(ls $OUT/pmc_fetch/*counter_collection.csv 2>/dev/null | head -1); W=$(ls $OUT/pmc_write/*counter_collection.csv 2>/dev/null | head -1)
 [ -n "$F" ] && python tools/pmc_summary.py $F $W --json $OUT/pmc_traffic.json --key 8b_q8_0 --algorithmic-bytes-per-launch 61811624 > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt
 for d in pmc_fetch pmc_write pmc_fetch_q4km pmc_write_q4km trace; do rm -rf $OUT/$d; done
+timeout 300 python tools/gemv_bench.py --dtypes Q8_0,Q4_K,Q6_K > $OUT/gemv_bench.txt 2>&1; grep "Q8_0" $OUT/gemv_bench.txt
+timeout 300 python tools/attn_bench.py > $OUT/attention_by_context.txt 2>&1; grep "^8b" $OUT/attention_by_context.txt | head -8
+[ -f ntransformer_amd/libntransformer_hip_trace.so ] && timeout 300 python tools/gemv_trace.py > $OUT/gemv_launch_timeline.txt 2>&1
+timeout 600 python bench.py --prompt-len 3900 --no-cpu-baseline --no-also --prompt-bench 0 > $OUT/bench_ctx3900.json 2>/dev/null; cut -c1-160 $OUT/bench_ctx3900.json
 timeout 300 python tools/sampling_bench.py > $OUT/sampling_bench.txt 2>&1; tail -8 $OUT/sampling_bench.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log
 tail -5 $OUT/bench.err; du -sh $OUT; ls $OUT
