@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntransformer_hip.so")
+LIB_PATH = os.environ.get("NTK_LIB_PATH") or os.path.join(_HERE, "libntransformer_hip.so")   # (override: A/B of two builds)
 
 NTK_OK = 0
 _STATUS = {0: "ok", -1: "unsupported dtype", -2: "bad shape", -3: "HIP launch/runtime error", -4: "misaligned pointer",
