@@ -401,7 +401,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 // runs].  A thread converts 4 consecutive columns, 8 consecutive threads hold a 32-column sub-block: its exponent and
                 // sum come from three DPP steps (every caller below keeps those 8 threads together: column bases are multiples of 256).
                 uint8_t* dimg = smem;
-                auto xi_store = [&](const u32x4 q, const int c, const bool live, const int g0) {
+                auto xi_store = [&](const u32x4 q, const int sp, const int cc, const bool live) {   // columns cc.. of slice sp
                     const float v0 = live ? __uint_as_float(q.x) : 0.0f, v1 = live ? __uint_as_float(q.y) : 0.0f,
                                 v2 = live ? __uint_as_float(q.z) : 0.0f, v3 = live ? __uint_as_float(q.w) : 0.0f;
                     float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
@@ -425,9 +425,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                     const uint32_t p1 = __builtin_amdgcn_perm(tc, ta, 0x07060302u);    // b1
                     const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u);    // b2 (signed top byte)
                     if (live) {
-                        int sp = 0, cc = c;
-                        if (p.ns > 1) { sp = c / p.slice_cols; cc = c - sp * p.slice_cols; }   // (uniform)
-                        uint8_t* row = dimg + (size_t)((sp - g0) * 64 + (cc >> 6)) * (XPITCH * 4);
+                        uint8_t* row = dimg + (size_t)(sp * 64 + (cc >> 6)) * (XPITCH * 4);
                         *reinterpret_cast<uint32_t*>(row + (cc & 63)) = p0;
                         *reinterpret_cast<uint32_t*>(row + 64 + (cc & 63)) = p1;
                         *reinterpret_cast<uint32_t*>(row + 128 + (cc & 63)) = p2;
@@ -468,22 +466,27 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                 // (host: in <= XIT * step and ns <= 2, so the register quads cover the row and one image pass holds it.  Rows of
                 // several slices -- the 14336 / 28672-column down projections -- were tried with a second pass from memory: correct,
                 // and slower than the float form, 70B Q4_K down 33.4 -> 37.1 us: a workgroup converts the whole row for only 16 rows)
+                int isp = 0, icc = tid * 4;   // (slice, column in the slice) of the thread's quad, advanced without a division: step < slice_cols
 #pragma unroll
                 for (int i = 0; i < XIT; ++i) {
                     if (i * step >= p.in) continue;   // uniform
-                    const int c = tid * 4 + i * step;
-                    xi_store(xv[i], c, c < p.in, 0);
+                    xi_store(xv[i], isp, icc, tid * 4 + i * step < p.in);
+                    icc += step;
+                    if (icc >= p.slice_cols) { icc -= p.slice_cols; ++isp; }
                 }
                 __syncthreads();
                 xi_read(0);
             } else
             {   // pass 0 (the only one up to 16384 columns): straight-line, the registers die here
                 const int cend = min(p.in, GS * p.slice_cols);
+                int isp = 0, icc = tid * 4;   // (slice, column in the slice) of the thread's quad, advanced without a division: step < slice_cols
 #pragma unroll
                 for (int i = 0; i < XIT; ++i) {
                     if (i * step >= cend) continue;   // uniform
                     const int c = tid * 4 + i * step;
-                    *reinterpret_cast<u32x4*>(ximg + (c < cend ? img_index(c, 0) : dummy)) = xv[i];
+                    *reinterpret_cast<u32x4*>(ximg + (c < cend ? (isp * 64 + (icc >> 6)) * XPITCH + (icc & 63) : dummy)) = xv[i];
+                    icc += step;
+                    if (icc >= p.slice_cols) { icc -= p.slice_cols; ++isp; }
                 }
                 for (int c = XIT * step + tid * 4; c < cend; c += step)   // columns the registers do not cover
                     *reinterpret_cast<float4*>(ximg + img_index(c, 0)) = *reinterpret_cast<const float4*>(p.x + c);
@@ -803,7 +806,8 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     const size_t regionA = p.ns == 1 ? image_bytes + (size_t)L.nwaves * STAGE : std::max((size_t)L.nwaves * STAGE, image_bytes);
     L.lds = regionA + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
     // fast prologue: aligned x / norm weights, whole float4s, norm weights fit the 4 register slots per thread
-    L.xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(kAblate & 1) && (!norm_w || in <= 4 * 4 * 64 * L.nwaves);
+    L.xfast = p.x_vec && (in % 4 == 0) && in >= 4 && !(kAblate & 1) && (!norm_w || in <= 4 * 4 * 64 * L.nwaves) &&
+              (p.ns == 1 || 4 * 64 * L.nwaves <= p.slice_cols);   // (the image index advances by one thread-count step per register quad)
     // A16 (K-quants whose blocks are multiples of 16 bytes): every row slice starts 16-byte aligned -> b128 LDS reads,
     // no v_alignbyte.  True for every GGUF tensor (data offsets are 32-byte aligned); the general form covers the rest.
     bool a16 = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
