@@ -18,6 +18,10 @@
 //     partial sums meet in LDS once per batch of 4 rows (one barrier, fixed summation order).
 //   * Fusions the engine uses (ntk_gemv_fused): RMSNorm prologue, Q|K|V or gate|up row segments sharing
 //     one x, residual-add epilogue, SiLU(gate)*up epilogue.
+//   * A decode launch lasts 6-22 us, so its first 3 us are designed like the loop: the activations are requested first thing
+//     (only the register quads the row needs), have landed before a wave requests its first weight row (a CU returns loads in
+//     request order), reach the lanes through a padded LDS image beside the staging areas, and the bookkeeping runs under
+//     their latency.  make trace + tools/gemv_trace.py print the timeline of a launch inside a hipGraph chain.
 //
 // HBM-bound: algorithmic bytes per launch = rows * row_bytes (+ in*4 for x per workgroup from L2).
 #include "gemv_core.hip.h"
