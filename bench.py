@@ -268,7 +268,7 @@ def main():
                       else "decode tokens/sec (%s %s, resident weights, greedy, batch 1)" % (args.model, args.mix),
             "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(tok_s / world / REF_3090_TOK_S, 3) if headline else None,
+            "vs_baseline": round(tok_s / REF_3090_TOK_S, 3) if headline else None,   # whole-job value / the published single-GPU number
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Llama-3.1-%s-shaped %s GGUF tensors (seed 20260925), resident in HBM, %d-token prompt, greedy decode"
                                    % (args.model.upper(), args.mix, args.prompt_len),
