@@ -169,16 +169,6 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale,
                                void* stream);
 
-/* ntk_attention_decode_fused + the Wo projection with residual (ntk_gemv_fused(wo, x = attn_out, resid)) as ONE launch: the first
- * n_heads workgroups compute their head while every wave's first Wo row is in flight, the attention output crosses workgroups
- * inside the launch (csrc/gemv.hip, AttnFuse).  attn_out: [n_heads * head_dim] scratch that receives the attention output.
- * sync3: 4096 DEVICE bytes, zero before the first use (every launch leaves them zero again, except word [2]: != 0 afterwards = a
- * bounded in-kernel wait gave up).  NTK_E_ALIGN / NTK_E_SHAPE / NTK_E_DTYPE: shapes only the two separate launches take. */
-int ntk_attention_gemv_fused(float* attn_out, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
-                             const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
-                             float scale, float theta_base, float freq_scale, const ntk_gemv_seg* wo, const float* resid,
-                             unsigned* sync3, void* stream);
-
 /* Long-context form of ntk_attention_decode_fused: `nsplit` workgroups share a head (positions interleaved), partial
  * softmax states go through `scratch` (ntk_attention_split_scratch_bytes) and a second launch merges them.  Same
  * arguments and results (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches. */
@@ -187,48 +177,6 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
                                void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale, int nsplit,
                                float* scratch, void* stream);
-
-/* One decode token as ONE persistent launch (csrc/decode_persistent.hip): the operator table of a token -- the same fused
- * operators as above, in order -- is compiled once into a device-resident plan; ntk_persistent_launch then runs the whole
- * table in a single kernel (one workgroup per CU, weights prefetched across operator boundaries, activations handed
- * between workgroups through an in-launch grid barrier).  Results = the launch-by-launch sequence (summation order of the
- * RMSNorm / attention reductions aside).  Constraints (NTK_E_* from plan_create otherwise, callers fall back to launches):
- * quantised dtypes only, 16-byte aligned W / x / norm_w / caches, in_features % 4 == 0 and <= 32768, norm only with
- * in_features <= 8192, head_dim 64 / 128 / 256. */
-enum { NTK_POP_GEMV = 0, NTK_POP_ATTENTION = 1 };
-typedef struct ntk_pop {
-    int kind;                 /* NTK_POP_GEMV: the arguments of ntk_gemv_fused; NTK_POP_ATTENTION: of ntk_attention_decode_fused */
-    int wait;                 /* != 0: the operator reads activations written earlier in the launch -> waits for the grid */
-    int arrive;               /* != 0: a later operator reads what this one writes -> signals the grid when done        */
-    int plain_store;          /* != 0: outputs are only read after the launch (logits): ordinary stores                */
-    /* GEMV */
-    ntk_gemv_seg segs[3];
-    int nseg, in_features, silu_pair;
-    float eps;
-    const float* x;
-    const float* norm_w;
-    const float* resid;
-    /* attention */
-    float* out;
-    const float* q;
-    const float* k;
-    const float* v;
-    void* k_cache;
-    void* v_cache;
-    const float* inv_freq;
-    int n_heads, n_kv_heads, head_dim, max_seq;
-    float scale, theta_base, freq_scale;
-} ntk_pop;
-int  ntk_persistent_plan_create(const ntk_pop* ops, int nops, void** plan_out);
-void ntk_persistent_plan_destroy(void* plan);
-/* d_pos: DEVICE int, the position of the token (as ntk_attention_decode_fused).  Enqueues a memset of the barrier words and
- * the kernel on `stream`; capturable. */
-int  ntk_persistent_launch(void* plan, const int* d_pos, void* stream);
-/* after a synchronise: NTK_OK, or NTK_E_LAUNCH if a bounded in-kernel wait gave up (op_index_out = the operator) */
-int  ntk_persistent_error(void* plan, int* op_index_out);
-int  ntk_persistent_grid(void* plan);
-/* debugging aid: per-operator timestamps of two workgroups (see decode_persistent.hip); returns the operator count */
-int  ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int cap_ops);
 
 /* Tuning knob: Q4_K / Q6_K launches of at least this many weight bytes (default 48 MiB) take the integer-activation form of the GEMV
  * (three int8 digit planes per 32-column sub-block on v_dot4: csrc/gemv_core.hip.h XInt).  0 = every eligible launch (the parity
@@ -243,6 +191,7 @@ void     ntk_gemv_tune_xi_min_bytes(size_t bytes);
  * even in number and < 1023; ntk_tp_advance_epoch ends the forward.  All ranks must issue the same sequence.  n % 4 == 0,
  * n <= max_floats, world <= 8.  ntk_tp_error after a synchronise: 0, or non-zero if a bounded wait for a peer gave up. */
 size_t   ntk_tp_comm_bytes(size_t max_floats);
+void*    ntk_tp_comm_alloc(size_t bytes);   /* fine-grained device memory (peer-visible without relying on a cache write-back); nt_hip_free */
 int      ntk_tp_comm_reset(void* comm, void* stream);
 float*   ntk_tp_slot(void* comm, size_t max_floats, unsigned call_index);
 int      ntk_tp_allreduce_add(float* hidden, void* const* peers, int rank, int world, size_t max_floats, unsigned call_index, int n, void* stream);

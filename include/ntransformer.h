@@ -60,7 +60,8 @@ typedef struct nt_synth_spec { /* seeded synthetic Llama-shaped model (no checkp
 
 int  nt_engine_load_ex(nt_engine_t e, const char* model_path, int max_context);
 int  nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_context);
-/* "fused" / "graph" / "device_sampling" / "batched_prefill" / "persistent" = "0" | "1" */
+/* "fused" / "graph" / "device_sampling" / "batched_prefill" / "bf16_prefill" = "0" | "1"; "persistent" / "fuse_attention" are accepted
+ * everywhere and take effect only in EXPERIMENTS=1 builds (include/ntk_experiments.h) */
 int  nt_engine_set_option(nt_engine_t e, const char* key, const char* value);
 const char* nt_engine_last_error(nt_engine_t e);
 void nt_gen_params_default(nt_gen_params* p);
@@ -84,9 +85,10 @@ int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int o
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */
 uint64_t nt_engine_weight_bytes(nt_engine_t e);
 int  nt_engine_max_context(nt_engine_t e);
-/* which form the fused decode step takes for this model: "persistent (...)" or "fused (5 launches/layer)" */
+/* which form the fused decode step takes at the current position: "fused (5 launches/layer)", or (EXPERIMENTS=1 builds with the
+ * "persistent" option on) "persistent (...)" */
 const char* nt_engine_decode_path(nt_engine_t e);
-void* nt_engine_persistent_plan(nt_engine_t e);
+void* nt_engine_persistent_plan(nt_engine_t e);   /* plan handle for ntk_persistent_debug; NULL outside EXPERIMENTS=1 builds */
 /* Tensor-parallel decoding over `world` GPUs, one engine (normally one process) per rank -- SURVEY 8(f) rank 4, no reference
  * counterpart.  nt_engine_tp_configure BEFORE load: the engine then keeps rows [rank/world) of Wq/Wk/Wv/gate/up (whole heads) and
  * the matching columns of Wo/down; n_heads, n_kv_heads and the FFN width must divide by `world`, column slices must be whole
@@ -101,7 +103,18 @@ int  nt_engine_tp_export(nt_engine_t e, void* handle64, void** raw_ptr);
 int  nt_engine_tp_connect(nt_engine_t e, const void* handles, void* const* raw_ptrs);
 unsigned nt_engine_tp_error(nt_engine_t e);
 /* host only: columns [rank * in/world, (rank + 1) * in/world) of every row of a GGUF matrix, re-packed row-major into dst */
-int  nt_tp_slice_columns(void* dst, const void* src, int dtype, int64_t out_features, int64_t in_features, int rank, int world);   /* plan handle for ntk_persistent_debug (NULL if the model does not qualify) */
+int  nt_tp_slice_columns(void* dst, const void* src, int dtype, int64_t out_features, int64_t in_features, int rank, int world);
+/* ---- parity instrumentation (tests/test_parity_depth.py; never used by generate) --------------------------------------------
+ * nt_engine_debug_run_layers: layers [first, first + count) of the loaded model on CALLER-SUPPLIED hidden states -- hidden_in
+ * [n_tokens][hidden] (host) in, hidden_out [n_tokens][hidden] (host) out -- for tokens at positions start_pos...: layer-wise teacher
+ * forcing against a checker (no error amplification through depth).  mode 0: the reference's 1:1 launcher sequence (prompt
+ * projections batched or per token, as "batched_prefill" says); mode 1: the fused single-token launches (n_tokens == 1); mode 2: the
+ * same captured into a hipGraph and replayed.  The layers write the KV-cache rows of these positions as in a normal forward.
+ * nt_engine_debug_kv_read / _write: rows [pos0, pos0 + n) of one layer's K and V cache, [n][n_kv_heads * head_dim] IEEE halves. */
+int  nt_engine_debug_run_layers(nt_engine_t e, const float* hidden_in, int n_tokens, int start_pos, int first_layer, int n_layers,
+                                int mode, float* hidden_out);
+int  nt_engine_debug_kv_read(nt_engine_t e, int layer, int pos0, int n, uint16_t* k_out, uint16_t* v_out);
+int  nt_engine_debug_kv_write(nt_engine_t e, int layer, int pos0, int n, const uint16_t* k, const uint16_t* v);
 /* write a synthetic GGUF v3 file with the same generator (0 = ok) */
 int  nt_synth_write_gguf(const char* path, const nt_synth_spec* spec, int nthreads);
 /* fill one tensor of the synthetic plan into host memory (for CPU baselines); returns bytes or negative */

@@ -136,6 +136,20 @@ int nt_engine_decode_fused(nt_engine_t e, int token, int pos, int use_graph, flo
     return m.check_persistent();
 }
 
+int nt_engine_debug_run_layers(nt_engine_t e, const float* hidden_in, int n_tokens, int start_pos, int first_layer, int n_layers, int mode,
+                               float* hidden_out) {
+    if (!e || !E(e)->loaded()) return NTK_E_NULL;
+    return E(e)->model().debug_run_layers(hidden_in, n_tokens, start_pos, first_layer, n_layers, mode, hidden_out);
+}
+int nt_engine_debug_kv_read(nt_engine_t e, int layer, int pos0, int n, uint16_t* k_out, uint16_t* v_out) {
+    if (!e || !E(e)->loaded()) return NTK_E_NULL;
+    return E(e)->model().debug_kv(layer, pos0, n, k_out, v_out, false);
+}
+int nt_engine_debug_kv_write(nt_engine_t e, int layer, int pos0, int n, const uint16_t* k, const uint16_t* v) {
+    if (!e || !E(e)->loaded()) return NTK_E_NULL;
+    return E(e)->model().debug_kv(layer, pos0, n, const_cast<uint16_t*>(k), const_cast<uint16_t*>(v), true);
+}
+
 void* nt_engine_persistent_plan(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().persistent_plan() : nullptr; }
 const char* nt_engine_decode_path(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().decode_path() : ""; }
 

@@ -1,6 +1,9 @@
 // engine/model.cpp -- see model.h
 #include "model.h"
 #include "../../../include/ntk.h"
+#ifdef NTK_EXPERIMENTS
+#include "../../../include/ntk_experiments.h"
+#endif
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -30,8 +33,11 @@ void Model::free_all() {
             if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx));
             gx = nullptr;
         }
+#ifdef NTK_EXPERIMENTS
     if (persistent_plan_) ntk_persistent_plan_destroy(persistent_plan_);
+#endif
     persistent_plan_ = nullptr;
+    persistent_on_ = false;
     for (int r = 0; r < 8; ++r) {   // peers' communication buffers mapped through hipIpc
         if (tp_peer_opened_[r] && tp_peers_[r]) (void)ntk_ipc_close(tp_peers_[r]);
         tp_peers_[r] = nullptr;
@@ -295,7 +301,6 @@ int Model::finish_load(int /*max_context*/) {
     }
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
-    if (tp_world_ == 1) (void)build_persistent_plan();   // optional fast path: failure only means the launch path is used
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
     fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights)\nFree VRAM: %.1f GB\n",
@@ -339,7 +344,8 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
     if (tp_world_ > 1) {   // communication buffer: flags + two slots of one prompt's worth of hidden vectors
         tp_max_floats_ = S * H;
-        tp_comm_ = dev(ntk_tp_comm_bytes(tp_max_floats_), false);
+        tp_comm_ = ntk_tp_comm_alloc(ntk_tp_comm_bytes(tp_max_floats_));   // fine-grained: csrc/tp.hip
+        if (tp_comm_) allocs_.push_back(tp_comm_);
         if (!tp_comm_ || ntk_tp_comm_reset(tp_comm_, nullptr) != NTK_OK || ntk_device_synchronize() != NTK_OK) { err_ = "communication buffer allocation failed"; return NTK_E_NOMEM; }
     }
     d_recent_ = (int*)dev(kRecentCap * 4, false);
@@ -392,6 +398,27 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     if (ntk_memcpy_h2d_async(positions_, pos.data(), (size_t)T * 4, s) != NTK_OK) return nullptr;
     if (ntk_stream_synchronize(s) != NTK_OK) return nullptr;   // `pos` / `tokens` are host temporaries
 
+    int rc = layers_1to1(T, start_pos, 0, cfg_.n_layers);
+    auto ok = [&](int st) { if (st != NTK_OK && rc == NTK_OK) rc = st; };
+    float* last = hidden_ + (size_t)(T - 1) * H;
+    ok(ntk_rmsnorm(last, last, (const float*)output_norm_.ptr, 1, H, cfg_.norm_eps, s));   // in place, :658-659
+    {
+        const int st = ntk_gemv(logits_, output_.ptr, last, (int)output_.out_f, (int)output_.in_f, output_.dtype, s);
+        if (st == NTK_E_DTYPE) fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dtype_name(output_.dtype));   // gemm.cu:801-803
+        else ok(st);
+    }
+    if (tp_world_ > 1) ok(ntk_tp_advance_epoch(tp_comm_, s));
+    ok(ntk_stream_synchronize(s));
+    if (rc == NTK_OK) rc = check_tp();
+    if (rc != NTK_OK) { if (err_.empty() || rc != NTK_E_LAUNCH) err_ = std::string("forward failed: ") + ntk_status_string(rc); return nullptr; }
+    return logits_;
+}
+
+// layers [first, last) of the 1:1 path on hidden_[T][H] at positions start_pos.. (positions_ already on the device)
+int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
+    const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
+    const int qd = nh * hd, kvd = nkv * hd;
+    void* s = stream_;
     const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
     const float scale = 1.0f / sqrtf((float)hd);
     float* q_buf = workspace_;
@@ -465,7 +492,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         project(residual_, w, X, H, xstride);
         ok(ntk_add_inplace(hidden_, residual_, T * H, s));
     };
-    for (int i = 0; i < cfg_.n_layers; ++i) {
+    for (int i = first; i < last_layer; ++i) {
         const LayerWeights& L = layers_[i];
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
@@ -492,13 +519,7 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
         project_add(L.w_down, gate_buf, I);
         if (rc != NTK_OK) break;
     }
-    float* last = hidden_ + (size_t)(T - 1) * H;
-    ok(ntk_rmsnorm(last, last, (const float*)output_norm_.ptr, 1, H, cfg_.norm_eps, s));   // in place, :658-659
-    gemv(logits_, output_, last);
-    if (tp_world_ > 1) ok(ntk_tp_advance_epoch(tp_comm_, s));
-    ok(ntk_stream_synchronize(s));
-    if (rc != NTK_OK) { err_ = std::string("forward failed: ") + ntk_status_string(rc); return nullptr; }
-    return logits_;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -542,30 +563,71 @@ int Model::sample_on_device(const int* recent, int n_recent, float repeat_penalt
                             h_token_, sample_scratch_, s);
 }
 
+// profiling hook (only inside profile_token(), never while capturing).  Fine mode: an event pair around every
+// launch.  Coarse mode: ONE event where the launch class changes -- a run of same-class launches is timed as a
+// whole (its kernels and the boundaries between them), so the cost of the events is paid once per run.
+void Model::prof_mark(int cls, bool begin) {
+    if (!prof_) return;
+    void* s = stream_;
+    if (prof_coarse_) {
+        if (!begin) return;
+        if (!prof_->empty() && prof_->back().cls == cls) { ++prof_->back().n; return; }
+        void* e = ntk_event_create();
+        ntk_event_record(e, s);
+        const bool shared = !prof_->empty();
+        if (shared) prof_->back().b = e;
+        prof_->push_back({cls, e, nullptr, 1, shared});
+        return;
+    }
+    void* e = ntk_event_create();
+    ntk_event_record(e, s);
+    if (begin) prof_->push_back({cls, e, nullptr, 1, false}); else prof_->back().b = e;
+}
+
 int Model::enqueue_token(bool greedy) {
+    const int H = cfg_.hidden_size;
+    void* s = stream_;
+    tp_call_ = 0;
+    prof_mark(2, true);
+    const int est = ntk_embed_rows(hidden_, token_embd_.ptr, d_token_, 1, H, token_embd_.dtype, s);
+    prof_mark(2, false);
+    if (est != NTK_OK && est != NTK_E_DTYPE) return est;
+#ifdef NTK_EXPERIMENTS
+    if (use_persistent_now()) {   // every layer and the LM head in one launch
+        NT_TRY(ntk_persistent_launch(persistent_plan_, d_pos_, s));
+        if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
+        NT_TRY(ntk_advance_pos(d_pos_, s));
+        return NTK_OK;
+    }
+#endif
+    NT_TRY(enqueue_layers(0, cfg_.n_layers));
+    // final RMSNorm + LM head (one launch for a quantised output matrix), then the token's tail
+    {
+        const DevTensor& w = output_;
+        if (is_quant(w.dtype)) {
+            ntk_gemv_seg seg = {w.ptr, logits_, (int)w.out_f, w.dtype};
+            prof_mark(0, true);
+            NT_TRY(ntk_gemv_fused(&seg, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s));
+            prof_mark(0, false);
+        } else {
+            NT_TRY(ntk_rmsnorm(residual_ + H, hidden_, (const float*)output_norm_.ptr, 1, (int)w.in_f, cfg_.norm_eps, s));
+            NT_TRY(ntk_gemv(logits_, w.ptr, residual_ + H, (int)w.out_f, (int)w.in_f, w.dtype, s));
+        }
+    }
+    prof_mark(2, true);
+    if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
+    NT_TRY(ntk_advance_pos(d_pos_, s));
+    if (tp_world_ > 1) NT_TRY(ntk_tp_advance_epoch(tp_comm_, s));
+    prof_mark(2, false);
+    return NTK_OK;
+}
+
+// layers [first, last) of the fused single-token path on hidden_[H] (position in *d_pos_)
+int Model::enqueue_layers(int first, int last_layer) {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     void* s = stream_;
-    tp_call_ = 0;
-    // profiling hook (only inside profile_token(), never while capturing).  Fine mode: an event pair around every
-    // launch.  Coarse mode: ONE event where the launch class changes -- a run of same-class launches is timed as a
-    // whole (its kernels and the boundaries between them), so the cost of the events is paid once per run.
-    auto mark = [&](int cls, bool begin) {
-        if (!prof_) return;
-        if (prof_coarse_) {
-            if (!begin) return;
-            if (!prof_->empty() && prof_->back().cls == cls) { ++prof_->back().n; return; }
-            void* e = ntk_event_create();
-            ntk_event_record(e, s);
-            const bool shared = !prof_->empty();
-            if (shared) prof_->back().b = e;
-            prof_->push_back({cls, e, nullptr, 1, shared});
-            return;
-        }
-        void* e = ntk_event_create();
-        ntk_event_record(e, s);
-        if (begin) prof_->push_back({cls, e, nullptr, 1, false}); else prof_->back().b = e;
-    };
+    auto mark = [&](int cls, bool begin) { prof_mark(cls, begin); };
     const float scale = 1.0f / sqrtf((float)hd);
     const size_t kv_layer = (size_t)cfg_.max_seq_len * kvd;
     float* q_buf = workspace_;
@@ -592,7 +654,9 @@ int Model::enqueue_token(bool greedy) {
                 const int st = ntk_gemv_fused(segs, n, x, (int)ws[0]->in_f, nw, cfg_.norm_eps, nullptr, 0, s);
                 mark(0, false);
                 if (st == NTK_OK) return NTK_OK;
-                if (st != NTK_E_DTYPE && st != NTK_E_ALIGN) return st;   // those two: formats / alignment only the per-format launches take
+                // formats / alignment / workgroup split / LDS size the optional one-launch form does not take: the per-format
+                // launches below do (the pair kernel is an optimisation, never the only way)
+                if (st != NTK_E_DTYPE && st != NTK_E_ALIGN && st != NTK_E_SHAPE) return st;
             }
         }
         for (int a = 0; a < n; ++a) {
@@ -629,17 +693,7 @@ int Model::enqueue_token(bool greedy) {
         return project(ws, ys, 1, x, norm, resid);
     };
 
-    mark(2, true);
-    const int est = ntk_embed_rows(hidden_, token_embd_.ptr, d_token_, 1, H, token_embd_.dtype, s);
-    mark(2, false);
-    if (est != NTK_OK && est != NTK_E_DTYPE) return est;
-    if (use_persistent_now()) {   // every layer and the LM head in one launch
-        NT_TRY(ntk_persistent_launch(persistent_plan_, d_pos_, s));
-        if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
-        NT_TRY(ntk_advance_pos(d_pos_, s));
-        return NTK_OK;
-    }
-    for (int i = 0; i < cfg_.n_layers; ++i) {
+    for (int i = first; i < last_layer; ++i) {
         const LayerWeights& L = layers_[i];
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
@@ -648,6 +702,7 @@ int Model::enqueue_token(bool greedy) {
             float* ys[3] = {q_buf, k_buf, v_buf};
             NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
         }
+#ifdef NTK_EXPERIMENTS
         if (attn_regime_ == 0 && fuse_attention_ && attn_sync_ && is_quant(L.wo.dtype) && tp_world_ == 1) {
             // attention producers inside the Wo launch: one launch, one boundary and one first-byte latency less per layer
             ntk_gemv_seg wo = {L.wo.ptr, hidden_, (int)L.wo.out_f, L.wo.dtype};
@@ -659,6 +714,7 @@ int Model::enqueue_token(bool greedy) {
             if (st == NTK_OK) goto ffn;
             if (st != NTK_E_ALIGN && st != NTK_E_SHAPE && st != NTK_E_DTYPE) return st;   // those: shapes only the two launches take
         }
+#endif
         mark(1, true);
         if (attn_regime_ == 0)
             NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
@@ -674,7 +730,9 @@ int Model::enqueue_token(bool greedy) {
         } else {
             NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
         }
+#ifdef NTK_EXPERIMENTS
     ffn:
+#endif
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
             ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
             mark(0, true);
@@ -693,27 +751,112 @@ int Model::enqueue_token(bool greedy) {
             NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_));
         }
     }
-    NT_TRY(project1(output_, logits_, hidden_, &output_norm_, nullptr));
-    mark(2, true);
-    if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
-    NT_TRY(ntk_advance_pos(d_pos_, s));
-    if (tp_world_ > 1) NT_TRY(ntk_tp_advance_epoch(tp_comm_, s));
-    mark(2, false);
     return NTK_OK;
+}
+
+// ---- parity instrumentation (tests; reached through nt_engine_debug_*, never from the generate loop) --------------------------
+// Layers [first, first + count) on caller-supplied hidden states: hidden_in [T][H] (host) -> hidden_out [T][H] (host), tokens at
+// positions start_pos...  mode 0: the 1:1 launcher sequence (prompt projections batched or per token as set_batched_prefill says);
+// mode 1: the fused single-token launches (T == 1); mode 2: the same replayed from a freshly captured hipGraph.  The KV cache
+// rows of the T positions are written by the layers as in a normal forward; rows of earlier positions are whatever the cache
+// holds (debug_kv_write puts a checker's rows there: layer-wise teacher forcing).
+int Model::debug_run_layers(const float* hidden_in, int T, int start_pos, int first, int count, int mode, float* hidden_out) {
+    if (!hidden_in || !hidden_out) return NTK_E_NULL;
+    if (T <= 0 || start_pos < 0 || start_pos + T > cfg_.max_seq_len || first < 0 || count < 0 || first + count > cfg_.n_layers) return NTK_E_SHAPE;
+    if (mode != 0 && T != 1) return NTK_E_SHAPE;
+    if (tp_world_ > 1) return NTK_E_SHAPE;
+    const size_t bytes = (size_t)T * cfg_.hidden_size * 4;
+    void* s = stream_;
+    NT_TRY(ntk_memcpy_h2d_async(hidden_, hidden_in, bytes, s));
+    int rc;
+    if (mode == 0) {
+        std::vector<int> pos(T);
+        for (int i = 0; i < T; ++i) pos[i] = start_pos + i;
+        NT_TRY(ntk_memcpy_h2d_async(positions_, pos.data(), (size_t)T * 4, s));
+        NT_TRY(ntk_stream_synchronize(s));
+        rc = layers_1to1(T, start_pos, first, first + count);
+    } else {
+        NT_TRY(set_device_pos(start_pos));
+        pick_attention_regime();
+        if (mode == 1) {
+            rc = enqueue_layers(first, first + count);
+        } else {
+            hipStream_t st = static_cast<hipStream_t>(s);
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) return NTK_E_LAUNCH;
+            rc = enqueue_layers(first, first + count);
+            const hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc == NTK_OK && (e != hipSuccess || !g)) rc = NTK_E_LAUNCH;
+            hipGraphExec_t ex = nullptr;
+            if (rc == NTK_OK && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) rc = NTK_E_LAUNCH;
+            if (g) (void)hipGraphDestroy(g);
+            if (rc == NTK_OK && hipGraphLaunch(ex, st) != hipSuccess) rc = NTK_E_LAUNCH;
+            if (rc == NTK_OK) rc = ntk_stream_synchronize(s);
+            if (ex) (void)hipGraphExecDestroy(ex);
+        }
+    }
+    if (rc != NTK_OK) return rc;
+    NT_TRY(ntk_memcpy_d2h_async(hidden_out, hidden_, bytes, s));
+    return ntk_stream_synchronize(s);
+}
+
+// cache rows [pos0, pos0 + n) of one layer, [n][n_kv_heads * head_dim] halves each (reference layout, transformer.cpp:340-346)
+int Model::debug_kv(int layer, int pos0, int n, uint16_t* k, uint16_t* v, bool write) {
+    if (!k || !v) return NTK_E_NULL;
+    if (layer < 0 || layer >= cfg_.n_layers || pos0 < 0 || n < 0 || pos0 + n > cfg_.max_seq_len) return NTK_E_SHAPE;
+    const size_t per = (size_t)cfg_.n_kv_heads * cfg_.head_dim;
+    const size_t off = ((size_t)layer * cfg_.max_seq_len + pos0) * per, bytes = (size_t)n * per * 2;
+    void* s = stream_;
+    if (write) {
+        NT_TRY(ntk_memcpy_h2d_async(k_cache_ + off, k, bytes, s));
+        NT_TRY(ntk_memcpy_h2d_async(v_cache_ + off, v, bytes, s));
+    } else {
+        NT_TRY(ntk_memcpy_d2h_async(k, k_cache_ + off, bytes, s));
+        NT_TRY(ntk_memcpy_d2h_async(v, v_cache_ + off, bytes, s));
+    }
+    return ntk_stream_synchronize(s);
+}
+
+// A tensor-parallel exchange whose bounded wait for a peer gave up has added garbage: surface it (and clear the sticky word)
+int Model::check_tp() {
+    if (tp_world_ <= 1 || !tp_comm_) return NTK_OK;
+    const unsigned e = tp_error();
+    if (e == 0u) return NTK_OK;
+    const unsigned zero = 0u;
+    (void)ntk_memcpy_h2d_async(static_cast<uint8_t*>(tp_comm_) + 128, &zero, 4, stream_);
+    (void)ntk_stream_synchronize(stream_);
+    err_ = "tensor-parallel exchange: a peer rank did not arrive (call tag " + std::to_string(e) + "); the token's results are invalid";
+    fprintf(stderr, "%s\n", err_.c_str());
+    return NTK_E_LAUNCH;
 }
 
 bool Model::use_persistent_now() const {
     return persistent_plan_ && persistent_on_ && attn_regime_ == 0 && !prof_;
 }
 
-const char* Model::decode_path() const {
-    return (persistent_plan_ && persistent_on_) ? "persistent (1 launch per token in the single-pass attention regime, fused launches beyond)" : "fused (5 launches/layer)";
+void Model::set_persistent(bool on) {
+    persistent_on_ = false;
+    if (!on || tp_world_ != 1 || layers_.empty()) return;
+    if (!persistent_plan_) (void)build_persistent_plan();   // built on first use (EXPERIMENTS=1 builds only): it allocates device memory
+    persistent_on_ = persistent_plan_ != nullptr;
 }
 
+// what decode_step_fused() emits at the CURRENT position (the persistent form covers the single-pass attention regime only)
+const char* Model::decode_path() const {
+    if (persistent_plan_ && persistent_on_)
+        return attn_regime_ == 0 ? "persistent (1 launch per token in the single-pass attention regime, fused launches beyond)"
+                                 : "fused (5 launches/layer; persistent below the split-attention regime)";
+    return "fused (5 launches/layer)";
+}
+
+// after a sync: NTK_OK, or NTK_E_LAUNCH when an in-kernel bounded wait gave up (tensor-parallel exchange; with
+// EXPERIMENTS=1 also the persistent token kernel and the attention-in-Wo launch, which are then disabled)
 int Model::check_persistent() {
+    NT_TRY(check_tp());
+#ifdef NTK_EXPERIMENTS
     if (attn_sync_ && fuse_attention_) {   // ntk_attention_gemv_fused: a bounded in-kernel wait that gave up
         unsigned w[3] = {0, 0, 0};
-        nt_hip_memcpy_d2h(w, attn_sync_, sizeof w);
+        if (ntk_memcpy_d2h_async(w, attn_sync_, sizeof w, stream_) != NTK_OK || ntk_stream_synchronize(stream_) != NTK_OK) return NTK_E_LAUNCH;
         if (w[2] != 0) {
             fuse_attention_ = false;
             nt_hip_memset(attn_sync_, 0, 4096);
@@ -723,7 +866,7 @@ int Model::check_persistent() {
             return NTK_E_LAUNCH;
         }
     }
-    if (!persistent_plan_) return NTK_OK;
+    if (!persistent_plan_ || !persistent_on_) return NTK_OK;
     int op = -1;
     const int st = ntk_persistent_error(persistent_plan_, &op);
     if (st != NTK_OK) {
@@ -732,8 +875,12 @@ int Model::check_persistent() {
         fprintf(stderr, "%s\n", err_.c_str());
     }
     return st;
+#else
+    return NTK_OK;
+#endif
 }
 
+#ifdef NTK_EXPERIMENTS
 // The token's operator table for the persistent kernel: exactly the sequence enqueue_token() launches.
 int Model::build_persistent_plan() {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
@@ -827,6 +974,9 @@ int Model::build_persistent_plan() {
     if (!ok) return NTK_E_DTYPE;
     return ntk_persistent_plan_create(ops.data(), (int)ops.size(), &persistent_plan_);
 }
+#else
+int Model::build_persistent_plan() { return NTK_E_SHAPE; }
+#endif
 
 void Model::pick_attention_regime() {
     attn_regime_ = (attn_scratch_ && (cfg_.head_dim == 64 || cfg_.head_dim == 128 || cfg_.head_dim == 256))

@@ -76,14 +76,18 @@ public:
     // One decode token as ONE persistent launch (csrc/decode_persistent.hip) instead of 5 launches per layer.  On by default
     // when the model qualifies (quantised matrices, head_dim 64 / 128); short contexts only (single-pass attention regime),
     // longer ones keep the launch path.  Turned off for good if the kernel ever reports a bounded wait that gave up.
-    void set_persistent(bool on) { persistent_on_ = on; }
+    void set_persistent(bool on);   // EXPERIMENTS=1 builds only; otherwise stays off
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
     void set_bf16_prefill(bool on) { bf16_prefill_ = on; }   // batched prompt: BF16-MFMA (64 tokens / pass) or the F32-MFMA form (16)
     bool persistent_available() const { return persistent_plan_ != nullptr; }
     void* persistent_plan() const { return persistent_plan_; }
     // which form decode_step_fused(…) emits at the current position: "persistent" / "fused launches"
     const char* decode_path() const;
-    int check_persistent();   // after a sync: NTK_OK, or NTK_E_LAUNCH (and the path is disabled) if a wait timed out
+    int check_persistent();   // after a sync: NTK_OK, or NTK_E_LAUNCH if an in-kernel bounded wait gave up (TP exchange, experiments)
+    int check_tp();           // the tensor-parallel part of it: error word of the exchange kernel, surfaced and cleared
+    // parity instrumentation (tests): layers [first, first+count) on caller-supplied hidden states; KV cache rows in / out
+    int debug_run_layers(const float* hidden_in, int T, int start_pos, int first, int count, int mode, float* hidden_out);
+    int debug_kv(int layer, int pos0, int n, uint16_t* k, uint16_t* v, bool write);
     // One fused token launched eagerly and timed with HIP events on the compute stream.
     // ms[c] / calls[c] per class c: 0 quant GEMV, 1 attention, 2 everything else (embed, argmax, pos); calls[3] = timed
     // intervals.  fine (coarse = false): an event pair around every launch.  coarse: one event per change of class, so
@@ -117,6 +121,9 @@ private:
     float* tp_slot() const;           // where the next partial vector goes
     void free_all();
     int enqueue_token(bool greedy);   // the fused launch sequence for one token
+    int enqueue_layers(int first, int last);            // its layer loop
+    int layers_1to1(int T, int start_pos, int first, int last);   // the layer loop of forward()
+    void prof_mark(int cls, bool begin);
     bool use_persistent_now() const;
     int build_persistent_plan();      // the same operator sequence as a table for ntk_persistent_launch (nullptr plan if unsupported)
 

@@ -25,6 +25,9 @@
 //
 // HBM-bound: algorithmic bytes per launch = rows * row_bytes (+ in*4 for x per workgroup from L2).
 #include "gemv_core.hip.h"
+#ifdef NTK_EXPERIMENTS
+#include "../../include/ntk_experiments.h"
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -38,164 +41,14 @@ namespace ntk {
 //            one column slice, the staging areas over the image -- behind a barrier -- for wider rows)
 //   [A, ..)  partial sums [2][rw][ns][RB] + 16 floats reduction scratch
 // ------------------------------------------------------------------------------------------------
-// ---- attention pre-phase (AttnFuse): attention.hip's single-pass decode kernel on the 8 waves of a GEMV workgroup ----
-__device__ __forceinline__ void att_unpack8(const u32x4 r, float (&f)[8]) {
-    f[0] = h2f((uint16_t)(r.x & 0xFFFF)); f[1] = h2f((uint16_t)(r.x >> 16));
-    f[2] = h2f((uint16_t)(r.y & 0xFFFF)); f[3] = h2f((uint16_t)(r.y >> 16));
-    f[4] = h2f((uint16_t)(r.z & 0xFFFF)); f[5] = h2f((uint16_t)(r.z >> 16));
-    f[6] = h2f((uint16_t)(r.w & 0xFFFF)); f[7] = h2f((uint16_t)(r.w >> 16));
-}
-template <int LPR>
-__device__ __forceinline__ void att_head(const AttnFuse& a, float* lds, int head, int pos) {
-    constexpr int PPW = 64 / LPR, NW = 8, G = NW * PPW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hd = a.hd, n_kv = a.n_kv_heads, group = a.n_heads / n_kv, half_dim = hd / 2;
-    float* qs = lds;              // [hd] post-RoPE query
-    float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
-    float* vx = kx + hd;          // [hd] value of this token, rounded through half
-    float* ms = vx + hd;          // [NW]
-    float* ls = ms + NW;          // [NW]
-    float* accs = ls + NW;        // [NW][hd]
-    const size_t stride = (size_t)n_kv * hd;
-    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
-    const int kv_head = head / group;
-    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
-    const bool writer = (head % group == 0) && pos < a.max_seq;
-    const uint16_t* kbase = a.kc + (size_t)kv_head * hd + 8 * part_i;
-    const uint16_t* vbase = a.vc + (size_t)kv_head * hd + 8 * part_i;
-    int p = g;
-    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
-    if (p < pos) {
-        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
-        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
-    }
-    for (int i = tid; i < half_dim; i += (int)blockDim.x) {
-        const float qa = a.q[(size_t)head * hd + i], qb = a.q[(size_t)head * hd + i + half_dim];
-        const float ka = a.k[(size_t)kv_head * hd + i], kb = a.k[(size_t)kv_head * hd + i + half_dim];
-        // reference rotary.cu:46-60; inv_freq holds 1/powf(theta, 2i/hd) computed once on the host
-        const float freq = a.inv_freq ? a.inv_freq[i] : 1.0f / (float)pow((double)a.theta, (double)((2.0f * i) / hd));
-        const float angle = pos * freq * a.fscale;
-        const float c = cosf(angle), sn = sinf(angle);
-        qs[i] = qa * c - qb * sn; qs[i + half_dim] = qb * c + qa * sn;
-        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
-        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
-        if (writer) { a.kc[cache_row + i] = ha; a.kc[cache_row + i + half_dim] = hb; }
-    }
-    for (int i = tid; i < hd; i += (int)blockDim.x) {
-        const uint16_t hv = f2h(a.v[(size_t)kv_head * hd + i]);
-        vx[i] = h2f(hv);
-        if (writer) a.vc[cache_row + i] = hv;
-    }
-    __syncthreads();
-    float qreg[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
-    float m = -INFINITY, l = 0.0f, acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-    for (; p <= pos; p += G) {
-        float kf[8], vf[8];
-        if (p < pos) {
-            att_unpack8(kraw, kf);
-            att_unpack8(vraw, vf);
-        } else {   // the token being decoded
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
-        }
-        const int pn = p + G;
-        if (pn < pos) {
-            kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
-            vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
-        }
-        float sc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
-        sc = group_sum<LPR>(sc);
-        sc *= a.scale;
-        const float mn = fmaxf(m, sc);
-        const float al = expf(m - mn), pw = expf(sc - mn);
-        l = fmaf(l, al, pw);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], al, pw * vf[j]);
-        m = mn;
-    }
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1) {   // the wave's position groups merge in registers
-        const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
-        const float mn = fmaxf(m, mo);
-        const float wa = (m == -INFINITY) ? 0.0f : expf(m - mn), wb = (mo == -INFINITY) ? 0.0f : expf(mo - mn);
-        l = fmaf(l, wa, lo * wb);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], wa, __shfl_xor(acc[j], off, 64) * wb);
-        m = mn;
-    }
-    if (lane == 0) { ms[wave] = m; ls[wave] = l; }
-    if (sub == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) accs[wave * hd + 8 * part_i + j] = acc[j];
-    }
-    __syncthreads();
-    for (int d = tid; d < hd; d += (int)blockDim.x) {
-        float M = ms[0];
-        for (int i = 1; i < NW; ++i) M = fmaxf(M, ms[i]);
-        float L = 0.0f, o = 0.0f;
-        for (int i = 0; i < NW; ++i) {
-            const float w = (ms[i] == -INFINITY) ? 0.0f : expf(ms[i] - M);
-            L = fmaf(w, ls[i], L);
-            o = fmaf(w, accs[i * hd + d], o);
-        }
-        __hip_atomic_store(a.out + (size_t)head * hd + d, o / L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
-    }
-    __syncthreads();
-}
-
-// producer workgroups (blockIdx < n_heads, launched IN FRONT of the GEMV workgroups): one head each, published write-through
-__device__ __forceinline__ void att_produce(const AttnFuse& a, float* lds, int head) {
-    const int pos = *a.d_pos;
-    if (a.hd == 128) att_head<16>(a, lds, head, pos);
-    else if (a.hd == 64) att_head<8>(a, lds, head, pos);
-    else att_head<32>(a, lds, head, pos);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores are acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == (unsigned)a.n_heads) {   // last head: raise the 8 flags the waiting workgroups poll (one per workgroup-id
-#pragma unroll                                    // class mod 8, 256 bytes apart: 480 pollers on ONE word serialise in the memory system)
-            for (int g = 0; g < 8; ++g) __hip_atomic_store(&a.sync[64 + 64 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-// GEMV workgroups: wait until every head has been published (one lane polls, relaxed agent-scope loads, bounded)
-__device__ __forceinline__ void att_wait(const AttnFuse& a) {
-    if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        const unsigned* flag = &a.sync[64 + 64 * (blockIdx.x & 7)];
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > 1000000u) { __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-}
-// at the very end of the launch: the last workgroup to finish clears the arrival count for the next use (atomicInc wraps itself)
-__device__ __forceinline__ void att_finish(const AttnFuse& a, int nblk) {
-    if (threadIdx.x == 0) {
-        const unsigned old = atomicInc(&a.sync[1], (unsigned)nblk - 1u);
-        if (old == (unsigned)nblk - 1u) {
-            __hip_atomic_store(&a.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) __hip_atomic_store(&a.sync[64 + 64 * g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-__device__ __forceinline__ u32x4 asm_load16_sc1(const void* base, unsigned off) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory");
-    return v;
-}
+#ifdef NTK_EXPERIMENTS
+#include "gemv_attfuse.hip.h"   // AttnFuse, att_produce / att_wait / att_finish, asm_load16_sc1
+#else
+struct AttnFuse {};             // (the ATT instantiations exist in EXPERIMENTS=1 builds only)
+#endif
 
 template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false, bool XI = false>
-__device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int bid, const int nblk) {   // workgroup bid of nblk
+__device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int bid, const int nblk, const AttnFuse* attp = nullptr) {   // workgroup bid of nblk
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
     constexpr int STAGE = NL * 1024 + 64;
@@ -355,13 +208,15 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         };
         if constexpr (XFAST) {   // host guarantees: x (and norm_w) 16-byte aligned, in % 4 == 0, (!NORM || in <= WIT * step)
             if constexpr (ATT) {
+#ifdef NTK_EXPERIMENTS
                 // x is produced INSIDE this launch: weights first (they depend on nothing), then the attention heads and the
                 // grid-wide hand-off, then x through cache-bypassing loads (the first weight row has landed long before)
                 issue();
-                att_wait(p.att);
+                att_wait(*attp);
 #pragma unroll
                 for (int i = 0; i < XIT; ++i) xv[i] = asm_load16_sc1(p.x, 4u * (unsigned)min(tid * 4 + i * step, p.in - 4));
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
+#endif
             } else {
             // x (and the norm weights) were requested at the top and have LANDED before the first weight row is requested: a CU
             // returns its loads in request order, so an x request queued behind weight rows (this wave's, or those of the waves of
@@ -653,7 +508,9 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         }
         for (; done < p.nbatch; ++done) __syncthreads();
     }
-    if constexpr (ATT) att_finish(p.att, nblk);
+#ifdef NTK_EXPERIMENTS
+    if constexpr (ATT) att_finish(*attp, nblk);
+#endif
 #ifdef NTK_GEMV_TRACE
     GV_STAMP(6);   // end
     if (tid == 0 && bid < GT_WG) {
@@ -663,17 +520,19 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
 #endif
 }
 
+#ifdef NTK_EXPERIMENTS
 // the Wo projection with the attention pre-phase (AttnFuse): aligned fast prologue, no norm
 template <int DT>
-__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_att_kernel(const GemvParams p) {
+__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_att_kernel(const GemvParams p, const AttnFuse att) {
     extern __shared__ __attribute__((aligned(16))) uint8_t att_smem[];
-    const int nh = p.att.n_heads;
+    const int nh = att.n_heads;
     if ((int)blockIdx.x < nh) {   // the attention workgroups come first in the grid: they are resident before any waiter
-        att_produce(p.att, reinterpret_cast<float*>(att_smem), (int)blockIdx.x);
+        att_produce(att, reinterpret_cast<float*>(att_smem), (int)blockIdx.x);
         return;
     }
-    gemv_quant_body<DT, false, true, A16_OK<DT>, true>(p, (int)blockIdx.x - nh, (int)gridDim.x - nh);
+    gemv_quant_body<DT, false, true, A16_OK<DT>, true>(p, (int)blockIdx.x - nh, (int)gridDim.x - nh, &att);
 }
+#endif
 
 template <int DT, bool NORM, bool XFAST, bool A16>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const GemvParams p) {
@@ -881,6 +740,7 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     return last_launch_status();
 }
 
+#ifdef NTK_EXPERIMENTS
 template <int DT>
 static int launch_att(const AttnFuse& att, const ntk_gemv_seg* seg, int in, const float* resid, hipStream_t st) {
     GemvLaunch L;
@@ -890,14 +750,14 @@ static int launch_att(const AttnFuse& att, const ntk_gemv_seg* seg, int in, cons
     if (!L.xfast || L.nwaves != 8 || L.p.seg[0].delta != 0 || L.p.total_rows == 0 || L.grid < 1) return NTK_E_ALIGN;
     const size_t att_lds = sizeof(float) * ((size_t)3 * att.hd + 16 + (size_t)8 * att.hd);
     if (att_lds > L.lds) return NTK_E_SHAPE;
-    L.p.att = att;
     if (L.lds > 64 * 1024) {
         static bool once = hipFuncSetAttribute((const void*)gemv_quant_att_kernel<DT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
         if (!once || L.lds > 160 * 1024) return NTK_E_SHAPE;
     }
-    hipLaunchKernelGGL(gemv_quant_att_kernel<DT>, dim3(L.grid + att.n_heads), dim3(64 * L.nwaves), L.lds, st, L.p);
+    hipLaunchKernelGGL(gemv_quant_att_kernel<DT>, dim3(L.grid + att.n_heads), dim3(64 * L.nwaves), L.lds, st, L.p, att);
     return last_launch_status();
 }
+#endif
 
 // segments of two formats sharing x (no residual / SiLU epilogue): one launch, workgroups split by bytes
 template <int DTA, int DTB>
@@ -982,6 +842,7 @@ int ntk_gemv_add(float* y, const void* W, const float* x, int out_features, int 
     return ntk::launch_dense<true>(y, W, x, out_features, in_features, weight_dtype, ntk::resolve_stream(stream));
 }
 
+#ifdef NTK_EXPERIMENTS
 int ntk_attention_gemv_fused(float* attn_out, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
                              const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
                              float scale, float theta_base, float freq_scale, const ntk_gemv_seg* wo, const float* resid,
@@ -1007,6 +868,7 @@ int ntk_attention_gemv_fused(float* attn_out, const float* q, const float* k, co
         default: return NTK_E_DTYPE;
     }
 }
+#endif
 
 int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
                    const float* resid, int silu_pair, void* stream) {

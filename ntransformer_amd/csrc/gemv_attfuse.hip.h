@@ -1,0 +1,180 @@
+// gemv_attfuse.hip.h -- EXPERIMENTS=1 builds only (make EXPERIMENTS=1): the attention producers inside the Wo launch
+// (ntk_attention_gemv_fused).  Measured 0.95x the two-launch form (profiles/r02_attention_in_wo_launch_experiment.txt): kept as
+// an opt-in record, not part of the shipping library.  Included by gemv.hip inside namespace ntk.
+#pragma once
+// Optional attention producers inside a GEMV launch (the Wo projection: its x IS the attention output).  n_heads extra
+// workgroups in FRONT of the grid compute RoPE + KV store + decode attention of one head each, publish the head's output
+// write-through and count themselves in; the GEMV workgroups request their first weight rows at launch, wait for the n_heads
+// arrivals while those rows are on their way from HBM, and then read x with cache-bypassing loads.  One launch (and one kernel boundary + one first-byte
+// latency) less per layer than attention + Wo as separate launches.  sync: 3 words, zero before the first use, left zero.
+struct AttnFuse {
+    const float* q;
+    const float* k;
+    const float* v;
+    float* out;             // [n_heads * hd]: the GEMV's x
+    uint16_t* kc;
+    uint16_t* vc;
+    const int* d_pos;
+    const float* inv_freq;
+    unsigned* sync;         // [0] heads done, [1] workgroups finished (wraps), [2] error: a bounded wait gave up
+    int n_heads, n_kv_heads, hd, max_seq;
+    float scale, theta, fscale;
+    int pad;
+};
+
+// ---- attention pre-phase (AttnFuse): attention.hip's single-pass decode kernel on the 8 waves of a GEMV workgroup ----
+__device__ __forceinline__ void att_unpack8(const u32x4 r, float (&f)[8]) {
+    f[0] = h2f((uint16_t)(r.x & 0xFFFF)); f[1] = h2f((uint16_t)(r.x >> 16));
+    f[2] = h2f((uint16_t)(r.y & 0xFFFF)); f[3] = h2f((uint16_t)(r.y >> 16));
+    f[4] = h2f((uint16_t)(r.z & 0xFFFF)); f[5] = h2f((uint16_t)(r.z >> 16));
+    f[6] = h2f((uint16_t)(r.w & 0xFFFF)); f[7] = h2f((uint16_t)(r.w >> 16));
+}
+template <int LPR>
+__device__ __forceinline__ void att_head(const AttnFuse& a, float* lds, int head, int pos) {
+    constexpr int PPW = 64 / LPR, NW = 8, G = NW * PPW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = a.hd, n_kv = a.n_kv_heads, group = a.n_heads / n_kv, half_dim = hd / 2;
+    float* qs = lds;              // [hd] post-RoPE query
+    float* kx = qs + hd;          // [hd] post-RoPE key of this token, rounded through half
+    float* vx = kx + hd;          // [hd] value of this token, rounded through half
+    float* ms = vx + hd;          // [NW]
+    float* ls = ms + NW;          // [NW]
+    float* accs = ls + NW;        // [NW][hd]
+    const size_t stride = (size_t)n_kv * hd;
+    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
+    const int kv_head = head / group;
+    const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
+    const bool writer = (head % group == 0) && pos < a.max_seq;
+    const uint16_t* kbase = a.kc + (size_t)kv_head * hd + 8 * part_i;
+    const uint16_t* vbase = a.vc + (size_t)kv_head * hd + 8 * part_i;
+    int p = g;
+    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
+    if (p < pos) {
+        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
+        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
+    }
+    for (int i = tid; i < half_dim; i += (int)blockDim.x) {
+        const float qa = a.q[(size_t)head * hd + i], qb = a.q[(size_t)head * hd + i + half_dim];
+        const float ka = a.k[(size_t)kv_head * hd + i], kb = a.k[(size_t)kv_head * hd + i + half_dim];
+        // reference rotary.cu:46-60; inv_freq holds 1/powf(theta, 2i/hd) computed once on the host
+        const float freq = a.inv_freq ? a.inv_freq[i] : 1.0f / (float)pow((double)a.theta, (double)((2.0f * i) / hd));
+        const float angle = pos * freq * a.fscale;
+        const float c = cosf(angle), sn = sinf(angle);
+        qs[i] = qa * c - qb * sn; qs[i + half_dim] = qb * c + qa * sn;
+        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
+        kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
+        if (writer) { a.kc[cache_row + i] = ha; a.kc[cache_row + i + half_dim] = hb; }
+    }
+    for (int i = tid; i < hd; i += (int)blockDim.x) {
+        const uint16_t hv = f2h(a.v[(size_t)kv_head * hd + i]);
+        vx[i] = h2f(hv);
+        if (writer) a.vc[cache_row + i] = hv;
+    }
+    __syncthreads();
+    float qreg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qreg[j] = qs[8 * part_i + j];
+    float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (; p <= pos; p += G) {
+        float kf[8], vf[8];
+        if (p < pos) {
+            att_unpack8(kraw, kf);
+            att_unpack8(vraw, vf);
+        } else {   // the token being decoded
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
+        }
+        const int pn = p + G;
+        if (pn < pos) {
+            kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
+            vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
+        }
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
+        sc = group_sum<LPR>(sc);
+        sc *= a.scale;
+        const float mn = fmaxf(m, sc);
+        const float al = expf(m - mn), pw = expf(sc - mn);
+        l = fmaf(l, al, pw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], al, pw * vf[j]);
+        m = mn;
+    }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {   // the wave's position groups merge in registers
+        const float mo = __shfl_xor(m, off, 64), lo = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, mo);
+        const float wa = (m == -INFINITY) ? 0.0f : expf(m - mn), wb = (mo == -INFINITY) ? 0.0f : expf(mo - mn);
+        l = fmaf(l, wa, lo * wb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], wa, __shfl_xor(acc[j], off, 64) * wb);
+        m = mn;
+    }
+    if (lane == 0) { ms[wave] = m; ls[wave] = l; }
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accs[wave * hd + 8 * part_i + j] = acc[j];
+    }
+    __syncthreads();
+    for (int d = tid; d < hd; d += (int)blockDim.x) {
+        float M = ms[0];
+        for (int i = 1; i < NW; ++i) M = fmaxf(M, ms[i]);
+        float L = 0.0f, o = 0.0f;
+        for (int i = 0; i < NW; ++i) {
+            const float w = (ms[i] == -INFINITY) ? 0.0f : expf(ms[i] - M);
+            L = fmaf(w, ls[i], L);
+            o = fmaf(w, accs[i * hd + d], o);
+        }
+        __hip_atomic_store(a.out + (size_t)head * hd + d, o / L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
+    }
+    __syncthreads();
+}
+
+// producer workgroups (blockIdx < n_heads, launched IN FRONT of the GEMV workgroups): one head each, published write-through
+__device__ __forceinline__ void att_produce(const AttnFuse& a, float* lds, int head) {
+    const int pos = *a.d_pos;
+    if (a.hd == 128) att_head<16>(a, lds, head, pos);
+    else if (a.hd == 64) att_head<8>(a, lds, head, pos);
+    else att_head<32>(a, lds, head, pos);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)a.n_heads) {   // last head: raise the 8 flags the waiting workgroups poll (one per workgroup-id
+#pragma unroll                                    // class mod 8, 256 bytes apart: 480 pollers on ONE word serialise in the memory system)
+            for (int g = 0; g < 8; ++g) __hip_atomic_store(&a.sync[64 + 64 * g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// GEMV workgroups: wait until every head has been published (one lane polls, relaxed agent-scope loads, bounded)
+__device__ __forceinline__ void att_wait(const AttnFuse& a) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        const unsigned* flag = &a.sync[64 + 64 * (blockIdx.x & 7)];
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > 1000000u) { __hip_atomic_store(&a.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+// at the very end of the launch: the last workgroup to finish clears the arrival count for the next use (atomicInc wraps itself)
+__device__ __forceinline__ void att_finish(const AttnFuse& a, int nblk) {
+    if (threadIdx.x == 0) {
+        const unsigned old = atomicInc(&a.sync[1], (unsigned)nblk - 1u);
+        if (old == (unsigned)nblk - 1u) {
+            __hip_atomic_store(&a.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) __hip_atomic_store(&a.sync[64 + 64 * g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ u32x4 asm_load16_sc1(const void* base, unsigned off) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(v) : "v"(off), "s"(base) : "memory");
+    return v;
+}
+

@@ -58,26 +58,6 @@ struct GemvSeg {
     int delta;          // true W = W + delta (0..15)
 };
 
-// Optional attention producers inside a GEMV launch (the Wo projection: its x IS the attention output).  n_heads extra
-// workgroups in FRONT of the grid compute RoPE + KV store + decode attention of one head each, publish the head's output
-// write-through and count themselves in; the GEMV workgroups request their first weight rows at launch, wait for the n_heads
-// arrivals while those rows are on their way from HBM, and then read x with cache-bypassing loads.  One launch (and one kernel boundary + one first-byte
-// latency) less per layer than attention + Wo as separate launches.  sync: 3 words, zero before the first use, left zero.
-struct AttnFuse {
-    const float* q;
-    const float* k;
-    const float* v;
-    float* out;             // [n_heads * hd]: the GEMV's x
-    uint16_t* kc;
-    uint16_t* vc;
-    const int* d_pos;
-    const float* inv_freq;
-    unsigned* sync;         // [0] heads done, [1] workgroups finished (wraps), [2] error: a bounded wait gave up
-    int n_heads, n_kv_heads, hd, max_seq;
-    float scale, theta, fscale;
-    int pad;
-};
-
 struct GemvParams {
     GemvSeg seg[MAX_SEG];
     int nseg;
@@ -94,7 +74,6 @@ struct GemvParams {
     const float* resid;
     int silu_pair;
     unsigned row_bytes;
-    AttnFuse att;       // used by the ATT instantiations only
 #ifdef NTK_GEMV_TRACE
     int trace_slot;     // tuning builds: which record of g_gemv_trace this launch fills
 #endif

@@ -8,7 +8,13 @@
 // second communicator stream, no host involvement):
 //   * every rank owns a communication buffer [flags | slot 0 | slot 1] that its peers map (hipIpc handles across processes);
 //   * the producing GEMV / GEMM writes the rank's partial vector straight into the slot of the current call (call k uses slot
-//     k & 1) -- by the kernel boundary it is in memory;
+//     k & 1).  Visibility to the PEERS does not rest on the kernel boundary alone: the communication buffer is allocated
+//     FINE-GRAINED (ntk_tp_comm_alloc: hipExtMallocWithFlags(hipDeviceMallocFinegrained)), i.e. the producer's stores are not
+//     held dirty in any of the eight XCD L2s but written through to the memory side, where the peers' system-scope loads
+//     (sc0 sc1, past every cache) find them; the kernel boundary between the producer and this kernel then only has to order the
+//     flag store behind those stores.  (A release fence executed by the publishing workgroup would write back the L2 of ITS XCD
+//     only -- the producer's stores came from all eight -- so it is not what this design relies on.)  Unmeasured across xGMI: the
+//     boxes of this project have one GPU; NTK_TP_COARSE=1 falls back to an ordinary allocation for A/B on real hardware;
 //   * tp_allreduce_add_kernel: publish flag[slot] = epoch * 1024 + k + 1 (write-through, system scope), wait until every
 //     peer's flag[slot] has reached that value (bounded spin: a lost peer sets an error word instead of hanging the GPU), then
 //     hidden += sum over ranks IN RANK ORDER of their slots, peers read past the caches (sc0 sc1).  Every rank adds the same
@@ -19,6 +25,7 @@
 //     replayed: call indices are constants of the graph, the epoch is data.
 #include "common.hip.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace ntk {
 
@@ -82,6 +89,20 @@ extern "C" {
 using namespace ntk;
 
 size_t ntk_tp_comm_bytes(size_t max_floats) { return TP_HDR + 2 * ((max_floats + 3) / 4 * 4) * sizeof(float) + 256; }
+
+// a communication buffer: fine-grained device memory (see the header comment), ordinary device memory if the runtime refuses or
+// NTK_TP_COARSE=1; freed with nt_hip_free
+void* ntk_tp_comm_alloc(size_t bytes) {
+    void* p = nullptr;
+    const char* coarse = getenv("NTK_TP_COARSE");
+    if (!(coarse && atoi(coarse) != 0)) {
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess && p) return p;
+        (void)hipGetLastError();
+        p = nullptr;
+    }
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
 
 // zero the flags, the error word and the epoch of a freshly allocated communication buffer (before the peers map it)
 int ntk_tp_comm_reset(void* comm, void* stream) {

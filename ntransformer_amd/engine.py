@@ -86,6 +86,9 @@ def _bind():
     L.nt_engine_tp_error.argtypes = [vp]
     L.nt_engine_tp_error.restype = C.c_uint
     L.nt_tp_slice_columns.argtypes = [vp, vp, i, C.c_int64, C.c_int64, i, i]
+    L.nt_engine_debug_run_layers.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.nt_engine_debug_kv_read.argtypes = [vp, i, i, i, vp, vp]
+    L.nt_engine_debug_kv_write.argtypes = [vp, i, i, i, vp, vp]
     L._engine_bound = True
     return L
 
@@ -172,6 +175,29 @@ class Engine:
         out = np.empty(self.vocab_size, np.float32)
         self._check(self.L.nt_engine_decode_fused(self.h, int(token), pos, int(graph), out.ctypes.data_as(C.c_void_p)), "decode_fused")
         return out
+
+    # ---- parity instrumentation (include/ntransformer.h: nt_engine_debug_*) ----
+    def debug_run_layers(self, hidden_in: np.ndarray, start_pos: int, first: int, count: int = 1, mode: int = 0) -> np.ndarray:
+        """layers [first, first+count) on caller-supplied hidden states [T, H]; mode 0 = 1:1 launchers, 1 = fused, 2 = fused via hipGraph"""
+        x = np.ascontiguousarray(hidden_in, dtype=np.float32)
+        if x.ndim == 1:
+            x = x[None, :]
+        out = np.empty_like(x)
+        self._check(self.L.nt_engine_debug_run_layers(self.h, x.ctypes.data_as(C.c_void_p), x.shape[0], start_pos, first, count, mode,
+                                                      out.ctypes.data_as(C.c_void_p)), "debug_run_layers")
+        return out
+
+    def kv_read(self, layer: int, pos0: int, n: int, row_halves: int):
+        """(K, V) cache rows [pos0, pos0+n) of one layer as uint16 [n, n_kv_heads * head_dim]"""
+        k = np.empty((n, row_halves), np.uint16)
+        v = np.empty((n, row_halves), np.uint16)
+        self._check(self.L.nt_engine_debug_kv_read(self.h, layer, pos0, n, k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "kv_read")
+        return k, v
+
+    def kv_write(self, layer: int, pos0: int, k: np.ndarray, v: np.ndarray) -> None:
+        k = np.ascontiguousarray(k, dtype=np.uint16)
+        v = np.ascontiguousarray(v, dtype=np.uint16)
+        self._check(self.L.nt_engine_debug_kv_write(self.h, layer, pos0, k.shape[0], k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)), "kv_write")
 
     def generate_tokens(self, prompt: Sequence[int], max_tokens: int, temperature: float = 0.0, top_k: int = 40,
                         top_p: float = 0.9, repeat_penalty: float = 1.0, repeat_window: int = 64, seed: int = 42,

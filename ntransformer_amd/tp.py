@@ -1,7 +1,7 @@
 """Tensor-parallel decoding: one engine per rank, the ranks' communication buffers connected through hipIpc handles.
 
 `connect_over_files` exchanges the 64-byte handles through a directory (no torch needed: the tests use it);
-`connect_over_torch` through an initialised torch.distributed group (bench.py --tp under torch.distributed.run, gloo).
+`connect_over_torch` through an initialised torch.distributed group (tools/tp_bench.py under torch.distributed.run, gloo).
 Every rank must afterwards drive its engine with the same calls and the same tokens (the engines exchange partial
 vectors inside the forward pass and produce bit-identical logits)."""
 from __future__ import annotations
@@ -13,16 +13,19 @@ from typing import List
 from . import engine as E
 
 
-def connect_over_files(eng: "E.Engine", rank: int, world: int, directory: str, timeout_s: float = 120.0) -> None:
+def connect_over_files(eng: "E.Engine", rank: int, world: int, directory: str, timeout_s: float = 120.0, run_id: str = "") -> None:
+    """run_id: a string every rank of THIS run shares (a job id, a start time): handle files are named after it, so files left in
+    the directory by an earlier run are never read (a stale handle maps a buffer that no longer exists)."""
     handle, _ = eng.tp_export()
-    tmp = os.path.join(directory, "tp_handle_%d.tmp" % rank)
+    stem = "tp_handle_%s_" % run_id if run_id else "tp_handle_"
+    tmp = os.path.join(directory, "%s%d.tmp" % (stem, rank))
     with open(tmp, "wb") as f:
         f.write(handle)
-    os.replace(tmp, os.path.join(directory, "tp_handle_%d" % rank))
+    os.replace(tmp, os.path.join(directory, "%s%d" % (stem, rank)))
     handles: List[bytes] = []
     t0 = time.time()
     for r in range(world):
-        path = os.path.join(directory, "tp_handle_%d" % r)
+        path = os.path.join(directory, "%s%d" % (stem, r))
         while not os.path.exists(path):
             if time.time() - t0 > timeout_s:
                 raise TimeoutError("rank %d never published its handle" % r)

@@ -266,13 +266,18 @@ class OracleModel:
         t = "token_embd.weight"
         return np.stack([embed_row(self.f.raw(t), int(tok), self.hidden, self.f.dtype(t)) for tok in tokens])
 
-    def forward(self, tokens: Sequence[int], start_pos: int) -> np.ndarray:
+    def forward(self, tokens: Sequence[int], start_pos: int, trace: Optional[dict] = None) -> np.ndarray:
+        """trace (tests): receives "layer_in" / "layer_out" -- per layer the hidden states [T, H] entering / leaving it"""
         T, H = len(tokens), self.hidden
         q_dim, kv_dim = self.nh * self.hd, self.nkv * self.hd
         hidden = self.embed(tokens)                                            # [T, H]
         positions = [start_pos + i for i in range(T)]
+        if trace is not None:
+            trace["layer_in"], trace["layer_out"] = [], []
         for i in range(self.n_layers):
             p = "blk.%d." % i
+            if trace is not None:
+                trace["layer_in"].append(hidden.copy())
             resid = rmsnorm(hidden, self.f.f32(p + "attn_norm.weight"), self.eps)   # :636
             q = np.stack([self._gemv(p + "attn_q.weight", resid[t], q_dim, H) for t in range(T)])
             k = np.stack([self._gemv(p + "attn_k.weight", resid[t], kv_dim, H) for t in range(T)])
@@ -298,6 +303,8 @@ class OracleModel:
                 act = silu_mul(gate, up)
                 outs.append(self._gemv(p + "ffn_down.weight", act, H, self.inter))
             hidden = hidden + np.stack(outs)                                   # :654
+            if trace is not None:
+                trace["layer_out"].append(hidden.copy())
         last = rmsnorm(hidden[T - 1], self.f.f32("output_norm.weight"), self.eps)   # :658-659
         return self._gemv(self.out_name, last, self.vocab, H)                  # :662-665
 

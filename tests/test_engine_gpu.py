@@ -191,9 +191,12 @@ def test_long_context_decode_uses_split_attention_and_matches_the_1to1_path(tmp_
 
 
 # ---------------------------------------------------------------------------------------------------
-# Parity at the BASELINE configs' real width / depth (SURVEY 8(d) "Parity procedure"; reference
+# Parity at the BASELINE configs' real width, shallow depth (SURVEY 8(d) "Parity procedure"; reference
 # src/model/transformer.cpp:604-669).  Teacher-forced: the oracle runs free greedy decode, the HIP engine is fed the
-# same tokens and every step's full logit vector is compared, max |d| <= 1e-3.  The observed errors are appended to
+# same tokens and every step's full logit vector is compared, max |d| <= 1e-3 -- attainable end to end while the model
+# is shallow enough that the half roundings of K / V (attention.cu:338) have not yet turned 1e-7 differences between two
+# correct F32 implementations into 1e-3 ones.  FULL depth (32 layers, 16 of the 70B shape) is tests/test_parity_depth.py,
+# which separates the two with layer-wise teacher forcing and a float64 arbiter.  The observed errors are appended to
 # gpurun_out/parity_observed.jsonl on the GPU box (copied to profiles/ by the round script).
 # ---------------------------------------------------------------------------------------------------
 def _log_observed(rec):
@@ -222,32 +225,7 @@ def _scratch_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
 
 
-def _oracle_self_sensitivity(m, prompt, fed, want, rel=6e-8):
-    """Conditioning of the oracle itself: the same teacher-forced run with every embedding row multiplied by
-    (1 + rel * N(0,1)), rel = one F32 ulp.  K and V are rounded to F16 on the way into the cache (reference
-    attention.cu:338), so the logits are a discontinuous function of their inputs: a 1e-7 change flips a few roundings per
-    layer (each a 4.9e-4 relative step) and the response does not shrink with the perturbation
-    (profiles/r02_oracle_fp_sensitivity_8b_q8_0.txt: 6e-8 -> 3.4e-3, 1e-6 -> 3.1e-3 at 32 layers)."""
-    orig = m.embed
-    worst = 0.0
-    for seed in (7, 8, 9):   # the response is a sum of discrete rounding flips: one draw is a noisy estimate of its size
-        rng = np.random.default_rng(seed)
-        m.embed = lambda tokens: (orig(tokens) * (1.0 + rel * rng.standard_normal((len(tokens), m.hidden)))).astype(np.float32)
-        m.k_cache[:] = 0
-        m.v_cache[:] = 0
-        try:
-            got = [m.forward(prompt, 0)]
-            pos = len(prompt)
-            for t in fed:
-                got.append(m.forward([t], pos))
-                pos += 1
-        finally:
-            m.embed = orig
-        worst = max(worst, float(np.abs(np.stack(got) - want).max()))
-    return worst
-
-
-def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, conditioned=False):
+def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
     import time
     spec = E.synth_spec(preset, mix, layers=layers)
     path = os.path.join(_scratch_dir(), "_parity_%s.gguf" % tag)
@@ -267,11 +245,7 @@ def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, con
         t_oracle = time.perf_counter() - t0
         want = np.stack(want)
         assert np.isfinite(want).all()
-        # `conditioned` (full depth only): the bar is the larger of the north-star 1e-3 and what a one-ulp input perturbation
-        # does to the ORACLE's own logits -- no F32 implementation with a different summation order can sit closer to the
-        # oracle than the oracle sits to itself
-        sens = _oracle_self_sensitivity(m, prompt, fed, want) if conditioned else None
-        bar = max(TOL, 1.5 * sens) if conditioned else TOL   # 1.5 x the largest of three perturbed runs
+        bar = TOL
         observed = {}
         # reference: the reference's exact launch sequence (per-token prompt loop, 15 launches per layer, --no-fuse);
         # launchers: batched MFMA prompt + 1:1 decode; fused / graph: batched prompt + fused decode (eager / hipGraph replay)
@@ -293,10 +267,9 @@ def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, con
             clear = (top2[:, 1] - top2[:, 0]) > 2 * TOL
             agree = bool(np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]))
             assert err.max() <= bar, (tag, mode, observed[mode], bar)
-            assert agree or conditioned, (tag, mode)
+            assert agree, (tag, mode)
         _log_observed({"test": tag, "model": preset, "mix": mix, "layers": layers, "prompt_tokens": n_prompt,
                        "decode_steps": n_decode, "tolerance": TOL, "bar_used": bar, "oracle_threads": threads,
-                       "oracle_self_sensitivity_to_1ulp_embedding_noise": sens,
                        "oracle_seconds": round(t_oracle, 2), "logit_rms": float(np.sqrt((want ** 2).mean())),
                        "max_abs_err_per_step": observed,
                        "max_abs_err": {k: max(v) for k, v in observed.items()}})
@@ -305,15 +278,6 @@ def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, con
             os.remove(path)
         except OSError:
             pass
-
-
-def test_full_depth_8b_q8_0_logits_match_oracle():
-    """BASELINE config 2 at its real size: all 32 layers of the Llama-3.1-8B shape, Q8_0, 16-token prompt + 4 teacher-forced
-    decode steps: error accumulation over the full depth.  Measured (profiles/r02_parity_observed.jsonl): the HIP
-    engine sits 2.2e-3 from the oracle at 32 layers while the oracle sits 3.4e-3 from ITSELF under a one-ulp input
-    perturbation (F16 rounding of K/V is a discontinuity); the north-star 1e-3 holds for the 2- and 8-layer models below.
-    The bar here is therefore max(1e-3, 1.5 x the oracle's own measured sensitivity: largest of three perturbed runs); both are logged."""
-    _parity_at_config("8b_q8_0_full_depth", "8b", "Q8_0", 32, 20, 4, conditioned=True)   # > 16 tokens: the BF16 prompt GEMM
 
 
 def test_8b_q4_k_m_mix_logits_match_oracle():
@@ -385,37 +349,6 @@ def test_reference_cli_runs_on_the_hip_library():
     assert re.search(r"Decode:\s+\d+ tokens", txt), txt[-2000:]
 
 
-@pytest.mark.parametrize("name,shape,mix", CASES)
-def test_persistent_token_kernel_matches_the_launch_path(name, shape, mix, tmp_path):
-    """One decode token as ONE persistent launch (csrc/decode_persistent.hip: weights prefetched by LDS-DMA across operators,
-    activations handed between workgroups through the in-launch grid barrier) against the 5-launches-per-layer path on the
-    same KV cache: same operators and per-row arithmetic, so the logits agree far inside the tolerance (only the RMSNorm and
-    attention reduction orders differ); eager and hipGraph replay; the bounded-wait error word must stay clear."""
-    path, z = golden_model(name, shape, mix, tmp_path)
-    prompt = [int(t) for t in z["prompt"]]
-    fed = [int(t) for t in z["fed"][1:]][:6] + [5, 9, 300 % 256, 17]
-    outs = {}
-    for mode in ("launches", "persistent", "persistent_graph"):
-        eng = E.Engine()
-        eng.load(path, int(z["ctx"]))
-        eng.set_option("persistent", mode != "launches")
-        if mode != "launches" and "persistent" not in eng.decode_path():
-            eng.close()
-            pytest.skip("model does not qualify for the persistent path (dense or mixed gate/up tensors)")
-        lg = [eng.forward(prompt, 0)]
-        pos = len(prompt)
-        for t in fed:
-            lg.append(eng.decode_fused(t, pos, mode == "persistent_graph"))
-            pos += 1
-        toks = eng.decode_greedy_steps(fed[-1], pos, 8)       # device argmax loop through the same kernel
-        outs[mode] = (np.stack(lg), toks)
-        eng.close()
-    for mode in ("persistent", "persistent_graph"):
-        err = np.abs(outs[mode][0] - outs["launches"][0]).max()
-        assert np.isfinite(outs[mode][0]).all() and err <= 5e-4, (name, mode, err)   # summation order differs; the logits bar is 1e-3
-    assert outs["persistent"][1] == outs["persistent_graph"][1]
-
-
 @pytest.mark.parametrize("cfg", [dict(temperature=0.7, top_k=40, top_p=0.9, repeat_penalty=1.1), dict(temperature=0.0, repeat_penalty=1.3),
                                  dict(temperature=1.5, top_k=5, top_p=1.0, repeat_penalty=1.0)])
 def test_device_sampling_gives_the_host_samplers_token_stream(cfg, tmp_path):
@@ -435,30 +368,18 @@ def test_device_sampling_gives_the_host_samplers_token_stream(cfg, tmp_path):
     assert len(set(outs[0])) > 3
 
 
-@pytest.mark.parametrize("name,shape,mix", [c for c in CASES if c[0] in ("tiny_q8_0", "tiny_q4_k_m", "small_q8_0", "small_q6_k")])
-def test_attention_inside_the_wo_launch_matches_separate_launches(name, shape, mix, tmp_path):
-    """Short contexts: RoPE + KV store + attention run as extra workgroups IN FRONT of the Wo projection's grid
-    (ntk_attention_gemv_fused: the GEMV workgroups request their first weight rows, then wait for the heads), one launch
-    less per layer.  Same arithmetic as ntk_attention_decode_fused + ntk_gemv_fused; compared on the same KV cache, eager and
-    hipGraph replay, across many positions (the sync words must return to zero after every launch)."""
-    path, z = golden_model(name, shape, mix, tmp_path)
-    prompt = [int(t) for t in z["prompt"]]
-    r = np.random.Generator(np.random.Philox(key=[20260925, 31]))
-    fed = [int(t) for t in r.integers(0, 256, 24)]
-    outs = {}
-    for mode in ("separate", "fused", "fused_graph"):
-        eng = E.Engine()
-        eng.load(path, int(z["ctx"]))
-        eng.set_option("fuse_attention", mode != "separate")
-        lg = [eng.forward(prompt, 0)]
-        pos = len(prompt)
-        for t in fed:
-            lg.append(eng.decode_fused(t, pos, mode == "fused_graph"))
-            pos += 1
-        toks = eng.decode_greedy_steps(fed[-1], pos, 16)
-        outs[mode] = (np.stack(lg), toks)
-        eng.close()
-    for mode in ("fused", "fused_graph"):
-        err = np.abs(outs[mode][0] - outs["separate"][0]).max()
-        assert np.isfinite(outs[mode][0]).all() and err <= 5e-4, (name, mode, err)   # summation order differs; the logits bar is 1e-3
-    assert outs["fused"][1] == outs["fused_graph"][1]
+def test_experiments_library_matches_the_launch_path():
+    """`make EXPERIMENTS=1` (ntransformer_amd/libntransformer_hip_exp.so, include/ntk_experiments.h): the persistent token kernel and
+    the attention-inside-the-Wo-launch form -- both slower than the shipping launch path, kept as opt-in records -- still reproduce
+    the launch path's logits and token streams.  The checks live in tests/experiments_check.py and run in a subprocess on THAT
+    library (NTK_LIB_PATH); the shipping library does not contain these paths (tests/test_host_logic.py asserts that)."""
+    import subprocess
+    import sys
+    exp = os.path.join(os.path.dirname(E.__file__), "libntransformer_hip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("libntransformer_hip_exp.so not built (make -C ntransformer_amd/csrc experiments)")
+    env = dict(os.environ, NTK_LIB_PATH=exp)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "experiments_check.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "experiments ok" in r.stdout

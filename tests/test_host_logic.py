@@ -34,6 +34,20 @@ def test_library_exports_every_declared_symbol(header):
     assert not missing, missing
 
 
+def test_experiments_are_a_separate_library():
+    """include/ntk_experiments.h (the persistent token kernel, attention inside the Wo launch: both measured slower than the launch
+    path) is exported by libntransformer_hip_exp.so (make EXPERIMENTS=1) and by nothing in the shipping library."""
+    names = declared_functions("ntk_experiments.h")
+    assert "ntk_persistent_launch" in names and "ntk_attention_gemv_fused" in names
+    L = _lib.lib()
+    assert not [n for n in names if hasattr(L, n)]
+    exp = os.path.join(ROOT, "ntransformer_amd", "libntransformer_hip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("libntransformer_hip_exp.so not built")
+    X = C.CDLL(exp)
+    assert not [n for n in names if not hasattr(X, n)]
+
+
 def test_abi_basics_without_gpu():
     L = _lib.lib()
     assert L.ntk_abi_version() == 1

@@ -1,0 +1,278 @@
+"""Parity at the BASELINE configs' full depth, made falsifiable (reference src/model/transformer.cpp:604-669 over
+src/cuda/*.cu; north star: logits within 1e-3 on identical weights and prompts).
+
+Why this file exists.  K and V are rounded to IEEE half on their way into the cache (reference attention.cu:338) -- the one
+discontinuity on the path.  Two correct F32 implementations differ by ~1e-7 before that rounding, so ~0.2-0.3 % of the cache
+elements round to the neighbouring half ("flips", each a 5e-4 relative step), and through 32 layers those flips alone move the
+logits by 2-3e-3 (measured on the CPU between the F32 restatement and the float64 arbiter: 2.4e-3 at 32 layers, 4.3e-4 at 4,
+while the restatement's accumulated F32 error proper is 4.8e-6 -- profiles/r03_oracle_vs_arbiter_cpu.txt).  An end-to-end
+comparison of two F32 implementations at depth therefore measures flip noise, not correctness.  Three checks that do measure
+correctness, each with a bar fixed BEFORE looking at the engine's error:
+
+ (a) LAYER-WISE TEACHER FORCING (nt_engine_debug_run_layers): every layer of the HIP engine is fed the ORACLE's input to that layer
+     and the oracle's cache rows of the earlier positions, in every launch mode.  No amplification through depth.  Compared with
+       - the float64 arbiter run on the same input and FORCED to the engine's own half roundings of this layer's K / V rows:
+         what is left is the engine's F32 error in one layer.  Bar 1e-5 x RMS of the layer output (F32 eps 6e-8 x sqrt(4096..28672
+         terms) x a handful of operators; the F32 restatement sits at 5-8e-7 against the same arbiter).
+       - the oracle's own output of the layer: bar 1e-4 x RMS (it contains the flips of the current tokens' rows inside this one
+         layer: 1.6-2.7e-5 between restatement and arbiter on the CPU; the judge's 5e-5 is logged as `within_5e-5`).
+     The cache rows the layer writes are checked against the arbiter's exact values: |half - exact| <= half an ulp + 1e-5 x row RMS
+     (restatement: 1.3e-6).
+ (b) FLOAT64 ARBITER, end to end at full depth:
+       - forced: the arbiter continues with the engine's rounding decisions; |HIP - f64| <= 1e-4 at every step (a tenth of the
+         north-star tolerance: the decisions are the engine's, so no discontinuity is left; restatement: 4.8e-6);
+       - free:   |HIP - f64| <= 1.25 x the largest |F32 restatement - f64| over three equally valid F32 runs (the restatement, and
+         the restatement on embeddings perturbed by one ulp, twice): which roundings flip is a random draw, so the distance of a
+         correct F32 implementation from the free arbiter is a distribution; the engine must not sit outside it.
+ (c) the plain end-to-end number |HIP - oracle| is logged beside them and held to a PINNED sanity bar (5e-3: twice the flip noise
+     measured on the CPU), with the arg-max agreeing wherever the oracle's top-2 gap exceeds twice that bar.
+
+Everything observed goes to gpurun_out/parity_depth.jsonl (-> profiles/r03_parity_depth.jsonl)."""
+import hashlib
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from ntransformer_amd import engine as E
+from oracle import arbiter as A
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LAYER_BAR_ARBITER = 1e-5      # (a) engine vs arbiter forced to the engine's roundings, relative to the layer output's RMS
+LAYER_BAR_ORACLE = 1e-4       # (a) engine vs oracle layer output (contains this layer's own flips)
+KV_BAR = 1e-5                 # (a)/(b) |stored half - exact| - half an ulp, relative to the row's RMS
+FORCED_BAR = 1e-4             # (b) |HIP - arbiter forced to HIP's cache|, absolute on logits
+FREE_FACTOR = 1.25            # (b) |HIP - free arbiter| <= factor x |oracle - free arbiter|
+E2E_SANITY_BAR = 5e-3         # (c) pinned: 2 x the flip noise between restatement and arbiter at 32 layers
+
+
+def _log(rec):
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_depth.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+
+
+def _scratch_dir():
+    return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+
+
+class _ArbiterLayers:
+    """arbiter output of one layer on a given input, forced to a given set of half roundings of this layer's rows: launch modes that
+    write identical rows share one run"""
+
+    def __init__(self, om):
+        self.om, self.memo = om, {}
+
+    def run(self, layer, hidden_in, start_pos, past_k, past_v, rows_k, rows_v):
+        key = (layer, start_pos, hashlib.sha1(rows_k.tobytes() + rows_v.tobytes()).hexdigest())
+        if key not in self.memo:
+            a = A.ArbiterModel.__new__(A.ArbiterModel)
+            a.om, a.kv_report = self.om, []
+            a.k_cache, a.v_cache = {layer: past_k}, {layer: past_v}   # only this layer's cache is touched
+            out = a.layer(layer, hidden_in.astype(np.float64), start_pos, (rows_k, rows_v))
+            self.memo[key] = (out, max(r["max_excess_over_row_rms"] for r in a.kv_report), sum(r["mismatches"] for r in a.kv_report))
+        return self.memo[key]
+
+
+def _teacher_stream(m, prompt, fed, perturb_seed=None, rel=6e-8):
+    """the oracle's logits on a fixed token stream; perturb_seed: every embedding row multiplied by (1 + rel N(0,1)), rel = one F32
+    ulp -- a second, equally valid F32 implementation as far as anything downstream of the first rounding can tell"""
+    orig = m.embed
+    if perturb_seed is not None:
+        rng = np.random.default_rng(perturb_seed)
+        m.embed = lambda tokens: (orig(tokens) * (1.0 + rel * rng.standard_normal((len(tokens), m.hidden)))).astype(np.float32)
+    keep = (m.k_cache.copy(), m.v_cache.copy())
+    m.k_cache[:] = 0
+    m.v_cache[:] = 0
+    try:
+        out = [m.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in fed:
+            out.append(m.forward([t], pos))
+            pos += 1
+    finally:
+        m.embed = orig
+        m.k_cache[:], m.v_cache[:] = keep
+    return np.stack(out)
+
+
+def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
+    spec = E.synth_spec(preset, mix, layers=layers)
+    path = os.path.join(_scratch_dir(), "_depth_%s.gguf" % tag)
+    E.synth_write_gguf(path, spec)
+    rec = {"test": tag, "model": preset, "mix": mix, "layers": layers, "prompt_tokens": n_prompt, "decode_steps": n_decode,
+           "bars": {"layer_vs_arbiter_rel": LAYER_BAR_ARBITER, "layer_vs_oracle_rel": LAYER_BAR_ORACLE, "kv_rel": KV_BAR,
+                    "forced_abs": FORCED_BAR, "free_factor": FREE_FACTOR, "e2e_sanity_abs": E2E_SANITY_BAR}}
+    try:
+        m = O.OracleModel(path, ctx)
+        per = m.nkv * m.hd
+        r = np.random.Generator(np.random.Philox(key=[20260925, 1234]))
+        prompt = [spec.bos] + [int(t) for t in r.integers(0, spec.vocab, n_prompt - 1)]
+        # ---- the oracle: free greedy run, every layer's input / output recorded ------------------------------------------------
+        t0 = time.perf_counter()
+        steps, want, fed = [], [], []
+        tr = {}
+        want.append(m.forward(prompt, 0, tr))
+        steps.append((list(prompt), 0, tr))
+        pos = len(prompt)
+        for _ in range(n_decode):
+            fed.append(m.argmax(want[-1]))
+            tr = {}
+            want.append(m.forward([fed[-1]], pos, tr))
+            steps.append(([fed[-1]], pos, tr))
+            pos += 1
+        want = np.stack(want)
+        rec["oracle_seconds"] = round(time.perf_counter() - t0, 2)
+        rec["logit_rms"] = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+        assert np.isfinite(want).all()
+
+        # ---- (a) layer-wise teacher forcing -----------------------------------------------------------------------------------
+        t0 = time.perf_counter()
+        arb_layers = _ArbiterLayers(m)
+        worst = {"vs_arbiter": 0.0, "vs_oracle": 0.0, "kv": 0.0}
+        per_mode = {}
+        flips_layer = 0
+        eng = E.Engine()
+        eng.load(path, ctx)
+        for toks, start, tr in steps:
+            T = len(toks)
+            lo, hi = start * per, (start + T) * per
+            # (mode of debug_run_layers, batched_prefill): prompt = the reference's per-token loop and the batched GEMM; decode = the
+            # reference's 15-launch sequence, the fused launches, the fused launches replayed from a hipGraph
+            modes = [("reference", 0, 0), ("launchers", 0, 1)] if T > 1 else [("launchers", 0, 1), ("fused", 1, 1), ("graph", 2, 1)]
+            for name, dbg_mode, batched in modes:
+                eng.set_option("batched_prefill", batched)
+                for l in range(layers):
+                    h_in, h_ref = tr["layer_in"][l], tr["layer_out"][l]
+                    rms = float(np.sqrt((h_ref.astype(np.float64) ** 2).mean()))
+                    got = eng.debug_run_layers(h_in, start, l, 1, dbg_mode)
+                    assert np.isfinite(got).all(), (tag, name, l)
+                    rk, rv = eng.kv_read(l, start, T, per)
+                    past_k, past_v = m.k_cache[l].copy(), m.v_cache[l].copy()     # oracle rows (earlier positions are what matter)
+                    arb_out, exkv, nflip = arb_layers.run(l, h_in, start, past_k, past_v, rk.reshape(-1), rv.reshape(-1))
+                    e_arb = float(np.abs(got - arb_out).max()) / rms
+                    e_orc = float(np.abs(got - h_ref).max()) / rms
+                    worst["vs_arbiter"] = max(worst["vs_arbiter"], e_arb)
+                    worst["vs_oracle"] = max(worst["vs_oracle"], e_orc)
+                    worst["kv"] = max(worst["kv"], exkv)
+                    pm = per_mode.setdefault(name, {"vs_arbiter": 0.0, "vs_oracle": 0.0})
+                    pm["vs_arbiter"] = max(pm["vs_arbiter"], e_arb)
+                    pm["vs_oracle"] = max(pm["vs_oracle"], e_orc)
+                    flips_layer += int((rk.reshape(-1) != m.k_cache[l][lo:hi]).sum() + (rv.reshape(-1) != m.v_cache[l][lo:hi]).sum())
+                    assert e_arb <= LAYER_BAR_ARBITER, (tag, name, "layer", l, "pos", start, e_arb)
+                    assert e_orc <= LAYER_BAR_ORACLE, (tag, name, "layer", l, "pos", start, e_orc)
+                    assert exkv <= KV_BAR, (tag, name, "layer", l, "pos", start, exkv)
+                    # teacher forcing of the cache: the next step's layers see the ORACLE's rows at these positions
+                    eng.kv_write(l, start, m.k_cache[l][lo:hi].reshape(T, per), m.v_cache[l][lo:hi].reshape(T, per))
+        eng.close()
+        rec["a_layerwise"] = {"max_rel_err_vs_forced_arbiter": worst["vs_arbiter"], "max_rel_err_vs_oracle": worst["vs_oracle"],
+                              "within_5e-5_of_oracle": bool(worst["vs_oracle"] <= 5e-5), "max_kv_excess_rel": worst["kv"],
+                              "half_roundings_differing_from_oracle": flips_layer, "per_mode": per_mode,
+                              "seconds": round(time.perf_counter() - t0, 2)}
+
+        # ---- (b) + (c) end to end ----------------------------------------------------------------------------------------------
+        t0 = time.perf_counter()
+        fedall = fed
+        arb = A.ArbiterModel(m)
+        free = [arb.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in fedall:
+            free.append(arb.forward([t], pos))
+            pos += 1
+        free = np.stack(free)
+        e_oracle_free = float(np.abs(want - free).max())
+        # two more equally valid F32 implementations (the restatement on embeddings perturbed by one ulp): how far a correct F32
+        # implementation sits from the arbiter is a random draw of flips; the bar is 1.25 x the largest of the three draws
+        e_variants = [float(np.abs(_teacher_stream(m, prompt, fedall, seed) - free).max()) for seed in (7, 8)]
+        free_bar = FREE_FACTOR * max([e_oracle_free] + e_variants)
+        # the oracle against the arbiter forced to the ORACLE's decisions: the restatement's own F32 error (reported)
+        arb = A.ArbiterModel(m)
+        fo = [arb.forward(prompt, 0, (m.k_cache, m.v_cache))]
+        pos = len(prompt)
+        for t in fedall:
+            fo.append(arb.forward([t], pos, (m.k_cache, m.v_cache)))
+            pos += 1
+        e_oracle_forced = float(np.abs(want - np.stack(fo)).max())
+        rec["b_arbiter"] = {"oracle_vs_free": e_oracle_free, "perturbed_oracles_vs_free": e_variants, "free_bar": free_bar,
+                            "oracle_vs_forced_to_oracle": e_oracle_forced, "modes": {}}
+        rec["c_end_to_end_vs_oracle"] = {}
+        forced_memo = {}
+        total = len(prompt) + len(fedall)
+        for mode in ("reference", "launchers", "fused", "graph"):
+            eng = E.Engine()
+            eng.load(path, ctx)
+            eng.set_option("batched_prefill", mode != "reference")
+            got = [eng.forward(prompt, 0)]
+            pos = len(prompt)
+            for t in fedall:
+                got.append(eng.decode_fused(t, pos, mode == "graph") if mode in ("fused", "graph") else eng.forward([t], pos))
+                pos += 1
+            got = np.stack(got)
+            assert np.isfinite(got).all(), (tag, mode)
+            K = np.zeros_like(m.k_cache)
+            V = np.zeros_like(m.v_cache)
+            for l in range(layers):
+                k, v = eng.kv_read(l, 0, total, per)
+                K[l][:total * per], V[l][:total * per] = k.reshape(-1), v.reshape(-1)
+            eng.close()
+            key = hashlib.sha1(K.tobytes() + V.tobytes()).hexdigest()
+            if key not in forced_memo:
+                arb = A.ArbiterModel(m)
+                ff = [arb.forward(prompt, 0, (K, V))]
+                pos = len(prompt)
+                for t in fedall:
+                    ff.append(arb.forward([t], pos, (K, V)))
+                    pos += 1
+                rep = arb.kv_report
+                forced_memo[key] = (np.stack(ff), sum(x["mismatches"] for x in rep), sum(x["elements"] for x in rep),
+                                    max(x["max_excess_over_row_rms"] for x in rep))
+            ff, nmis, nel, excess = forced_memo[key]
+            e_forced = np.abs(got - ff).max(axis=1)
+            e_free = float(np.abs(got - free).max())
+            e_e2e = np.abs(got - want).max(axis=1)
+            rec["b_arbiter"]["modes"][mode] = {"hip_vs_forced_to_hip_per_step": [float(x) for x in e_forced], "hip_vs_free": e_free,
+                                               "ratio_to_oracle_vs_free": e_free / e_oracle_free,
+                                               "half_roundings_differing_from_arbiter": nmis, "cache_elements": nel,
+                                               "max_kv_excess_rel": excess}
+            rec["c_end_to_end_vs_oracle"][mode] = [float(x) for x in e_e2e]
+            assert e_forced.max() <= FORCED_BAR, (tag, mode, "forced arbiter", e_forced)
+            assert excess <= KV_BAR, (tag, mode, "a stored half is further from the exact value than rounding + F32 error allow", excess)
+            assert e_free <= free_bar, (tag, mode, "free arbiter", e_free, free_bar)
+            assert e_e2e.max() <= E2E_SANITY_BAR, (tag, mode, "end to end", e_e2e)
+            top2 = np.sort(want, axis=1)[:, -2:]
+            clear = (top2[:, 1] - top2[:, 0]) > 2 * E2E_SANITY_BAR
+            assert np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]), (tag, mode, "arg-max")
+        rec["b_c_seconds"] = round(time.perf_counter() - t0, 2)
+        rec["passed"] = True
+    finally:
+        _log(rec)
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
+def test_depth_8b_q8_0_all_32_layers():
+    """BASELINE config 2 (the configuration the metric is quoted on): Llama-3.1-8B shape, Q8_0, all 32 layers."""
+    _depth_parity("8b_q8_0_32_layers", "8b", "Q8_0", 32, 20, 4)
+
+
+def test_depth_8b_q4_k_m_all_32_layers():
+    """BASELINE config 3: the llama.cpp Q4_K_M tensor mix (Q4_K + Q6_K `use_more_bits` layers, Q6_K output) at full depth."""
+    _depth_parity("8b_q4_k_m_32_layers", "8b", "Q4_K_M", 32, 20, 4)
+
+
+@pytest.mark.parametrize("mix", ["Q4_K_M", "Q6_K"])
+def test_depth_70b_width_16_layers(mix):
+    """BASELINE configs 4 / 5 at their real width (H 8192, FFN 28672, 64 / 8 heads), 16 of the 80 layers: load_layer
+    (transformer.cpp:286-328) over the Q5_K attn_v / Q6_K ffn_down mix well beyond the first two layers."""
+    _depth_parity("70b_width_16_layers_" + mix.lower(), "70b", mix, 16, 18, 3)
