@@ -17,7 +17,11 @@ Besides the contract fields the line carries
   cpu_baseline -- the reference's own CLI + host loop (oracle/_ref/ntransformer_cpu: reference src/main.cpp, engine.cpp,
                   transformer.cpp ... compiled unmodified, linked with the CPU restatement of its CUDA kernels) run on the
                   SAME full-size 8B Q8_0 GGUF on this host's cores; its own `Decode: ... tok/s` line is the value
-  config.also  -- (N=1) BASELINE configs 3 and 4 -- 8B Q4_K_M and 70B Q4_K_M -- timed in the same process the same way
+  config.also  -- (N=1) the other BASELINE configurations timed in the same process the same way: 8B Q4_K_M (config 3), 70B Q4_K_M
+                  -n 64 (config 4), 70B Q6_K -n 64 (config 5, one replica) and the headline model decoding behind a 3900-token prompt
+                  (the long-context attention regime)
+  vs_baseline  -- whole-job value / the published single-GPU number of BASELINE.md (48.9 tok/s, RTX 3090): with N independent replicas
+                  (scaling = weak) that is N x the per-GPU speed-up, which `vs_baseline_per_gpu` states on its own
 """
 import argparse
 import json
@@ -47,8 +51,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="the persistent one-launch-per-token kernel instead of fused launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=24, help="-n of the reference CLI run that is the CPU baseline")
-    ap.add_argument("--no-also", action="store_true", help="skip BASELINE configs 3 and 4 (8B Q4_K_M, 70B Q4_K_M)")
+    ap.add_argument("--cpu-tokens", type=int, default=128, help="-n of the reference CLI run that is the CPU baseline (BASELINE config 1: 128)")
+    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (8B Q4_K_M, 70B Q4_K_M, 70B Q6_K, 3.9K-context 8B Q8_0)")
     ap.add_argument("--no-pmc-note", action="store_true")
     ap.add_argument("--prompt-bench", type=int, default=1024, help="also time one prompt pass of this many tokens (0 = skip); reported under config.prompt_pass")
     return ap.parse_args()
@@ -103,7 +107,10 @@ def cpu_baseline_reference_cli(args, spec):
     t_write = time.perf_counter() - t0
     try:
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive")
-        cmd = [exe, "-m", path, "-p", "Hi", "-n", str(args.cpu_tokens), "-t", "0", "--repeat-penalty", "1.0", "-c", str(args.ctx)]
+        # 15 ASCII bytes = BOS + 15 byte-level tokens in the synthetic vocabulary (GPT-2 byte alphabet, no merges): the 16-token prompt
+        # length of the GPU run, greedy, -n 128 = BASELINE config 1 / SURVEY 8(d)
+        cpu_prompt = "abcdefghijklmno"[:max(1, args.prompt_len - 1)]
+        cmd = [exe, "-m", path, "-p", cpu_prompt, "-n", str(args.cpu_tokens), "-t", "0", "--repeat-penalty", "1.0", "-c", str(args.ctx)]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
         wall = time.perf_counter() - t0
@@ -116,9 +123,9 @@ def cpu_baseline_reference_cli(args, spec):
         return {"value": round(n_dec / (ms_dec * 1e-3), 4), "unit": "tokens/s", "cores": threads, "kind": "port",
                 "sample": "reference CLI (oracle/_ref/ntransformer_cpu: reference main.cpp + Engine + Transformer host code, "
                           "unmodified; kernels = the CPU restatement, OpenMP over output rows) on the FULL %s %s GGUF "
-                          "(%.1f GB in %s), -p Hi -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Stats line, %d decode tokens in "
+                          "(%.1f GB in %s), -p %s -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Stats line, %d decode tokens in "
                           "%.0f ms (prompt %s tokens %s ms); whole run %.1f s + %.1f s writing the file"
-                          % (args.model, args.mix, os.path.getsize(path) / 1e9, os.path.dirname(path), args.cpu_tokens, args.ctx,
+                          % (args.model, args.mix, os.path.getsize(path) / 1e9, os.path.dirname(path), cpu_prompt, args.cpu_tokens, args.ctx,
                              n_dec, ms_dec, mp.group(1) if mp else "?", mp.group(2) if mp else "?", wall, t_write),
                 "host": _cpu_model(), "host_cpus": info}
     finally:
@@ -148,7 +155,14 @@ def _gemv_bytes_per_token(spec, mix):
     return total
 
 
-def run_workload(args, model, mix, steps, warmup, timed, sync):
+def activation_form(mix):
+    """what the GEMV launches multiply the integer weights with (csrc/gemv_core.hip.h): F32 activations everywhere, except that Q4_K /
+    Q6_K launches of >= 48 MiB with rows of <= 2 column slices take 22-bit block-floating integer activations (exact integer dot
+    products per 32-column sub-block; error per term 2^-23 of the sub-block's largest |x|, the level of the F32 rounding it replaces)"""
+    return "f32" if mix in ("Q8_0", "Q4_0", "F16", "F32", "Q5_K") else "f32; int24-block for Q4_K / Q6_K launches >= 48 MiB"
+
+
+def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     """Load `model`:`mix` resident, prompt + first token untimed, `warmup` tokens untimed, exactly `steps` greedy decode
     tokens timed by `timed` (replica.timed_steps partial).  Returns the measurements (rank-local roofline included)."""
     import numpy as np
@@ -163,7 +177,8 @@ def run_workload(args, model, mix, steps, warmup, timed, sync):
     eng.load_synthetic(spec, args.ctx)
     t_load = time.perf_counter() - t_load
     rng = np.random.Generator(np.random.Philox(key=[20260925, 99]))
-    prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, args.prompt_len - 1)]
+    prompt_len = prompt_len or args.prompt_len
+    prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, prompt_len - 1)]
     # prefill + first token (untimed), exactly Engine::generate's first half
     first = eng.generate_tokens(prompt, 1, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False)
     tok, pos = first[0], len(prompt)
@@ -269,7 +284,8 @@ def main():
             "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(tok_s / REF_3090_TOK_S, 3) if headline else None,   # whole-job value / the published single-GPU number
-            "dtype": "f32", "data": "synthetic",
+            "vs_baseline_per_gpu": round(tok_s / world / REF_3090_TOK_S, 3) if headline else None,
+            "dtype": "f32", "activation_form": activation_form(args.mix), "data": "synthetic",
             "config": {"workload": "Llama-3.1-%s-shaped %s GGUF tensors (seed 20260925), resident in HBM, %d-token prompt, greedy decode"
                                    % (args.model.upper(), args.mix, args.prompt_len),
                        "ctx": args.ctx, "decode_positions": [r["pos"], r["pos_end"]], "replicas": world,
@@ -280,21 +296,27 @@ def main():
             "hbm_fraction_of_8TBs_end_to_end": round(r["b_tok"] * tok_s / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline_block(args, args.model, args.mix, r),
         }
-        # ---- BASELINE configs 3 and 4 under the same clock (N = 1 only: they are single-GPU configurations) ----
+        # ---- the other BASELINE configurations under the same clock (N = 1 only: they are single-GPU configurations) ----
         if world == 1 and headline and not args.no_also:
             also = []
-            for model, mix, steps in (("8b", "Q4_K_M", 128), ("70b", "Q4_K_M", 64)):
+            for model, mix, steps, plen in (("8b", "Q4_K_M", 128, None), ("70b", "Q4_K_M", 64, None), ("70b", "Q6_K", 64, None),
+                                            ("8b", "Q8_0", 64, 3900)):
                 try:
-                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local, sync)
+                    keep_pb = args.prompt_bench
+                    if plen:
+                        args.prompt_bench = 0
+                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local, sync, prompt_len=plen)
+                    args.prompt_bench = keep_pb
                     a_tok_s = steps / a["elapsed"]
                     rb = roofline_block(args, model, mix, a)
-                    also.append({"workload": "Llama-3.1-%s-shaped %s, resident, %d-token prompt, greedy decode" % (model.upper(), mix, args.prompt_len),
+                    also.append({"workload": "Llama-3.1-%s-shaped %s, resident, %d-token prompt, greedy decode" % (model.upper(), mix, plen or args.prompt_len),
                                  "value": round(a_tok_s, 3), "unit": "tokens/s", "steps": steps, "warmup": min(args.warmup, 8),
-                                 "ms_per_step": round(1e3 * a["elapsed"] / steps, 4),
-                                 "algorithmic_bytes_per_token": a["b_tok"],
+                                 "ms_per_step": round(1e3 * a["elapsed"] / steps, 4), "decode_positions": [a["pos"], a["pos_end"]],
+                                 "algorithmic_bytes_per_token": a["b_tok"], "activation_form": activation_form(mix),
                                  "frac": round(a["b_tok"] * a_tok_s / (HBM_PEAK_GBS * 1e9), 4),
                                  "gemv_launch_frac": rb["frac"], "gemv_avg_launch_us": rb["avg_launch_us"],
-                                 "gemv_launches_per_token": rb["launches_per_token"], "path": a["path"], "prompt_pass": a.get("prompt"),
+                                 "gemv_launches_per_token": rb["launches_per_token"],
+                                 "token_ms_by_class_eager": rb["token_ms_by_class_eager"], "path": a["path"], "prompt_pass": a.get("prompt"),
                                  "load_seconds": round(a["t_load"], 2)})
                 except Exception as e:   # the headline must survive a problem in an extra workload
                     also.append({"workload": "%s %s" % (model, mix), "value": None, "error": repr(e)})
@@ -317,7 +339,8 @@ def _pmc_traffic(model, mix):
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     key = "%s_%s" % (model, mix.lower())
     try:
-        g = json.load(open(path))[key]["ntk::gemv_quant_kernel"]
+        d = json.load(open(path))[key]
+        g = d.get("ntk::gemv_quant_*") or d["ntk::gemv_quant_kernel"]   # all forms of the GEMV pooled (tools/pmc_summary.py)
         return int(g["fetch_bytes_per_launch"] + g["write_bytes_per_launch_raw"]), "profiles/pmc_traffic.json[%s]" % key
     except Exception:
         return None, None

@@ -115,31 +115,7 @@ __device__ __forceinline__ void ld16_agent_x4(u32x4& a, u32x4& b, u32x4& c, u32x
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory");
 }
 
-// ---- LDS-DMA: 1 KiB per wave instruction straight from HBM into the wave's ring slot (no VGPR bounce, no ds_write) ----
-// lds_dst: wave-uniform LDS byte address of the chunk; gsrc: this lane's 16 source bytes.  M0 is compiler-reserved: it is
-// saved, set and restored inside the one statement that uses it (cdna_hip_programming.md section 5.7).  Inactive lanes
-// (EXEC) move nothing.  The compiler does not count these loads: waits are explicit (wait_vm).
-__device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* gsrc) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// wait until at most n of the wave's vector-memory operations are outstanding (they complete in order): n = the DMA
-// instructions issued AFTER the row that must have landed.  Anything else issued after it (a y store, a residual load)
-// only makes the wait stricter than needed, never weaker.
-__device__ __forceinline__ void wait_vm(int n) {   // wave-uniform
-    if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (n >= 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
+// (dma16 and wait_vm: gemv_core.hip.h)
 
 // ---- grid barrier: arrive / wait split, XCD-hierarchical counters, bounded spin ----------------------------------
 __device__ __forceinline__ void grid_arrive(unsigned* sync, unsigned epoch) {

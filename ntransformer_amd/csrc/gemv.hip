@@ -47,11 +47,15 @@ namespace ntk {
 struct AttnFuse {};             // (the ATT instantiations exist in EXPERIMENTS=1 builds only)
 #endif
 
-template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false, bool XI = false>
+template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false, bool XI = false, bool DMA = false>
 __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int bid, const int nblk, const AttnFuse* attp = nullptr) {   // workgroup bid of nblk
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
-    constexpr int STAGE = NL * 1024 + 64;
+    // DMA form (rows of one column slice, fast prologue): the wave's staging area is a ring of NB row slots filled by LDS-DMA
+    static_assert(!DMA || (XFAST && !ATT && DMA_OK<DT>), "DMA form: fast prologue, K-quants");
+    constexpr int NB = DMA ? F::NBUF : 1;
+    constexpr int SLOT = DMA_SLOT<DT>;
+    constexpr int STAGE = DMA ? NB * SLOT : NL * 1024 + 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef NTK_GEMV_TRACE
     unsigned long long gv_t[GT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -144,6 +148,13 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     };
 
     u32x4 pf[NL];
+    // rows that start 16-byte aligned (A16) cover the same 16-byte chunks row after row: the clamped chunk offsets are lane constants
+    unsigned pre_off[NL];
+    if constexpr (A16) {
+        const unsigned last0 = (slice_bytes - 1u) & ~15u;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) pre_off[j] = min(16u * (unsigned)(lane + 64 * j), last0);
+    }
     int pf_seg = 0, pf_row = 0, pf_shift = 0;   // what the bytes in pf[] belong to
     float pf_res = 0.0f;                         // residual of that row (ns == 1): fetched a row ahead, not in the epilogue
     auto issue = [&]() {   // prefetch the item under the cursor (rows * row_bytes < 4 GiB: checked on the host)
@@ -160,9 +171,37 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         const uint8_t* a = p.seg[cu_seg].W + (rel & ~15u);
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const unsigned off = min(16u * (unsigned)(lane + 64 * j), last);
+            unsigned off;
+            if constexpr (A16) off = pre_off[j]; else off = min(16u * (unsigned)(lane + 64 * j), last);
             pf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + off));
         }
+    };
+    // ---- DMA form: ring bookkeeping (all wave-uniform).  vm_issued counts every vector-memory operation of the wave from here on
+    //      (DMA pieces, the residual's DMA, the y stores); d_mark[slot] = its value right after the slot's last DMA piece ----
+    unsigned vm_issued = 0;
+    int d_seg[NB], d_row[NB], d_shift[NB];
+    unsigned d_mark[NB];
+    const uint32_t lds_stage = (uint32_t)(uintptr_t)stage;   // generic -> LDS byte address: the low 32 bits
+    auto dma_issue = [&](const int slot) {   // the item under the cursor -> ring slot `slot`
+        d_seg[slot] = cu_seg; d_row[slot] = cu_row;
+        const unsigned rel = (unsigned)p.seg[cu_seg].delta + (unsigned)cu_row * p.row_bytes + slice_byte0;
+        d_shift[slot] = (int)(rel & 15u);
+        const unsigned last = ((rel & 15u) + slice_bytes - 1u) & ~15u;
+        const uint8_t* a = p.seg[cu_seg].W + (rel & ~15u);
+        const uint32_t dst = lds_stage + (uint32_t)(slot * SLOT);
+        if (p.resid != nullptr) {   // the row's residual travels with it (last 16 bytes of the slot): no register waits for it
+            if (lane == 0) dma4(__builtin_amdgcn_readfirstlane(dst + (uint32_t)(SLOT - 16)), p.resid + cu_row);
+            ++vm_issued;
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if (1024u * (unsigned)j <= last) {   // uniform: the piece exists (then lane 0 of it does)
+                const unsigned off = 16u * (unsigned)(lane + 64 * j);
+                if (off <= last) dma16(__builtin_amdgcn_readfirstlane(dst + 1024u * (unsigned)j), a + off);
+                ++vm_issued;
+            }
+        }
+        d_mark[slot] = vm_issued;
     };
     if (n_my <= 0) { cu_seg = 0; cu_row = 0; }   // a wave without rows still prefetches (row 0): keeps the prologue branch-free
 
@@ -226,6 +265,11 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             // asm "uses" them, so the compiler's own wait sits in front of it.
             asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
             if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
+            if constexpr (DMA) {   // rows 0 .. NB-2 of the wave start their way into the ring (LDS-DMA: no registers involved)
+#pragma unroll
+                for (int k = 0; k + 1 < NB; ++k)
+                    if (k < n_my) { if (k > 0) cursor_advance(); dma_issue(k); }
+            } else
             issue();   // unconditional (a wave without rows re-reads row 0)
             GV_STAMP(8);   // first weight row requested
             }
@@ -419,6 +463,17 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
         for (int j = 0; j < 32; ++j) if ((j & 8) != 0) x2[j] *= 0.0625f;   // pairs 8..15 of each 16: columns 16..31 of a block
     }
     float gate_carry = 0.0f;
+    // SiLU(gate) * up epilogue of rows of one column slice: the wave's results are collected lane by lane (lane i keeps pair i of the
+    // current batch of 64 pairs) and SiLU -- expf and a division, ~25 VALU instructions -- runs ONCE per batch on up to 64 lanes instead
+    // of once per pair on one lane (the K-quant launches are VALU-issue bound: 12 of ~145 instructions per row went here)
+    float pair_g = 0.0f, pair_u = 0.0f;
+    auto silu_flush = [&](const int last_pair) {   // pairs (last_pair & ~63) .. last_pair of this wave
+        const int base = last_pair & ~63;
+        if (lane <= last_pair - base) {
+            const int row = group + (base + lane) * ngroups;
+            p.seg[0].y[row] = pair_g / (1.0f + expf(-pair_g)) * pair_u;   // reference gemm.cu:719-724
+        }
+    };
 
     // cross-slice combine of one batch (ns > 1): wave s == 0 of each row group sums the ns partials of
     // item i in slice order and applies the epilogue; `cnt` items of batch b are valid
@@ -455,6 +510,41 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     // Every wave walks its own list of (segment,row) items; the valid ones are a prefix of length n_my.
     // All loads / LDS writes are unpredicated (lanes past the slice end re-read its last chunk) so the loop
     // body is straight-line code: hipcc then waits for the prefetch exactly once, right before the ds_writes.
+    if constexpr (DMA) {
+        // NB - 1 rows are on their way; per row: wait for its pieces (in-order completion: count what was issued after them), start
+        // the row NB - 1 ahead into the slot the previous row has just left, decode from the slot, reduce, store.  Unrolled by NB so
+        // that slot numbers are constants.  p.ns == 1 (host).
+        for (int q0 = 0; q0 < n_my; q0 += NB) {
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int q = q0 + u;
+                if (q >= n_my) break;
+                wait_vm(vm_issued - d_mark[u]);
+                if (q + NB - 1 < n_my) { cursor_advance(); dma_issue((u + NB - 1) % NB); }
+                const uint8_t* st = stage + u * SLOT;
+                const int seg = d_seg[u], row = d_row[u], shift = A16 ? 0 : d_shift[u];
+                float acc;
+                if constexpr (XI && DT == NTK_DT_Q6_K) acc = DotI<DT>::run(st, shift, lane, ncols, xi);
+                else if constexpr (XI) acc = DotI<DT>::run(st, lane, ncols, xi);
+                else acc = Dot<DT, A16>::run(st, shift, lane, ncols, x2, sx16, sx32);
+                const float tot = wave_sum_lane63(acc);   // valid in lane 63
+                if (p.silu_pair) {
+                    if ((q & 1) == 0) { if (lane == 63) gate_carry = tot; }
+                    else {
+                        if (lane == 63) p.seg[0].y[row] = gate_carry / (1.0f + expf(-gate_carry)) * tot;   // reference gemm.cu:719-724
+                        ++vm_issued;
+                    }
+                } else {
+                    if (lane == 63) {
+                        float v = tot;
+                        if (p.resid != nullptr && seg == 0) v = *reinterpret_cast<const float*>(st + SLOT - 16) + v;   // elementwise.cu:23-32
+                        p.seg[seg].y[row] = v;
+                    }
+                    ++vm_issued;
+                }
+            }
+        }
+    } else
     for (int q = 0; q < n_my; ++q) {
         const int seg = pf_seg, row = pf_row, shift = A16 ? 0 : pf_shift;
         const float res = pf_res;
@@ -480,15 +570,18 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
 #endif
 
         if (p.ns == 1) {
-            if (lane == 63) {
-                if (p.silu_pair) {
-                    if ((q & 1) == 0) gate_carry = tot;
-                    else p.seg[0].y[row] = gate_carry / (1.0f + expf(-gate_carry)) * tot;   // reference gemm.cu:719-724
-                } else {
-                    float v = tot;
-                    if (p.resid != nullptr && seg == 0) v = res + v;                      // reference elementwise.cu:23-32
-                    p.seg[seg].y[row] = v;
+            if (p.silu_pair) {
+                const float t63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tot), 63));
+                const int pi = (q >> 1) & 63;
+                if ((q & 1) == 0) { if (lane == pi) pair_g = t63; }
+                else {
+                    if (lane == pi) pair_u = t63;
+                    if (pi == 63 || q == n_my - 1) silu_flush(q >> 1);   // n_my is even: gate and up rows alternate
                 }
+            } else if (lane == 63) {
+                float v = tot;
+                if (p.resid != nullptr && seg == 0) v = res + v;                      // reference elementwise.cu:23-32
+                p.seg[seg].y[row] = v;
             }
         } else {
             const int b = q / RB, i = q % RB;
@@ -539,18 +632,28 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     gemv_quant_body<DT, NORM, XFAST, A16>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // integer-activation form (Q4_K, aligned fast prologue, rows of <= 16384 columns): gemv_core.hip.h XInt / DotI
-template <int DT, bool NORM>
+template <int DT, bool NORM, bool DMA = false>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_xi_kernel(const GemvParams p) {
-    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
+    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, true, DMA>(p, (int)blockIdx.x, (int)gridDim.x);
 }
+#ifdef NTK_EXPERIMENTS
+// LDS-DMA row ring (K-quants, rows of one column slice, aligned fast prologue): float activations
+template <int DT, bool NORM>
+__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_dma_kernel(const GemvParams p) {
+    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+#else
+template <int DT, bool NORM>
+__global__ void gemv_quant_dma_kernel(const GemvParams) {}   // (never launched: DMA_OK is false)
+#endif
 
 // Two weight formats in ONE launch (llama.cpp's Q4_K_M stores attn_v as Q6_K / Q5_K next to Q4_K attn_q / attn_k): the first
 // `split` workgroups run format A on its segments, the rest format B on its own -- the two halves share nothing but x.  One
 // launch instead of two for the fused norm + Q|K|V projection of those layers (16 of 32 at 8B, all 80 at 70B).
-template <int DTA, int DTB, bool NORM>
+template <int DTA, int DTB, bool NORM, bool DMA = false>
 __global__ __launch_bounds__(512, 4) void gemv_quant_pair_kernel(const GemvParams pa, const GemvParams pb, const int split) {
-    if ((int)blockIdx.x < split) gemv_quant_body<DTA, NORM, true, A16_OK<DTA>>(pa, (int)blockIdx.x, split);
-    else gemv_quant_body<DTB, NORM, true, A16_OK<DTB>>(pb, (int)blockIdx.x - split, (int)gridDim.x - split);
+    if ((int)blockIdx.x < split) gemv_quant_body<DTA, NORM, true, A16_OK<DTA>, false, false, DMA>(pa, (int)blockIdx.x, split);
+    else gemv_quant_body<DTB, NORM, true, A16_OK<DTB>, false, false, DMA>(pb, (int)blockIdx.x - split, (int)gridDim.x - split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -609,7 +712,18 @@ struct GemvLaunch {
     int grid, nwaves;
     size_t lds;
     bool xfast, a16;
+    bool dma;          // eligible for the LDS-DMA row ring (K-quants, one column slice, aligned fast prologue)
+    size_t lds_dma;    // ... and its LDS footprint
 };
+
+// NTK_GEMV_DMA=0: the register-prefetch form everywhere (A/B on one build)
+static bool dma_enabled() {
+    static const bool on = [] { const char* e = getenv("NTK_GEMV_DMA"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+static bool raise_lds_limit(const void* fn) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+}
 
 // argument checks + geometry of one single-format launch (max_wg workgroups at most)
 template <int DT>
@@ -676,6 +790,8 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     bool a16 = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
     for (int i = 0; i < nseg; ++i) a16 = a16 && p.seg[i].delta == 0;
     L.a16 = a16;
+    L.dma = DMA_OK<DT> && dma_enabled() && L.xfast && p.ns == 1 && a16 == A16_OK<DT> && !(kAblate & 7);
+    L.lds_dma = image_bytes + (size_t)L.nwaves * F::NBUF * DMA_SLOT<DT> + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
     return NTK_OK;
 }
 
@@ -727,6 +843,16 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
         if (!xi_off && L.xfast && (L.a16 || DT == NTK_DT_Q6_K) && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves && launch_bytes >= g_xi_min_bytes) {
             using XFn = void (*)(const GemvParams);
             static const XFn xt[2] = {gemv_quant_xi_kernel<DT, false>, gemv_quant_xi_kernel<DT, true>};
+            if constexpr (DMA_OK<DT>) {
+                if (L.dma) {   // integer activations + LDS-DMA row ring
+                    static const XFn xd[2] = {gemv_quant_xi_kernel<DT, false, true>, gemv_quant_xi_kernel<DT, true, true>};
+                    static const bool ok = raise_lds_limit((const void*)xd[0]) && raise_lds_limit((const void*)xd[1]);
+                    if (ok && L.lds_dma <= 160 * 1024) {
+                        hipLaunchKernelGGL(xd[norm_w ? 1 : 0], g, b, L.lds_dma, st, L.p);
+                        return last_launch_status();
+                    }
+                }
+            }
             if (L.lds > 64 * 1024) {
                 static bool once2 = hipFuncSetAttribute((const void*)xt[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                                     hipFuncSetAttribute((const void*)xt[1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -734,6 +860,17 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
             }
             hipLaunchKernelGGL(xt[norm_w ? 1 : 0], g, b, L.lds, st, L.p);
             return last_launch_status();
+        }
+    }
+    if constexpr (DMA_OK<DT>) {
+        if (L.dma) {   // LDS-DMA row ring, float activations
+            using DFn = void (*)(const GemvParams);
+            static const DFn dt_[2] = {gemv_quant_dma_kernel<DT, false>, gemv_quant_dma_kernel<DT, true>};
+            static const bool ok = raise_lds_limit((const void*)dt_[0]) && raise_lds_limit((const void*)dt_[1]);
+            if (ok && L.lds_dma <= 160 * 1024) {
+                hipLaunchKernelGGL(dt_[norm_w ? 1 : 0], g, b, L.lds_dma, st, L.p);
+                return last_launch_status();
+            }
         }
     }
     hipLaunchKernelGGL(table[norm_w ? 1 : 0][L.xfast ? 1 : 0][L.a16 ? 1 : 0], g, b, L.lds, st, L.p);
@@ -778,8 +915,19 @@ static int launch_pair(const ntk_gemv_seg* sa, int na, const ntk_gemv_seg* sb, i
     // the pair kernel is the aligned fast form of both formats: anything else goes out as two launches (NTK_E_ALIGN -> caller)
     if (!A.xfast || !B.xfast || A.nwaves != B.nwaves || A.a16 != A16_OK<DTA> || B.a16 != A16_OK<DTB>) return NTK_E_ALIGN;
     for (int i = 0; i < na; ++i) if (A.p.seg[i].delta != 0 && A16_OK<DTA>) return NTK_E_ALIGN;
-    const size_t lds = std::max(A.lds, B.lds);
     using PairFn = void (*)(const GemvParams, const GemvParams, int);
+    if constexpr (DMA_OK<DTA> && DMA_OK<DTB>) {
+        if (A.dma && B.dma) {   // both halves on the LDS-DMA row ring
+            static const PairFn td[2] = {gemv_quant_pair_kernel<DTA, DTB, false, true>, gemv_quant_pair_kernel<DTA, DTB, true, true>};
+            static const bool ok = raise_lds_limit((const void*)td[0]) && raise_lds_limit((const void*)td[1]);
+            const size_t ld = std::max(A.lds_dma, B.lds_dma);
+            if (ok && ld <= 160 * 1024) {
+                hipLaunchKernelGGL(td[norm_w ? 1 : 0], dim3(A.grid + B.grid), dim3(64 * A.nwaves), ld, st, A.p, B.p, A.grid);
+                return last_launch_status();
+            }
+        }
+    }
+    const size_t lds = std::max(A.lds, B.lds);
     static const PairFn table[2] = {gemv_quant_pair_kernel<DTA, DTB, false>, gemv_quant_pair_kernel<DTA, DTB, true>};
     if (lds > 64 * 1024) {
         static bool once = hipFuncSetAttribute((const void*)table[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&

@@ -42,11 +42,60 @@ template <int DT> struct Fmt;
 // BW/BB: weights / bytes per GGUF block; NL: 1 KiB chunks per <=4096-column slice (+15 alignment bytes);
 // MINW: waves per SIMD the register allocator must leave room for (4 -> <=128 VGPRs, 3 -> <=168: the 5/6-bit
 // decoders keep more packed dwords live and would otherwise spill the prefetch registers)
-template <> struct Fmt<NTK_DT_Q8_0> { static constexpr int BW = 32, BB = 34, NL = 5, MINW = 4; };
-template <> struct Fmt<NTK_DT_Q4_0> { static constexpr int BW = 32, BB = 18, NL = 3, MINW = 4; };
-template <> struct Fmt<NTK_DT_Q4_K> { static constexpr int BW = 256, BB = 144, NL = 3, MINW = 4; };
-template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, NL = 3, MINW = 4; };
-template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 4; };
+// NBUF: row slices per wave in the LDS-DMA ring (gemv.hip, DMA form: NBUF - 1 rows in flight beside the one being decoded), sized
+// so that two 8-wave workgroups still fit a CU's 160 KB (image 17 KB + 8 x NBUF x slice)
+template <> struct Fmt<NTK_DT_Q8_0> { static constexpr int BW = 32, BB = 34, NL = 5, MINW = 4, NBUF = 1; };
+template <> struct Fmt<NTK_DT_Q4_0> { static constexpr int BW = 32, BB = 18, NL = 3, MINW = 4, NBUF = 3; };
+template <> struct Fmt<NTK_DT_Q4_K> { static constexpr int BW = 256, BB = 144, NL = 3, MINW = 4, NBUF = 3; };
+template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, NL = 3, MINW = 4, NBUF = 2; };
+template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 4, NBUF = 2; };
+// bytes of one ring slot: a <= 4096-column slice + its alignment shift, rounded to 16, + 16 (the row's residual value)
+template <int DT> constexpr int DMA_SLOT = ((4096 / Fmt<DT>::BW * Fmt<DT>::BB + 30) / 16) * 16 + 16;
+// Formats that have the DMA form.  EXPERIMENTS=1 builds only: measured in round 3 (profiles/r03_gemv_lds_dma_ring_experiment.txt), two
+// or three row slices in flight per wave instead of one change NOTHING -- Q4_K gate|up 16.7 -> 16.3 us, LM head 52.8 -> 52.7, 70B
+// gate|up 48.7 -> 49.1, 8B Q4_K_M decode 632 -> 629 tok/s, 70B 104.3 -> 104.7: the long K-quant launches are bound by VALU issue (84 % of
+// the SIMD's issue slots, profiles/r02_kquant_valu_experiments.txt), not by bytes in flight.  Correct (all GEMV parity tests ran on
+// it), kept as an opt-in record beside the persistent kernel and the attention-in-Wo launch.
+#ifdef NTK_EXPERIMENTS
+template <int DT> constexpr bool DMA_OK = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K || DT == NTK_DT_Q6_K);
+#else
+template <int DT> constexpr bool DMA_OK = false;
+#endif
+
+// ---- LDS-DMA: up to 1 KiB per wave instruction straight from HBM into the wave's ring slot (no VGPR bounce, no ds_write) ----
+// lds_dst: wave-uniform LDS byte address the wave's lane 0 writes (lane l writes lds_dst + 16 l / 4 l); gsrc: this lane's source.
+// M0 is compiler-reserved: saved, set and restored inside the one statement that uses it (cdna_hip_programming.md 5.7).  Inactive
+// lanes (EXEC) move nothing.  The compiler does not count these loads: the waits are explicit (wait_vm).
+__device__ __forceinline__ void dma16(uint32_t lds_dst, const uint8_t* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4(uint32_t lds_dst, const float* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// wait until at most n of the wave's vector-memory operations are outstanding (they complete in order): n = the operations issued
+// AFTER the last DMA instruction of the row that must have landed.  An operation issued and not counted only makes the wait
+// stricter than needed, never weaker; counting one that was not issued would be the bug.
+__device__ __forceinline__ void wait_vm(unsigned n) {   // wave-uniform
+    if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (n == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if (n == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // formats that have a 16-byte-aligned fast decoder (others instantiate only the general one)
 template <int DT> constexpr bool A16_OK = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
@@ -253,9 +302,10 @@ template <> struct DotI<NTK_DT_Q4_K> {   // reference gemm.cu:190-244 (rows 16-b
             b1 = __builtin_amdgcn_udot4(hi, xi.d[1][8 + i], b1, false);
             b2 = __builtin_amdgcn_sdot4((int)hi, (int)xi.d[2][8 + i], b2, false);
         }
-        // every partial sum is below 2^24: exact as a float; the planes recombine with two FMAs
-        const float fa = fmaf(65536.0f, (float)a2, fmaf(256.0f, (float)a1, (float)a0)) * xi.inv[0];
-        const float fb = fmaf(65536.0f, (float)b2, fmaf(256.0f, (float)b1, (float)b0)) * xi.inv[1];
+        // the planes recombine in INTEGER arithmetic: |sum_k n_k X_k| <= 15 * 32 * 2^22 < 2^31, so a0 + 256 a1 + 65536 a2 is the exact
+        // sub-block sum (two v_lshl_add_u32), rounded to F32 once (before: three converts and two FMAs)
+        const float fa = (float)(int)(a0 + (a1 << 8) + ((uint32_t)a2 << 16)) * xi.inv[0];
+        const float fb = (float)(int)(b0 + (b1 << 8) + ((uint32_t)b2 << 16)) * xi.inv[1];
         float t = d1 * fa;
         t = fmaf(-m1, xi.sx[0] + xi.sx[1], t);
         t = fmaf(d2, fb, t);
@@ -292,8 +342,9 @@ template <> struct DotI<NTK_DT_Q6_K> {   // reference gemm.cu:421-459; lane = (b
                 b1 = __builtin_amdgcn_udot4(qb, xi.d[1][8 + 4 * is + i], b1, false);
                 b2 = __builtin_amdgcn_sdot4((int)qb, (int)xi.d[2][8 + 4 * is + i], b2, false);
             }
-            S[is] = fmaf(65536.0f, (float)a2, fmaf(256.0f, (float)a1, (float)a0)) * xi.inv[0];
-            S[2 + is] = fmaf(65536.0f, (float)b2, fmaf(256.0f, (float)b1, (float)b0)) * xi.inv[1];
+            // (q <= 63 over 16 columns can reach 2^32: the top plane stays a float term; the two unsigned planes combine as integers)
+            S[is] = fmaf(65536.0f, (float)a2, (float)(a0 + (a1 << 8))) * xi.inv[0];
+            S[2 + is] = fmaf(65536.0f, (float)b2, (float)(b0 + (b1 << 8))) * xi.inv[1];
         }
         float bs = sb2f(sc_lo, 0) * fmaf(-32.0f, xi.sx[0], S[0]);
         bs = fmaf(sb2f(sc_lo, 1), fmaf(-32.0f, xi.sx[1], S[1]), bs);

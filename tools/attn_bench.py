@@ -36,8 +36,8 @@ def main():
         k = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         v = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         out = DB.zeros(nh * hd * 4)
-        scratch = DB(int(L.ntk_attention_split_scratch_bytes(nh, hd, 64)))
-        for pos, nsplit in ((16, 1), (128, 1), (255, 1), (320, 1), (320, 8), (320, 16), (320, 32), (512, 1), (512, 8), (512, 32), (1024, 1), (1024, 8), (1024, 16), (1024, 32), (2048, 16), (2048, 32), (4095, 1), (4095, 8), (4095, 16), (4095, 32), (4095, 64)):
+        scratch = DB.zeros(int(L.ntk_attention_split_scratch_bytes(nh, hd, 64)))
+        for pos, nsplit in ((16, 1), (128, 1), (128, 2), (255, 1), (255, 2), (255, 4), (320, 1), (320, 2), (320, 4), (320, 8), (320, 16), (320, 32), (512, 1), (512, 2), (512, 4), (512, 8), (512, 32), (1024, 1), (1024, 4), (1024, 8), (1024, 16), (1024, 32), (2048, 8), (2048, 16), (2048, 32), (4095, 1), (4095, 4), (4095, 8), (4095, 16), (4095, 32), (4095, 64)):
             dpos = DB.from_numpy(np.array([pos], np.int32))
             n = 64
             def launch(i):
@@ -61,7 +61,7 @@ def main():
             kvb = 2 * (pos + 1) * per * 2
             res.append({"model": name, "pos": pos, "nsplit": nsplit, "us": round(us, 2), "kv_MB": round(kvb / 1e6, 3), "GBs": round(kvb / us / 1e3, 1)})
             print("%-4s pos %5d nsplit %2d: %8.2f us per layer (%s), KV %7.3f MB -> %7.1f GB/s"
-                  % (name, pos, nsplit, us, "1 launch" if nsplit == 1 else "2 launches", kvb / 1e6, kvb / us / 1e3), flush=True)
+                  % (name, pos, nsplit, us, "single pass" if nsplit == 1 else "split", kvb / 1e6, kvb / us / 1e3), flush=True)
     if a.json: json.dump(res, open(a.json, "w"), indent=1)
 
 
