@@ -169,12 +169,9 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale,
                                void* stream);
 
-/* Long-context form of ntk_attention_decode_fused: the cache walk of a head is split over workgroups.  Every Llama shape (group =
- * n_heads / n_kv_heads in {1, 2, 4, 8}) takes the KV-head form: one workgroup per (KV head, split) reads each cache row ONCE for the
- * whole query group, `nsplit` x group splits per KV head, and the last split to finish merges them -- ONE launch.  Other group sizes:
- * `nsplit` workgroups per query head + a merge launch.  Partial softmax states and the per-KV-head ticket words live in `scratch`
- * (ntk_attention_split_scratch_bytes; ZERO it once before the first use, every launch leaves it reusable).  Same arguments and
- * results as ntk_attention_decode_fused (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches. */
+/* Long-context form of ntk_attention_decode_fused: `nsplit` workgroups share a head (positions interleaved), partial
+ * softmax states go through `scratch` (ntk_attention_split_scratch_bytes) and a second launch merges them.  Same
+ * arguments and results (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches. */
 size_t ntk_attention_split_scratch_bytes(int n_heads, int head_dim, int nsplit);
 int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache,
                                void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,

@@ -12,7 +12,6 @@
 // engine's decode path additionally fuses RoPE + KV store into the attention launch and takes the position
 // from device memory so the launch can be replayed from a hipGraph.
 #include "common.hip.h"
-#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -446,294 +445,6 @@ __global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __r
     }
 }
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// 16-byte write-through store / eight 16-byte loads past the L1 with ONE wait (asm: the compiler would wait after each atomic load)
-__device__ __forceinline__ void st16_sc1(float* p, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void ld16_sc1_x8(f32x4 (&a)[8], const float* const (&p)[8]) {
-    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
-                 "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
-                 "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(a[4]), "=&v"(a[5]), "=&v"(a[6]), "=&v"(a[7])
-                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
-}
-
-// ---------------------------------------------------------------------------------------------
-// Long-context decode attention, one workgroup per (KV head, split) -- round 3 (replaces the per-query-head split kernel above as
-// the engine's long-context form; reference attention.cu:108-202 walks the cache once per QUERY head, i.e. every K / V row is read
-// n_heads / n_kv_heads times).  A workgroup loads each cache row of its KV head ONCE (16 bytes per lane) and scores it against all
-// GQ = n_heads / n_kv_heads query heads of the group, whose rotated queries it keeps in registers; per head an online-softmax state
-// (running max, sum, 8 output dims per lane), rescaled once per batch of D positions.  The splits of a KV head leave their
-// un-normalised states in `part` with write-through (sc1) stores, count themselves in on a per-KV-head ticket word, and the LAST
-// arriver merges the splits in split order and writes the heads' outputs: one launch, no combine kernel, no grid-wide wait (no
-// workgroup ever waits for another one, so nothing depends on dispatch order or placement).  The hand-off is the
-// write-through form of cdna_hip_programming.md guideline 16 (R1): every storing wave drains vmcnt, one barrier, one lane takes the
-// ticket with an agent-scope atomic; the merging workgroup reads the states with sc1 loads (past its L1).
-// Ticket word (64 bit): {tag = position of the token, count}.  The tag makes the word self-initialising per token -- a launch that
-// finds another tag (or a full count left by a replay at the same position) starts the count at 1 -- so the words need no reset
-// between launches and survive hipGraph replay; callers zero them once (ntk_attention_decode_split documents it).
-// part layout: [n_kv_heads][nsplit][GQ][hd + 4] floats = acc[hd], m, l, pad; tickets: 64-bit words at the END of the scratch buffer.
-// ---------------------------------------------------------------------------------------------
-template <int LPR, int GQ, int D, int NW>
-__global__ __launch_bounds__(64 * NW) void attention_decode_gqa_kernel(
-    float* __restrict__ output, float* __restrict__ part, unsigned long long* __restrict__ tickets, const float* __restrict__ q,
-    const float* __restrict__ k, const float* __restrict__ v, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
-    const int* __restrict__ d_pos, const float* __restrict__ inv_freq, const int n_kv_heads, const int max_seq, const float scale,
-    const float theta, const float fscale, const int lds_floats) {
-    constexpr int HD = 8 * LPR, PPW = 64 / LPR, G = NW * PPW, NT = 64 * NW, half_dim = HD / 2;
-    constexpr float EMPTY = -3.0e38f;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kvh = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
-    const int stepG = nsplit * G, first = sp * G;
-    float* qs = lds;                    // [GQ][HD] rotated queries
-    float* kx = qs + GQ * HD;           // [HD] rotated key of this token, rounded through half
-    float* vx = kx + HD;                // [HD]
-    float* ms = vx + HD;                // [NW][GQ]
-    float* ls = ms + NW * GQ;           // [NW][GQ]
-    float* accs = ls + NW * GQ;         // [NW][GQ][HD]
-    int* s_last = reinterpret_cast<int*>(lds + lds_floats);   // (in the dynamic region: a static would shift its base)
-    const size_t stride = (size_t)n_kv_heads * HD;
-    const int sub = lane / LPR, part_i = lane % LPR, g = wave * PPW + sub;
-    const uint16_t* kbase = kc + (size_t)kvh * HD + 8 * part_i;
-    const uint16_t* vbase = vc + (size_t)kvh * HD + 8 * part_i;
-    const int pmax = max_seq - 1;
-
-    // first rows of every group on their way before the position is known (indices clamped, validity applied later)
-    u32x4 kraw[D], vraw[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const size_t row = (size_t)min(first + g + stepG * d, pmax) * stride;
-        kraw[d] = *reinterpret_cast<const u32x4*>(kbase + row);
-        vraw[d] = *reinterpret_cast<const u32x4*>(vbase + row);
-    }
-    const int pos = *d_pos;
-    // RoPE of the group's GQ queries and of the key, half-rounding of k and v (reference rotary.cu:46-60, attention.cu:338)
-    uint16_t st_k[2] = {0, 0};
-    for (int idx = tid; idx < (GQ + 1) * half_dim; idx += NT) {
-        const int hq = idx / half_dim, i = idx % half_dim;   // hq == GQ: the key
-        const float* src = hq < GQ ? q + (size_t)(kvh * GQ + hq) * HD : k + (size_t)kvh * HD;
-        const float a = src[i], b = src[i + half_dim];
-        const float f = inv_freq ? inv_freq[i] : 1.0f / (float)pow((double)theta, (double)((2.0f * i) / HD));
-        const float angle = pos * f * fscale;
-        float c, sn;
-        sincosf(angle, &sn, &c);
-        const float ra = a * c - b * sn, rb = b * c + a * sn;
-        if (hq < GQ) { qs[hq * HD + i] = ra; qs[hq * HD + i + half_dim] = rb; }
-        else {
-            const uint16_t ha = f2h(ra), hb = f2h(rb);
-            kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
-            if (sp == 0 && pos < max_seq) {   // split 0 stores the new cache row (nobody reads it in this launch: the token comes from LDS)
-                kc[(size_t)pos * stride + (size_t)kvh * HD + i] = ha;
-                kc[(size_t)pos * stride + (size_t)kvh * HD + i + half_dim] = hb;
-            }
-        }
-    }
-    for (int i = tid; i < HD; i += NT) {
-        const uint16_t hv = f2h(v[(size_t)kvh * HD + i]);
-        vx[i] = h2f(hv);
-        if (sp == 0 && pos < max_seq) vc[(size_t)pos * stride + (size_t)kvh * HD + i] = hv;
-    }
-    (void)st_k;
-    __syncthreads();
-
-    float qreg[GQ][8];
-#pragma unroll
-    for (int h = 0; h < GQ; ++h)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qreg[h][j] = qs[h * HD + 8 * part_i + j];
-    float m[GQ], l[GQ], acc[GQ][8];
-#pragma unroll
-    for (int h = 0; h < GQ; ++h) {
-        m[h] = EMPTY; l[h] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[h][j] = 0.0f;
-    }
-    // one batch of NP positions of this group: scores of all heads, then ONE rescale of the running state per head
-    auto batch = [&](const float (*kf)[8], const float (*vf)[8], const bool* valid, const int np) {
-#pragma unroll
-        for (int h = 0; h < GQ; ++h) {
-            float sc[D];
-            float mn = m[h];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (d >= np) { sc[d] = EMPTY; continue; }
-                float t = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t = fmaf(qreg[h][j], kf[d][j], t);
-                t = group_sum<LPR>(t) * scale;
-                sc[d] = valid[d] ? t : EMPTY;
-                mn = fmaxf(mn, sc[d]);
-            }
-            const float a = expf(m[h] - mn);
-            float lsum = l[h] * a;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[h][j] *= a;
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                if (d >= np) continue;
-                const float pw = valid[d] ? expf(sc[d] - mn) : 0.0f;
-                lsum += pw;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(pw, vf[d][j], acc[h][j]);
-            }
-            l[h] = lsum;
-            m[h] = mn;
-        }
-    };
-    for (int base = first; base < pos; base += stepG * D) {   // uniform trip count
-        float kf[D][8], vf[D][8];
-        bool valid[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            valid[d] = base + g + stepG * d < pos;
-            u32x4 vr = vraw[d];
-            if (!valid[d]) vr = u32x4{0u, 0u, 0u, 0u};   // rows past the position hold anything (0 * NaN)
-            unpack8(kraw[d], kf[d]);
-            unpack8(vr, vf[d]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (base + stepG * D < pos) {   // uniform: another batch follows
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const size_t row = (size_t)min(base + stepG * D + g + stepG * d, pmax) * stride;
-                kraw[d] = *reinterpret_cast<const u32x4*>(kbase + row);
-                vraw[d] = *reinterpret_cast<const u32x4*>(vbase + row);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        batch(kf, vf, valid, D);
-    }
-    {   // the token being decoded: from LDS, by the group whose turn it is
-        float kf[D][8], vf[D][8];
-        bool valid[D];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[0][j] = kx[8 * part_i + j]; vf[0][j] = vx[8 * part_i + j]; }
-        valid[0] = first + g == pos % stepG;
-        batch(kf, vf, valid, 1);
-    }
-    // ---- merge the wave's PPW position groups in registers (lanes LPR apart), then the NW waves through LDS ----
-#pragma unroll
-    for (int h = 0; h < GQ; ++h) {
-#pragma unroll
-        for (int off = LPR; off < 64; off <<= 1) {
-            const float mo = __shfl_xor(m[h], off, 64), lo = __shfl_xor(l[h], off, 64);
-            const float mn = fmaxf(m[h], mo);
-            const float wa = expf(m[h] - mn), wb = expf(mo - mn);
-            l[h] = fmaf(l[h], wa, lo * wb);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(acc[h][j], wa, __shfl_xor(acc[h][j], off, 64) * wb);
-            m[h] = mn;
-        }
-        if (sub == 0) {
-            if (part_i == 0) { ms[wave * GQ + h] = m[h]; ls[wave * GQ + h] = l[h]; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) accs[(wave * GQ + h) * HD + 8 * part_i + j] = acc[h][j];
-        }
-    }
-    __syncthreads();
-    // ---- the workgroup's state per head: NW wave states merged, four output dims per thread ----
-    constexpr int ST = HD + 4;                      // floats per stored state: acc[HD], m, l, pad (16-byte aligned records)
-    constexpr int ITEMS = GQ * (HD / 4);            // (head, 4 dims) work items
-    float* mine = part + ((size_t)(kvh * nsplit + sp) * GQ) * ST;
-    for (int it = tid; it < ITEMS; it += NT) {
-        const int h = it / (HD / 4), d4 = it % (HD / 4);
-        float M = ms[h];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) M = fmaxf(M, ms[w * GQ + h]);
-        float L = 0.0f;
-        f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const float wt = expf(ms[w * GQ + h] - M);
-            L = fmaf(wt, ls[w * GQ + h], L);
-            const f32x4 a = *reinterpret_cast<const f32x4*>(accs + (w * GQ + h) * HD + 4 * d4);
-            val.x = fmaf(wt, a.x, val.x); val.y = fmaf(wt, a.y, val.y); val.z = fmaf(wt, a.z, val.z); val.w = fmaf(wt, a.w, val.w);
-        }
-        if (nsplit == 1) {
-            *reinterpret_cast<f32x4*>(output + (size_t)(kvh * GQ + h) * HD + 4 * d4) = f32x4{val.x / L, val.y / L, val.z / L, val.w / L};
-        } else {   // write-through (sc1): the merging workgroup reads these past its L1 (guideline 16, R1)
-            st16_sc1(mine + (size_t)h * ST + 4 * d4, val);
-            if (d4 == 0) {
-                const unsigned long long ml = (unsigned long long)__float_as_uint(M) | ((unsigned long long)__float_as_uint(L) << 32);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + (size_t)h * ST + HD), ml, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    if (nsplit == 1) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its write-through stores are acknowledged
-    __syncthreads();
-    if (tid == 0) {   // take the ticket: {tag = pos, count}
-        unsigned long long* tk = tickets + kvh;
-        unsigned long long old = __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
-        unsigned cnt;
-        do {
-            const unsigned tag = (unsigned)(old >> 32), c = (unsigned)old;
-            cnt = (tag == (unsigned)pos && c < (unsigned)nsplit) ? c + 1u : 1u;
-            want = ((unsigned long long)(unsigned)pos << 32) | cnt;
-        } while (!__hip_atomic_compare_exchange_strong(tk, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        *s_last = cnt == (unsigned)nsplit;
-    }
-    __syncthreads();
-    if (!*s_last) return;
-    // ---- the last arriver merges the nsplit states of every head of the group, in split order.  Step A: every (split, head)'s
-    //      (m, l) into LDS with ONE round trip; step B: SG thread groups share a (head, 4 dims) item, each sums its splits' acc
-    //      records (8 sc1 loads in flight), the groups' sums meet in LDS in group order ----
-    const float* all = part + ((size_t)kvh * nsplit * GQ) * ST;
-    float* mlx = accs;                               // [nsplit][GQ][2]   (the wave states are dead)
-    for (int t = tid; t < nsplit * GQ; t += NT) {
-        const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(all + (size_t)t * ST + HD), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-        mlx[2 * t] = __uint_as_float((unsigned)ml);
-        mlx[2 * t + 1] = __uint_as_float((unsigned)(ml >> 32));
-    }
-    __syncthreads();
-    constexpr int SG = NT / ITEMS >= 1 ? NT / ITEMS : 1;
-    float* red = mlx + 2 * nsplit * GQ;              // [SG][ITEMS][4] + [SG][ITEMS] sums of l
-    const int it = tid % ITEMS, sg = tid / ITEMS;    // (NT is a multiple of ITEMS for every instantiation)
-    if (sg < SG) {
-        const int h = it / (HD / 4), d4 = it % (HD / 4);
-        float M = EMPTY;
-        for (int s2 = 0; s2 < nsplit; ++s2) M = fmaxf(M, mlx[2 * (s2 * GQ + h)]);
-        float L = 0.0f;
-        f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int s0 = sg; s0 < nsplit; s0 += 8 * SG) {
-            f32x4 a[8];
-            const float* p0 = all + ((size_t)s0 * GQ + h) * ST + 4 * d4;
-            const size_t step = (size_t)SG * GQ * ST;
-            const int nlive = min(8, (nsplit - s0 + SG - 1) / SG);
-            const float* pp[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) pp[u] = p0 + (size_t)min(u, nlive - 1) * step;   // (dead slots re-read the last live record)
-            ld16_sc1_x8(a, pp);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (u >= nlive) break;
-                const int s2 = s0 + u * SG;
-                const float wt = expf(mlx[2 * (s2 * GQ + h)] - M);
-                L = fmaf(wt, mlx[2 * (s2 * GQ + h) + 1], L);
-                val.x = fmaf(wt, a[u].x, val.x); val.y = fmaf(wt, a[u].y, val.y); val.z = fmaf(wt, a[u].z, val.z); val.w = fmaf(wt, a[u].w, val.w);
-            }
-        }
-        *reinterpret_cast<f32x4*>(red + ((size_t)sg * ITEMS + it) * 4) = val;
-        red[(size_t)SG * ITEMS * 4 + (size_t)sg * ITEMS + it] = L;
-    }
-    __syncthreads();
-    if (tid < ITEMS) {
-        const int h = tid / (HD / 4), d4 = tid % (HD / 4);
-        float L = 0.0f;
-        f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int g2 = 0; g2 < SG; ++g2) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(red + ((size_t)g2 * ITEMS + tid) * 4);
-            val.x += a.x; val.y += a.y; val.z += a.z; val.w += a.w;
-            L += red[(size_t)SG * ITEMS * 4 + (size_t)g2 * ITEMS + tid];
-        }
-        *reinterpret_cast<f32x4*>(output + (size_t)(kvh * GQ + h) * HD + 4 * d4) = f32x4{val.x / L, val.y / L, val.z / L, val.w / L};
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Prompt attention, flash style (replaces attention_prefill_kernel, reference attention.cu:216-311,
 // whose one-block-per-(head, query) form re-reads every K / V row once per query: 32 x 1024 blocks each walking up
@@ -991,10 +702,8 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
     return ntk::last_launch_status();
 }
 
-// states [n_heads * nsplit][hd + 2] (either kernel form: the KV-head form has n_kv_heads x (nsplit x group) x group of them) +
-// 256 ticket words; ZERO the buffer once before its first use
 size_t ntk_attention_split_scratch_bytes(int n_heads, int head_dim, int nsplit) {
-    return (size_t)n_heads * (size_t)nsplit * 8 * (size_t)(head_dim + 4) * sizeof(float) + 256 * sizeof(unsigned long long);
+    return (size_t)n_heads * (size_t)nsplit * (size_t)(head_dim + 2) * sizeof(float);
 }
 
 int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
@@ -1008,43 +717,6 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     hipStream_t st = ntk::resolve_stream(stream);
     uint16_t* k16 = static_cast<uint16_t*>(k_cache);
     uint16_t* v16 = static_cast<uint16_t*>(v_cache);
-    // the KV-head form: each cache row read once for the whole query group, the splits merged by the last arriver (one launch).
-    // Same number of workgroups as the per-head form: nsplit x group splits per KV head.  NTK_ATT_GQA=0: the per-head form.
-    static const bool gqa_off = [] { const char* e = getenv("NTK_ATT_GQA"); return e && atoi(e) == 0; }();
-    static const int gqa_splits = [] { const char* e = getenv("NTK_ATT_GQA_SPLITS"); return e ? atoi(e) : 0; }();   // tuning: splits per KV head
-    const int gq = n_heads / n_kv_heads;
-    if (!gqa_off && n_kv_heads <= 256 && (gq == 1 || gq == 2 || gq == 4 || gq == 8)) {
-        // splits per KV head: as many workgroups as the per-head form would start, at most 64 (the merge reads them all)
-        const int ns = std::min(gqa_splits > 0 ? std::min(gqa_splits, nsplit * gq) : nsplit * gq, 64);
-        float* part = scratch;   // n_kv_heads x ns x gq records <= n_heads x nsplit x 8 (ntk_attention_split_scratch_bytes)
-        unsigned long long* tickets = reinterpret_cast<unsigned long long*>(
-            reinterpret_cast<uint8_t*>(scratch) + (size_t)n_heads * (size_t)nsplit * 8 * (size_t)(head_dim + 4) * sizeof(float));
-        constexpr int NW = 8;
-#define NTK_ATTG(LPR_, GQ_, D_)                                                                                                          \
-        do {                                                                                                                             \
-            const size_t tailf = std::max<size_t>((size_t)NW * GQ_ * head_dim, (size_t)2 * ns * GQ_ + (size_t)64 * NW * 5);                \
-            const size_t gl = sizeof(float) * ((size_t)(GQ_ + 2) * head_dim + 2 * NW * GQ_ + tailf) + 16;                                \
-            static const bool ok = gl <= 64 * 1024 || hipFuncSetAttribute(reinterpret_cast<const void*>(ntk::attention_decode_gqa_kernel<LPR_, GQ_, D_, NW>), \
-                                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; \
-            if (!ok) return NTK_E_LAUNCH;                                                                                                \
-            hipLaunchKernelGGL((ntk::attention_decode_gqa_kernel<LPR_, GQ_, D_, NW>), dim3(n_kv_heads, ns), dim3(64 * NW), gl, st, output, part, \
-                               tickets, q, k, v, k16, v16, d_pos, inv_freq, n_kv_heads, max_seq, scale, theta_base, freq_scale,          \
-                               (int)((gl - 16) / sizeof(float)));                                                                        \
-            return ntk::last_launch_status();                                                                                            \
-        } while (0)
-#define NTK_ATTG_HD(GQ_, D_)                                          \
-        do {                                                          \
-            if (head_dim == 128) NTK_ATTG(16, GQ_, D_);               \
-            else if (head_dim == 64) NTK_ATTG(8, GQ_, D_);            \
-            else NTK_ATTG(32, GQ_, D_);                               \
-        } while (0)
-        if (gq == 1) NTK_ATTG_HD(1, 4);
-        else if (gq == 2) NTK_ATTG_HD(2, 4);
-        else if (gq == 4) NTK_ATTG_HD(4, 4);
-        else NTK_ATTG_HD(8, 2);
-#undef NTK_ATTG_HD
-#undef NTK_ATTG
-    }
     const int G = 4 * (64 / (head_dim / 8));
     const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
 #define NTK_ATTSP(...) hipLaunchKernelGGL((ntk::attention_decode_split_kernel<__VA_ARGS__>), dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \

@@ -332,7 +332,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_token_ = (int*)dev(64, true);
     argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
-    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), true);   // zeroed once: ticket words
+    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
     sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
     attn_sync_ = (unsigned*)dev(4096, true);

@@ -222,7 +222,7 @@ def attention_decode_fused(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_
 def attention_decode_split(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale,
                            theta_base, nsplit, freq_scale=1.0, inv_freq=None, stream=None):
     """Long-context decode attention: nsplit workgroups per head + a merge launch (ntk_attention_decode_split)."""
-    scratch = DeviceBuffer.zeros(int(_lib.lib().ntk_attention_split_scratch_bytes(n_heads, head_dim, nsplit)))   # zero once: ticket words
+    scratch = DeviceBuffer(int(_lib.lib().ntk_attention_split_scratch_bytes(n_heads, head_dim, nsplit)))
     check(_lib.lib().ntk_attention_decode_split(_p(output), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(d_pos),
                                                 _p(inv_freq), n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base,
                                                 freq_scale, nsplit, _p(scratch), stream), "attention_decode_split")
