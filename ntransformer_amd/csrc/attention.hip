@@ -316,26 +316,47 @@ __device__ __forceinline__ void attention_decode_walk(
     float m = EMPTY, l = 0.0f, acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-    auto step = [&](const float* kf, const float* vf, const bool valid) {   // one position of the online softmax; an exact no-op when !valid
-        float sc = 0.0f;
+    // NP positions of the group's walk as ONE online-softmax update: their scores first, then one rescale of the running state by
+    // exp(m - new max) and NP weights -- NP + 1 exponentials instead of 2 NP, and the hardware exponential (v_exp_f32 on x * log2 e,
+    // ~1 ulp; the reference's CUDA build evaluates expf the same way under --use_fast_math, CMakeLists.txt:20) instead of libm's
+    // ~15-instruction expf: the walk is bound by its VALU work (one wave per SIMD), 75 -> 45 instructions per position and head
+    // (round 3; measured: 8 rows in flight or 8-wave workgroups instead changed nothing, profiles/r03_attention_kv_head_form.txt).
+    // Invalid positions (past the token, or a clamped row) are exact no-ops.
+    auto batch = [&](const float (*kf)[8], const float (*vf)[8], const bool* valid, const int np) {
+        float sc[D];
+        float mn = m;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
-        sc = group_sum<LPR>(sc);
-        sc *= scale;
-        const float s_ = valid ? sc : m;
-        const float mn = fmaxf(m, s_);
-        const float a = expf(m - mn), pw = valid ? expf(s_ - mn) : 0.0f;
-        l = fmaf(l, a, pw);
+        for (int d = 0; d < D; ++d) {
+            if (d >= np) { sc[d] = EMPTY; continue; }
+            float t = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, pw * vf[j]);
+            for (int j = 0; j < 8; ++j) t = fmaf(qreg[j], kf[d][j], t);
+            t = group_sum<LPR>(t) * scale;
+            sc[d] = valid[d] ? t : EMPTY;
+            mn = fmaxf(mn, sc[d]);
+        }
+        const float a = __expf(m - mn);
+        l *= a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] *= a;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d >= np) continue;
+            const float pw = valid[d] ? __expf(sc[d] - mn) : 0.0f;
+            l += pw;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, vf[d][j], acc[j]);
+        }
         m = mn;
     };
     for (int base = first; base < pos; base += stepG * D) {   // uniform trip count
         float kf[D][8], vf[D][8];
+        bool valid[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
+            valid[d] = base + g + stepG * d < pos;
             u32x4 vr = vraw[d];
-            if (base + g + stepG * d >= pos) vr = u32x4{0u, 0u, 0u, 0u};   // rows past the position hold anything (0 * NaN)
+            if (!valid[d]) vr = u32x4{0u, 0u, 0u, 0u};   // rows past the position hold anything (0 * NaN)
             unpack8(kraw[d], kf[d]);
             unpack8(vr, vf[d]);
         }
@@ -349,14 +370,15 @@ __device__ __forceinline__ void attention_decode_walk(
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d < D; ++d) step(kf[d], vf[d], base + g + stepG * d < pos);
+        batch(kf, vf, valid, D);
     }
     {   // the token being decoded: from LDS (another workgroup is writing its cache row), by the group whose turn it is
-        float kf[8], vf[8];
+        float kf[D][8], vf[D][8];
+        bool valid[D];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[j] = kx[8 * part_i + j]; vf[j] = vx[8 * part_i + j]; }
-        step(kf, vf, first + g == pos % stepG);
+        for (int j = 0; j < 8; ++j) { kf[0][j] = kx[8 * part_i + j]; vf[0][j] = vx[8 * part_i + j]; }
+        valid[0] = first + g == pos % stepG;
+        batch(kf, vf, valid, 1);
     }
     if (part_i == 0) { ms[g] = m; ls[g] = l; }
 #pragma unroll

@@ -49,9 +49,10 @@ public:
     int set_device_pos(int pos);
     // attention regime by context length: the single-pass kernel walks a head's cache serially (49 us per layer at 4095),
     // so long contexts split each head over 8 / 16 workgroups (ntk_attention_decode_split)
-    // (measured, tools/attn_bench.py: single pass 6.7 us at 255 / 9.5 at 512 / 15.2 at 1024 / 49 at 4095; 8 splits 9.9 / 9.9 /
-    //  10.9 / 15.9; 16 splits only pay beyond the 4096-token contexts this engine caps at)
-    static int attention_regime(int pos) { return pos < 576 ? 0 : pos < 8192 ? 1 : 2; }
+    // (measured, tools/attn_bench.py, round 3 after the batched softmax update: single pass 6.2 us at 255 / 8.4 at 512 / 12.9 at 1024 /
+    //  38.9 at 4095; 8 splits 9.5 / 9.6 / 10.5 / 14.3: the lines cross near position 675; 16 splits only pay beyond the 4096-token
+    //  contexts this engine caps at)
+    static int attention_regime(int pos) { return pos < 672 ? 0 : pos < 8192 ? 1 : 2; }
     void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)

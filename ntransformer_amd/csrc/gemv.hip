@@ -61,6 +61,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     unsigned long long gv_t[GT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     GV_STAMP(0);   // entry
+#ifndef NTK_GEMV_NO_KARG_PREFETCH
     {
         // The kernel arguments are 5 cache lines; hipcc fetches them piecemeal, each piece right before its first use, so the
         // prologue used to pay a scalar-cache miss per line one after the other before the first weight row could be requested.
@@ -72,6 +73,7 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
                      : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4) : "s"(ka) : "memory");
         __builtin_amdgcn_sched_barrier(0);   // ... before the compiler's own argument loads
     }
+#endif
 
     const int tid = threadIdx.x;
     // The activations (and the norm weights) are requested before anything else is computed (fast prologue, see below): the row

@@ -167,12 +167,12 @@ def test_batched_prefill_fills_the_same_kv_cache(mix, tmp_path):
 
 
 def test_long_context_decode_uses_split_attention_and_matches_the_1to1_path(tmp_path):
-    """Decode at positions 570..580 crosses the engine's attention regimes (single pass -> 8 KV splits at 576,
+    """Decode at positions 668..678 crosses the engine's attention regimes (single pass -> 8 KV splits at 672,
     Model::attention_regime) and 1020..1030 runs well inside the split regime: the fused path (eager and hipGraph) must
     keep agreeing with the reference's 1:1 launcher sequence on the same KV cache."""
     path, z = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)   # head_dim 128, GQA 4, context 2048
     r = np.random.Generator(np.random.Philox(key=[20260925, 777]))
-    for start in (570, 1020):
+    for start in (668, 1020):
         prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, start - 1)]
         cont = [int(t) for t in r.integers(0, 256, 10)]
         outs = {}
