@@ -658,6 +658,10 @@ __global__ __launch_bounds__(512, 4) void gemv_quant_pair_kernel(const GemvParam
     else gemv_quant_body<DTB, NORM, true, A16_OK<DTB>, false, false, DMA>(pb, (int)blockIdx.x - split, (int)gridDim.x - split);
 }
 
+#ifdef NTK_EXPERIMENTS
+#include "gemv_colsplit.hip.h"   // EXPERIMENTS=1: the column-split form of the Q8_0 GEMV at 4096 columns (slower: profiles/r03_gemv_colsplit.txt)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Dense F16 / F32 rows (reference gemm.cu:476-671): one wave per row, 16-byte lane loads when the row
 // is aligned, scalar otherwise (the reference's own F32 test uses in = 3).  Not on any target config.
@@ -830,6 +834,27 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
         }();
         if (!once || L.lds > 160 * 1024) return NTK_E_SHAPE;
     }
+#ifdef NTK_EXPERIMENTS
+    if constexpr (DT == NTK_DT_Q8_0) {
+        // column-split form (gemv_colsplit.hip.h): rows of exactly 4096 columns, everything 16-byte aligned.  Opt-in: NTK_GEMV_COLSPLIT=1.
+        static const int cs_mode = [] { const char* e = getenv("NTK_GEMV_COLSPLIT"); return e ? atoi(e) : 0; }();
+        bool cs = cs_mode != 0 && in == CS_COLS && L.xfast && !(kAblate & 7);
+        for (int i = 0; i < nseg && cs; ++i) cs = L.p.seg[i].delta == 0;
+        if (cs) {
+            const int total = L.p.total_rows, mats = silu_pair ? 2 : 1;
+            const int cgrid = std::min(total, max_workgroups());
+            const size_t items = (size_t)((total + cgrid - 1) / cgrid) * mats;
+            const size_t clds = (size_t)8 * CS_RBT * CS_STRIPE + items * 8 * sizeof(float) + 64;
+            using CFn = void (*)(const GemvParams);
+            static const CFn ct[2] = {gemv_q8_colsplit_kernel<false>, gemv_q8_colsplit_kernel<true>};
+            static const bool ok = raise_lds_limit((const void*)ct[0]) && raise_lds_limit((const void*)ct[1]);
+            if (ok && clds <= 150 * 1024) {
+                hipLaunchKernelGGL(ct[norm_w ? 1 : 0], dim3(cgrid), dim3(512), clds, st, L.p);
+                return last_launch_status();
+            }
+        }
+    }
+#endif
     const dim3 g(L.grid), b(64 * L.nwaves);
 #ifdef NTK_GEMV_TRACE
     static int trace_counter = 0;

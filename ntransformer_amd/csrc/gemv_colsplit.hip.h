@@ -1,0 +1,158 @@
+// gemv_colsplit.hip.h -- column-split form of the Q8_0 GEMV for rows of 4096 columns (included by gemv.hip, namespace ntk).
+// EXPERIMENTS=1 builds only: built in round 3, correct, and SLOWER than the row form on every shape (profiles/r03_gemv_colsplit.txt:
+// q 5.6 -> 6.5 us, gate|up 21.7 -> 27.8, LM head 83.6 -> 127; headline 554 -> 469 tok/s).  Kept as an opt-in record (NTK_GEMV_COLSPLIT=1).
+//
+// Same arithmetic per block as Dot<Q8_0> (reference gemm.cu:129-141: sum += d * sum_j q_j x_j), another decomposition, aimed at the
+// FIXED cost of a launch rather than at its streaming rate (round 3; DESIGN.md 3.1 "where the time goes": at 4096 columns a launch
+// spends ~2.4 us before its median workgroup has the activations in registers -- x round trip, LDS image store, workgroup barrier,
+// every wave reading all 16 KB of x back from LDS -- and weights resident in the Infinity Cache make it no faster,
+// profiles/r03_gemv_colsplit.txt: the launch is a latency pipeline, not a bandwidth problem):
+//   * wave w of the 8 owns columns [512 w, 512 w + 512) of EVERY row of its workgroup; lane l owns 8 of them, so the activations are two
+//     16-byte global loads per lane, coalesced, straight into registers: no LDS image, no barrier in front of the first weight byte,
+//     and the weight loads are issued BEFORE x has landed (a wave's own x is ahead of its own weights in the CU's in-order queue);
+//   * a row's stripe of a wave is 16 blocks = 544 contiguous bytes = 34 lanes x 16 B: one load instruction per row, 8 rows in flight
+//     per wave; the bytes bounce through a wave-private LDS area (blocks are 34 bytes: the lane that loads a chunk is not the lane
+//     that owns its columns) and every lane pulls ITS quarter block (8 quants) + the block's scale;
+//   * a row's sum = 64 lanes x 8 waves: DPP reduction per wave, the 8 wave partials of every row meet in LDS ONCE, at the end of the
+//     launch (one barrier per launch), summed in wave order; RMSNorm prologue (the sum of squares crosses the waves through LDS while
+//     the first weight rows fly), Q|K|V / gate|up segments, residual and SiLU epilogues as in gemv_quant_body.
+// More VALU work per weight than the row form (a reduction per 8 weights and lane instead of per 64: ~3.2 against 2.3 instructions
+// per weight), which Q8_0 can afford (its row form issues VALU on 48 % of the cycles); the K-quants cannot, and their 6-bit scale
+// unpacking per quarter block would cost more than the decode -- they stay on the row form.
+#pragma once
+
+constexpr int CS_COLS = 4096;     // row length this form is built for (8 waves x 512 columns)
+constexpr int CS_STRIPE = 544;    // bytes of a row one wave owns (16 blocks of 34)
+constexpr int CS_RBT = 8;         // rows in flight per wave (one load instruction each)
+
+template <bool NORM>
+__global__ __launch_bounds__(512, 4) void gemv_q8_colsplit_kernel(const GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x, nblk = gridDim.x;
+
+    // ---- activations: this lane's 8 columns, requested first thing ----
+    const float* xsrc = p.x + 512 * wave + 8 * lane;
+    f32x2 xp[4];
+    {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(xsrc), b = *reinterpret_cast<const u32x4*>(xsrc + 4);
+        xp[0] = f32x2{__uint_as_float(a.x), __uint_as_float(a.y)}; xp[1] = f32x2{__uint_as_float(a.z), __uint_as_float(a.w)};
+        xp[2] = f32x2{__uint_as_float(b.x), __uint_as_float(b.y)}; xp[3] = f32x2{__uint_as_float(b.z), __uint_as_float(b.w)};
+    }
+    f32x2 wn[4];
+    if constexpr (NORM) {
+        const float* wsrc = p.norm_w + 512 * wave + 8 * lane;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(wsrc), b = *reinterpret_cast<const u32x4*>(wsrc + 4);
+        wn[0] = f32x2{__uint_as_float(a.x), __uint_as_float(a.y)}; wn[1] = f32x2{__uint_as_float(a.z), __uint_as_float(a.w)};
+        wn[2] = f32x2{__uint_as_float(b.x), __uint_as_float(b.y)}; wn[3] = f32x2{__uint_as_float(b.z), __uint_as_float(b.w)};
+    }
+
+    // ---- the workgroup's items: item i = (segment, row); SiLU pairs keep gate row r and up row r next to each other ----
+    const int mats = p.silu_pair ? 2 : 1;
+    const int n_rows_wg = (p.total_rows > bid) ? (p.total_rows - 1 - bid) / nblk + 1 : 0;
+    const int n_items = n_rows_wg * mats;
+    uint8_t* stage = smem + (size_t)wave * (CS_RBT * CS_STRIPE);
+    float* part = reinterpret_cast<float*>(smem + 8 * (CS_RBT * CS_STRIPE));   // [n_items][8]
+    float* red = part + (size_t)n_items * 8;                                       // [8] sums of squares
+    auto locate = [&](const int i, int& seg, int& row) {   // uniform in i
+        int r = bid + (i >> (mats - 1)) * nblk;
+        if (p.silu_pair) { seg = i & 1; row = r; return; }
+        seg = 0;
+        while (seg + 1 < p.nseg && r >= p.seg[seg].rows) { r -= p.seg[seg].rows; ++seg; }
+        row = r;
+    };
+    // the 16 bytes lane l (< 34) fetches of item i: W_seg + row * row_bytes + 544 wave + 16 l
+    u32x4 pf[CS_RBT];
+    auto issue = [&](const int b0) {
+#pragma unroll
+        for (int r = 0; r < CS_RBT; ++r) {
+            const int i = min(b0 + r, n_items - 1);   // (a short last batch re-reads its last row: no lane-predicated loads)
+            int seg, row;
+            locate(i, seg, row);
+            const uint8_t* a = p.seg[seg].W + (size_t)p.seg[seg].delta + (size_t)row * p.row_bytes + (size_t)(CS_STRIPE * wave);
+            pf[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + 16 * min(lane, 33)));
+        }
+    };
+    if (n_items > 0) issue(0);
+    // the residual of the row this thread will finish (epilogue below), fetched now rather than at the end of the launch
+    float res_pre = 0.0f;
+    if (p.resid != nullptr && !p.silu_pair && tid < n_items) {
+        int seg, row;
+        locate(tid, seg, row);
+        if (seg == 0) res_pre = p.resid[row];
+    }
+
+    // ---- RMSNorm (reference rmsnorm.cu:16-70): x * rsqrt(mean x^2 + eps) * w, the row's sum of squares crossing the waves through LDS
+    //      while the first weight rows are on their way ----
+    if constexpr (NORM) {
+        float ssq = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssq = fmaf(xp[j].x, xp[j].x, ssq); ssq = fmaf(xp[j].y, xp[j].y, ssq); }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red[wave] = ssq;
+        __syncthreads();
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) tot += red[w];
+        const float rms_inv = 1.0f / sqrtf(tot / (float)CS_COLS + p.eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xp[j].x = xp[j].x * rms_inv * wn[j].x; xp[j].y = xp[j].y * rms_inv * wn[j].y; }
+    }
+
+    // ---- rows: batches of CS_RBT, the next batch's loads issued as soon as this one's registers are in LDS ----
+    // lane -> (block b = lane / 4, quarter k = lane % 4) of the wave's 16 blocks; its 8 quants sit at byte 34 b + 2 + 8 k of a row's
+    // stripe -- 2-byte aligned, with a lane-constant offset inside the dword (544 = 16 x 34: the same in every row of the batch)
+    const int blk = lane >> 2, qk = lane & 3;
+    const int qoff = 34 * blk + 2 + 8 * qk;
+    const int qal = qoff & ~3;
+    const uint32_t qsh = (uint32_t)(qoff & 3);
+    for (int b0 = 0; b0 < n_items; b0 += CS_RBT) {
+        const int nb = min(CS_RBT, n_items - b0);
+        if (lane < 34) {
+#pragma unroll
+            for (int r = 0; r < CS_RBT; ++r) *reinterpret_cast<u32x4*>(stage + r * CS_STRIPE + 16 * lane) = pf[r];
+        }
+        __builtin_amdgcn_wave_barrier();   // a wave's DS operations execute in order: the image is visible to its own reads
+        if (b0 + CS_RBT < n_items) issue(b0 + CS_RBT);
+#pragma unroll
+        for (int r = 0; r < CS_RBT; ++r) {
+            if (r >= nb) break;   // uniform
+            const uint8_t* st = stage + r * CS_STRIPE;
+            const uint32_t d0 = *reinterpret_cast<const uint32_t*>(st + qal), d1 = *reinterpret_cast<const uint32_t*>(st + qal + 4),
+                           d2 = *reinterpret_cast<const uint32_t*>(st + qal + 8);
+            const float d = h2f(*reinterpret_cast<const uint16_t*>(st + 34 * blk));
+            const uint32_t q0 = __builtin_amdgcn_alignbyte(d1, d0, qsh), q1 = __builtin_amdgcn_alignbyte(d2, d1, qsh);
+            f32x2 a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+            a0 = pkfma(f32x2{sb2f(q0, 0), sb2f(q0, 1)}, xp[0], a0);
+            a1 = pkfma(f32x2{sb2f(q0, 2), sb2f(q0, 3)}, xp[1], a1);
+            a0 = pkfma(f32x2{sb2f(q1, 0), sb2f(q1, 1)}, xp[2], a0);
+            a1 = pkfma(f32x2{sb2f(q1, 2), sb2f(q1, 3)}, xp[3], a1);
+            const float tot = wave_sum_lane63(d * hsum(a0, a1));
+            if (lane == 63) part[(size_t)(b0 + r) * 8 + wave] = tot;
+        }
+        __builtin_amdgcn_wave_barrier();   // all reads of the image precede its next overwrite
+    }
+
+    // ---- one barrier per launch: every row's 8 wave partials are in LDS; summed in wave order, epilogue, store ----
+    __syncthreads();
+    const int n_out = p.silu_pair ? n_rows_wg : n_items;
+    for (int t = tid; t < n_out; t += 512) {
+        if (p.silu_pair) {
+            const float* pg = part + (size_t)(2 * t) * 8;
+            float g = 0.0f, u = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { g += pg[w]; u += pg[8 + w]; }
+            p.seg[0].y[bid + t * nblk] = g / (1.0f + expf(-g)) * u;   // reference gemm.cu:719-724
+        } else {
+            const float* pg = part + (size_t)t * 8;
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += pg[w];
+            int r = bid + t * nblk, seg = 0;
+            while (seg + 1 < p.nseg && r >= p.seg[seg].rows) { r -= p.seg[seg].rows; ++seg; }
+            if (p.resid != nullptr && seg == 0) v = (t == tid ? res_pre : p.resid[r]) + v;   // reference elementwise.cu:23-32
+            p.seg[seg].y[r] = v;
+        }
+    }
+}

@@ -385,6 +385,8 @@ def test_experiments_library_matches_the_launch_path():
     assert "experiments ok" in r.stdout
     # the third experiment of that library: the LDS-DMA row ring of the K-quant GEMV (gemv.hip DMA form; no faster than the register
     # prefetch, profiles/r03_gemv_lds_dma_ring_experiment.txt) -- every GEMV parity test on it
+    # ... and the fourth, the column-split Q8_0 GEMV (gemv_colsplit.hip.h, NTK_GEMV_COLSPLIT=1; slower: profiles/r03_gemv_colsplit.txt)
+    env["NTK_GEMV_COLSPLIT"] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(os.path.dirname(__file__), "test_hip_kernels.py"), "-m", "gpu", "-q", "-x",
                         "-p", "no:cacheprovider", "-k", "gemv"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
