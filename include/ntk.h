@@ -248,6 +248,13 @@ int ntk_sample_top_k(float* logits, int n, const int* d_recent, int n_recent, fl
 /* the repeat penalty alone (greedy decoding with a penalty = this + ntk_argmax) */
 int ntk_repeat_penalty(float* logits, int n, const int* d_recent, int n_recent, float repeat_penalty, void* stream);
 
+/* The greedy tail of a decode token in two launches instead of three: ntk_argmax, then -- in the same final launch -- the token id to the
+ * pinned host ring h_ring4 (4 x 8 bytes, may be NULL): slot (*d_pos & 3) receives ONE 8-byte store {token, *d_pos + 1 in the high
+ * word}, and *d_pos += 1.  The ring lets a host loop keep the NEXT token's launches queued while it polls for this one (a token that
+ * runs one ahead lands in another slot), instead of synchronising the stream per token. */
+int ntk_argmax_advance(const float* logits, int n, int* d_out_token, int* h_mirror, unsigned long long* h_ring4, int* d_pos,
+                       float* scratch, void* stream);
+
 /* *d_pos += 1 (one thread); keeps positions on the device across graph replays */
 int ntk_advance_pos(int* d_pos, void* stream);
 

@@ -171,6 +171,33 @@ __global__ __launch_bounds__(256) void argmax_stage2(const float* __restrict__ s
 }
 __global__ void advance_pos_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
 
+// stage 2 of the greedy tail of a token (ntk_argmax_advance): final arg-max, the token to the device word and to the pinned host ring
+// -- slot (position & 3), ONE 8-byte store {token, position + 1}: the host can poll it while the next token's launches are already
+// queued, and a token that runs one ahead cannot overwrite what the host has not read yet -- and the position advanced, in one launch
+__global__ __launch_bounds__(256) void argmax_advance_stage2(const float* __restrict__ sv, const int* __restrict__ si, int nblk,
+                                                             int* __restrict__ d_out, int* __restrict__ h_mirror,
+                                                             unsigned long long* __restrict__ h_ring, int* __restrict__ d_pos) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    float v = -FLT_MAX;
+    int idx = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) amax_merge(v, idx, sv[i], si[i]);
+    for (int off = 32; off > 0; off >>= 1) amax_merge(v, idx, __shfl_xor(v, off, 64), __shfl_xor(idx, off, 64));
+    if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = v; ri[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax_merge(v, idx, rv[w], ri[w]);
+        if (idx == 0x7FFFFFFF) idx = 0;   // all NaN / empty: the reference returns 0
+        const int pos = *d_pos;
+        *d_out = idx;
+        if (h_mirror) *h_mirror = idx;
+        if (h_ring)
+            __hip_atomic_store(h_ring + (pos & 3), (unsigned long long)(unsigned)idx | ((unsigned long long)(unsigned)(pos + 1) << 32),
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *d_pos = pos + 1;
+    }
+}
+
 static inline dim3 g1(int n) { return dim3((n + 255) / 256); }
 
 }  // namespace ntk
@@ -270,6 +297,18 @@ int ntk_argmax(const float* logits, int n, int* d_out_token, int* h_mirror, floa
     hipStream_t st = resolve_stream(stream);
     hipLaunchKernelGGL(argmax_stage1, dim3(nblk), dim3(256), 0, st, logits, n, sv, si);
     hipLaunchKernelGGL(argmax_stage2, dim3(1), dim3(256), 0, st, (const float*)sv, (const int*)si, nblk, d_out_token, h_mirror);
+    return last_launch_status();
+}
+int ntk_argmax_advance(const float* logits, int n, int* d_out_token, int* h_mirror, unsigned long long* h_ring4, int* d_pos, float* scratch,
+                       void* stream) {
+    if (!logits || !d_out_token || !scratch || !d_pos) return NTK_E_NULL;
+    if (n <= 0) return NTK_E_SHAPE;
+    const int nblk = n < 256 * 8 ? 1 : (n / (256 * 8) < 1024 ? n / (256 * 8) : 1024);
+    float* sv = scratch;
+    int* si = reinterpret_cast<int*>(scratch + 1024);
+    hipStream_t st = resolve_stream(stream);
+    hipLaunchKernelGGL(argmax_stage1, dim3(nblk), dim3(256), 0, st, logits, n, sv, si);
+    hipLaunchKernelGGL(argmax_advance_stage2, dim3(1), dim3(256), 0, st, (const float*)sv, (const int*)si, nblk, d_out_token, h_mirror, h_ring4, d_pos);
     return last_launch_status();
 }
 int ntk_advance_pos(int* d_pos, void* stream) {

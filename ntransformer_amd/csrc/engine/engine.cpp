@@ -81,16 +81,26 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
         model_.set_device_pos(pos);
         model_.set_device_token(next);
     }
+    // Greedy decoding on the device keeps ONE step queued ahead of the token the host is waiting for: the token id feeds the next step
+    // on the device, so the next step's launches need nothing from the host, and the host's per-token work (poll, EOS check, detokenise,
+    // graph launch) overlaps the GPU's.  A step queued behind what turns out to be EOS is discarded (one KV row past the end, harmless).
+    int queued = 0;   // greedy steps launched and not yet consumed
     for (int i = 1; i < cfg.max_tokens; ++i) {
         if (stop_at_eos && next == eos) break;              // engine.cpp:106
         if (pos >= max_pos) { fprintf(stderr, "\n[context of %d tokens exhausted]\n", max_pos); break; }
         if (opt_.fused) {
-            rc = model_.decode_step_fused(dev_greedy, opt_.graph);
-            if (rc != NTK_OK) break;
             if (dev_greedy) {
-                if ((rc = model_.sync()) != NTK_OK) break;
-                next = model_.host_token();                 // first max, same as Sampler::argmax
-            } else if (dev_sample) {
+                if (queued == 0) { if ((rc = model_.decode_step_fused(true, opt_.graph)) != NTK_OK) break; ++queued; }
+                if (i + 1 < cfg.max_tokens && pos + 1 < max_pos) {   // the step after this one, before this one's token is known
+                    if ((rc = model_.decode_step_fused(true, opt_.graph)) != NTK_OK) break;
+                    ++queued;
+                }
+                if ((rc = model_.wait_token(pos, &next)) != NTK_OK) break;   // first max, same as Sampler::argmax
+                --queued;
+            } else {
+            rc = model_.decode_step_fused(false, opt_.graph);
+            if (rc != NTK_OK) break;
+            if (dev_sample) {
                 const int have = (int)tokens.size(), win = std::min(have, cfg.repeat_window);   // sampler.cpp:34
                 const float r = cfg.temperature > 0.0f ? sampler.draw() : 0.0f;                  // greedy takes no draw
                 rc = model_.sample_on_device(tokens.data() + have - win, win, cfg.repeat_penalty, cfg.temperature, cfg.top_k,
@@ -104,6 +114,7 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
                 next = sampler.sample(host.data(), V);
                 model_.set_device_token(next);
             }
+            }
         } else {
             logits = model_.forward(&next, 1, pos);          // engine.cpp:109
             if (!logits) { rc = NTK_E_LAUNCH; break; }
@@ -116,6 +127,7 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
         ++stats_.gen_tokens;
         if (!emit(next)) break;
     }
+    if (opt_.fused) { const int sr = model_.sync(); if (rc == NTK_OK) rc = sr; }   // (a discarded run-ahead step may still be in flight)
     stats_.decode_ms = ms_since(d0);
     if (rc == NTK_OK && opt_.fused) rc = model_.check_persistent();
     if (rc != NTK_OK) err_ = std::string("decode failed: ") + ntk_status_string(rc);
@@ -129,13 +141,20 @@ int Engine::decode_greedy_steps(int token, int pos, int n, int* out) {
     if (opt_.fused) {
         model_.set_device_pos(pos);
         model_.set_device_token(next);
+        // exactly n steps, one always queued ahead of the token the host is waiting for (see Engine::run); the host still sees every
+        // token, in order, as Engine::generate does
+        int launched = 0;
         for (int i = 0; i < n; ++i) {
-            int rc = model_.decode_step_fused(true, opt_.graph);
-            if (rc == NTK_OK) rc = model_.sync();            // the host sees every token, like Engine::generate
+            while (launched < n && launched <= i + 1) {
+                const int rc = model_.decode_step_fused(true, opt_.graph);
+                if (rc != NTK_OK) return rc;
+                ++launched;
+            }
+            const int rc = model_.wait_token(pos + i, &next);
             if (rc != NTK_OK) return rc;
-            next = model_.host_token();
             if (out) out[i] = next;
         }
+        { const int rc = model_.sync(); if (rc != NTK_OK) return rc; }
         return model_.check_persistent();   // a bounded in-kernel wait that gave up invalidates the run (and disables the path)
     }
     std::vector<float> host(model_.config().vocab_size);

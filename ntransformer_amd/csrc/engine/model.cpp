@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <thread>
 
 namespace nt {
@@ -53,6 +54,8 @@ void Model::free_all() {
     allocs_.clear();
     if (h_token_) nt_hip_free_host(h_token_);
     h_token_ = nullptr;
+    if (h_ring_) nt_hip_free_host(h_ring_);
+    h_ring_ = nullptr;
     if (h_recent_) nt_hip_free_host(h_recent_);
     h_recent_ = nullptr;
     sample_scratch_ = nullptr;
@@ -334,6 +337,8 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
     attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
+    h_ring_ = (unsigned long long*)nt_hip_malloc_host(64);
+    if (h_ring_) memset(h_ring_, 0, 64);
     sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
     attn_sync_ = (unsigned*)dev(4096, true);
     gemm_ws_bytes_ = ntk_gemm_quant_workspace_bytes(std::max(cfg_.hidden_size, cfg_.intermediate_size),   // (Q|K|V and gate|up go out as one launch)
@@ -351,7 +356,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_recent_ = (int*)dev(kRecentCap * 4, false);
     h_recent_ = (int*)nt_hip_malloc_host(kRecentCap * 4);
     if (!k_cache_ || !v_cache_ || !hidden_ || !residual_ || !logits_ || !workspace_ || !positions_ || !tokens_dev_ ||
-        !d_pos_ || !d_token_ || !argmax_scratch_ || !h_token_) {
+        !d_pos_ || !d_token_ || !argmax_scratch_ || !h_token_ || !h_ring_) {
         err_ = "buffer allocation failed";
         return NTK_E_NOMEM;
     }
@@ -535,7 +540,10 @@ int Model::set_device_pos(int pos) {
     // small copy, once per generation -- on the model's own stream: a blocking copy on the legacy stream would collide with a
     // hipGraph capture in progress on another thread's stream (tensor-parallel ranks sharing a process)
     NT_TRY(ntk_memcpy_h2d_async(d_pos_, &pos, 4, stream_));
-    return ntk_stream_synchronize(stream_);
+    NT_TRY(ntk_stream_synchronize(stream_));
+    // nothing is in flight: forget the tokens of earlier positions (a re-based position could otherwise match a stale {token, position} tag)
+    if (h_ring_) memset(h_ring_, 0, 64);
+    return NTK_OK;
 }
 int Model::sync() { return ntk_stream_synchronize(stream_); }
 int Model::host_token() const { return *h_token_; }
@@ -595,8 +603,8 @@ int Model::enqueue_token(bool greedy) {
 #ifdef NTK_EXPERIMENTS
     if (use_persistent_now()) {   // every layer and the LM head in one launch
         NT_TRY(ntk_persistent_launch(persistent_plan_, d_pos_, s));
-        if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
-        NT_TRY(ntk_advance_pos(d_pos_, s));
+        if (greedy) NT_TRY(ntk_argmax_advance(logits_, cfg_.vocab_size, d_token_, h_token_, h_ring_, d_pos_, argmax_scratch_, s));
+        else NT_TRY(ntk_advance_pos(d_pos_, s));
         return NTK_OK;
     }
 #endif
@@ -615,10 +623,35 @@ int Model::enqueue_token(bool greedy) {
         }
     }
     prof_mark(2, true);
-    if (greedy) NT_TRY(ntk_argmax(logits_, cfg_.vocab_size, d_token_, h_token_, argmax_scratch_, s));
-    NT_TRY(ntk_advance_pos(d_pos_, s));
+    // greedy: arg-max, token -> device word + pinned ring, position + 1 in ONE tail (ntk_argmax_advance); otherwise only the position
+    if (greedy) NT_TRY(ntk_argmax_advance(logits_, cfg_.vocab_size, d_token_, h_token_, h_ring_, d_pos_, argmax_scratch_, s));
+    else NT_TRY(ntk_advance_pos(d_pos_, s));
     if (tp_world_ > 1) NT_TRY(ntk_tp_advance_epoch(tp_comm_, s));
     prof_mark(2, false);
+    return NTK_OK;
+}
+
+// The token decoded at position `pos` by a greedy fused step, without synchronising the stream: the final launch of the step stores
+// {token, pos + 1} into slot (pos & 3) of the pinned ring; the host polls that word.  Meanwhile the NEXT step may already be queued (its
+// token lands in another slot), so the GPU never waits for the host between tokens (Engine::run / decode_greedy_steps keep one step
+// ahead).  A poll that sees nothing for 2 s falls back to a stream synchronisation and reports what that returns.
+int Model::wait_token(int pos, int* token) {
+    volatile unsigned long long* slot = h_ring_ + (pos & 3);
+    const unsigned want = (unsigned)(pos + 1);
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long v = *slot;
+        if ((unsigned)(v >> 32) == want) { *token = (int)(unsigned)v; return NTK_OK; }
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFu) == 0xFFFFu) {
+            const auto now = std::chrono::steady_clock::now();
+            if (spins == 0xFFFFu) wait_t0_ = now;
+            else if (std::chrono::duration<double>(now - wait_t0_).count() > 2.0) break;
+        }
+    }
+    NT_TRY(ntk_stream_synchronize(stream_));
+    const unsigned long long v = *slot;
+    if ((unsigned)(v >> 32) != want) { err_ = "decode step finished without publishing its token"; return NTK_E_LAUNCH; }
+    *token = (int)(unsigned)v;
     return NTK_OK;
 }
 

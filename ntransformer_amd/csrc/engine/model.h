@@ -4,6 +4,7 @@
 // FFN::forward, RMSNorm::forward).  The reference's streaming / tiered / delta / speculative paths exist
 // to fit 24 GB of VRAM and are dropped: 288 GB of HBM holds every target model resident.
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -56,6 +57,9 @@ public:
     void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)
+    // token of the greedy fused step that decoded position `pos`, polled from the pinned ring without a stream synchronisation (the
+    // caller may already have queued the next step)
+    int wait_token(int pos, int* token);
     float* logits_ptr() { return logits_; }
     int copy_logits(float* host);           // D2H of [vocab] floats (blocking)
     // Sample the next token from the device logits with the reference's sampler (ntk_sample_top_k / penalty + ntk_argmax when
@@ -150,6 +154,8 @@ private:
     int* d_pos_ = nullptr;          // device scalar: position of the token being decoded
     int* d_token_ = nullptr;        // device scalar: id of the token being decoded
     int* h_token_ = nullptr;        // pinned mirror of the argmax result
+    unsigned long long* h_ring_ = nullptr;   // pinned ring of 4 x {token, position + 1}: ntk_argmax_advance / wait_token
+    std::chrono::steady_clock::time_point wait_t0_;
     float* argmax_scratch_ = nullptr;
     void* sample_scratch_ = nullptr;
     int* d_recent_ = nullptr;       // device copy of the repeat-penalty window
