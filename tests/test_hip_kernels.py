@@ -406,9 +406,11 @@ def test_gemv_fused_residual_in_place(qname, in_f, out_f):
     assert np.abs(hd.numpy() - ref).max() <= tol_for(ref, in_f)
 
 
-@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q4_0"])
-@pytest.mark.parametrize("in_f,inter", [(256, 512), (4096, 1792), (8192, 515)])
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q4_0", "Q6_K"])
+@pytest.mark.parametrize("in_f,inter", [(256, 512), (4096, 1792), (8192, 515), (4096, 6144), (4096, 14336)])
 def test_gemv_fused_norm_gate_up_silu(qname, in_f, inter):
+    """(4096, 6144) and the real 8B shape (4096, 14336): half the waves of the launch get one gate / up pair more than the others;
+    also through the integer-activation decoders."""
     gt, dt = QUANT[qname], G.GGML_TO_DT[QUANT[qname]]
     r = rng(in_f + inter + gt)
     x = r.standard_normal(in_f).astype(np.float32)
@@ -422,6 +424,17 @@ def test_gemv_fused_norm_gate_up_silu(qname, in_f, inter):
     ops.gemv_fused([(gd, od, inter, dt), (ud, scratch, inter, dt)], xd, in_f, norm_w=nd, eps=1e-5, silu_pair=True)
     ops.synchronize()
     assert np.abs(od.numpy() - ref).max() <= 4 * tol_for(ref, in_f)
+    if qname in ("Q4_K", "Q6_K") and inter >= 6144:   # ... and through the integer-activation decoders (every eligible launch)
+        from ntransformer_amd import _lib
+        L = _lib.lib()
+        L.ntk_gemv_tune_xi_min_bytes(0)
+        try:
+            od2 = DB.from_numpy(np.full(inter, np.nan, np.float32))
+            ops.gemv_fused([(gd, od2, inter, dt), (ud, scratch, inter, dt)], xd, in_f, norm_w=nd, eps=1e-5, silu_pair=True)
+            ops.synchronize()
+        finally:
+            L.ntk_gemv_tune_xi_min_bytes(48 << 20)
+        assert np.abs(od2.numpy() - ref).max() <= 4 * tol_for(ref, in_f)
 
 
 # ------------------------------------------------------------------------------- norm / rope / kv / attention
