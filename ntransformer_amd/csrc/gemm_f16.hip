@@ -1,0 +1,843 @@
+// gemm_f16.hip -- batched prompt projections on the FP16 matrix cores, 64 tokens per pass over the weights.
+//
+// Replaces the reference's prefill, which runs launch_gemv once per prompt token and matrix
+// (reference src/model/attention.cpp:144-162,200-210, src/model/ffn.cpp:96-133), and supersedes gemm_prefill.hip's F32-MFMA
+// form (16 tokens per pass, 29-65 TFLOP/s of the 157 TFLOP/s F32 matrix rate) for the formats of the target models.
+//
+// Arithmetic -- exact products, F32 accumulation, activations within one F32 ulp of the reference's:
+//   * a GGUF weight is (integer) x (scale): the INTEGER part (Q8_0: -128..127, Q4_K: 0..15, Q6_K: -32..31) is exact in FP16;
+//   * an F32 activation x is scaled by a power of two s -- one per token, chosen so that the token's largest |x| s lies in
+//     [2^14, 2^15) -- and split into TWO FP16 pieces: h1 = rn16(x s), h2 = rn16(x s - h1).  The difference is exact in F32 (13
+//     significant bits), so |x s - h1 - h2| <= 2^-23 |x s| -- one F32 ulp of the activation -- for every x within 2^-17 of the
+//     token's largest, and <= 2^-25 / s (2^-39 of the largest) below that, where h2 is an FP16 subnormal (2^-28 of the largest if
+//     the matrix cores flush it) -- against the 2^-24 every F32 addition of the reference's own accumulation (gemm.cu:129-141)
+//     rounds by.  Round 2 used three BF16 pieces (8 + 8 + 8 bits, nothing rounded at all): one third more matrix instructions
+//     and operand traffic for that last ulp;
+//   * sum_k q_k x_k over a 32-column block = two v_mfma_f32_16x16x32_f16 whose FP16 x FP16 products are exact in the F32
+//     accumulator; the per-block scale (FP16 d, 6-bit K-quant sub-scales, Q6_K's int8 sub-scales per 16 columns) multiplies
+//     the F32 block sum afterwards, the K-quant minimum enters as -dmin*m * s sum_k x_k, and 1 / s multiplies the finished sum
+//     (powers of two: exact) -- the same factorisation as reference gemm.cu:129-141, 190-244, 421-459.
+//
+// Decomposition (gfx950, wave64):
+//   * pre-pass (row_scale_kernel, split_x_kernel): the tokens' scales; X[T,in] F32 -> two FP16 planes in MFMA operand order,
+//     1 KiB per (32-column step, plane, 16-token block), plus per (step, token) the sum of x s (K-quant minimum); written once
+//     per distinct X, read from L2 by every workgroup;
+//   * main kernel: workgroup = 4 waves, wave = 16*RT output rows x 64 tokens (RT*4 accumulator tiles of 16x16); the operand
+//     planes of a step (8 KB) reach a 4-slot LDS ring by LDS-DMA and are read by the 4 waves ONE STEP AHEAD of the MFMAs that
+//     use them (a second register set: the matrix instructions never wait for the LDS pipe); the raw GGUF rows travel
+//     HBM -> registers -> a per-wave LDS image in units of whole blocks and are decoded per step into FP16 integers;
+//   * MFMA operand slots: lane (i = lane % 16, g = lane / 16) holds columns {4g..4g+3} and {16+4g..16+4g+3} of the 32-column
+//     step for row / token i -- the same permutation on both operands, so the dot product is unchanged, and the two halves are
+//     the two 16-column sub-scale groups of Q6_K (which uses two K = 16 MFMAs per step).
+// Bound: MFMA (FP16 dense 2.5 PFLOP/s, two products per weight-token pair), the LDS reads of the activation planes co-critical.
+#include "common.hip.h"
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+namespace ntk {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GB_TOK = 64;           // tokens per pass
+constexpr int GB_MAX_SPLIT = 8;     // K splits x token chunks of one launch never exceed this (size of the partial-sum area)
+constexpr int GB_MAX_CHUNKS = 16;   // 64-token chunks per launch (32 measured no better: 15.1k vs 16.0k tok/s at 2048 tokens)
+constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
+constexpr int GB_PLANES = 2;         // FP16 pieces of an activation
+constexpr int GB_STEP_BYTES = GB_PLANES * 4 * GB_PIECE;   // 8 KB of activation operands per step
+constexpr int GB_AUX_BYTES = GB_TOK * 4;                  // per step: the 64 tokens' sums of x s (K-quant minimum term)
+
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {   // two small integers -> FP16 pair (exact)
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+typedef uint32_t __attribute__((aligned(2))) u32_a2;
+typedef uint16_t __attribute__((aligned(2))) u16_a2;
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const u32_a2*>(p); }   // 2-byte aligned global dword
+__device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return *reinterpret_cast<const u16_a2*>(p); }
+
+// ---- pre-pass 1: the tokens' scales --------------------------------------------------------------------------------------------
+// s = 2^(14 - floor(log2 m)), m = the token's largest |x|: m s in [2^14, 2^15) -- FP16's largest binade but one.  Exponent fields are
+// kept inside [1, 253] so that both s and 1 / s are normal numbers (an all-zero or subnormal token multiplies to zero either way; a
+// token holding Inf / NaN propagates it through the first piece).  grid = ceil(T / 4), block = 256: one wave per token.
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ X, int T, int in, float* __restrict__ scale, float* __restrict__ inv) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    const float4* row = reinterpret_cast<const float4*>(X + (size_t)t * in);
+    float m = 0.0f;
+    for (int c = lane; c < in / 4; c += 64) {
+        const float4 v = row[c];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    uint32_t mb = __float_as_uint(m);
+    if (m != m) mb = 0x7F800000u;   // (fmaxf drops NaNs: a NaN anywhere in the row is found by the planes, any scale will do)
+    const int em = (int)((mb >> 23) & 0xFFu);
+    const int es = min(253, max(1, 268 - em));
+    if (lane == 0) {
+        scale[t] = __uint_as_float((uint32_t)es << 23);
+        inv[t] = __uint_as_float((uint32_t)(254 - es) << 23);
+    }
+}
+
+// ---- pre-pass 2: X -> FP16 planes in operand order + per-step sums ---------------------------------------------------------------
+// grid = (in / 32 steps + 1 (a record of zeros), 64-token chunks), block = 256 = 4 token blocks x 64 lanes
+__global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ X, int T, int in, u32x4* __restrict__ xb, float* __restrict__ aux,
+                                                      size_t chunk_bytes, const float* __restrict__ scale) {
+    const int step = blockIdx.x, tb = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 15, g = lane >> 4, t = tb * 16 + j;
+    // blockIdx.y = 64-token chunk: its tokens, its planes
+    X += (size_t)blockIdx.y * GB_TOK * in;
+    scale += (size_t)blockIdx.y * GB_TOK;
+    T = min(GB_TOK, T - (int)blockIdx.y * GB_TOK);
+    xb = reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(xb) + blockIdx.y * chunk_bytes);
+    aux = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(aux) + blockIdx.y * chunk_bytes);
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+    float sc = 1.0f;
+    if (t < T && step * 32 < in) {   // block in/32 writes the all-zero record that K ranges rounded up to whole trips read
+        const float* row = X + (size_t)t * in + step * 32 + 4 * g;
+        const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 16);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        sc = scale[t];
+    }
+    float p1[8], p2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {   // h1 = rn16(x s); the remainder is exact in F32 (13 significant bits) and h2 = rn16(remainder)
+        x[e] *= sc;
+        const _Float16 h1 = (_Float16)x[e];
+        p1[e] = (float)h1;
+        p2[e] = x[e] - p1[e];
+    }
+    auto pk = [](float lo, float hi) {   // round-to-nearest conversions (p1 is already an FP16 value: exact)
+        const f16x2 h = {(_Float16)lo, (_Float16)hi};
+        return __builtin_bit_cast(uint32_t, h);
+    };
+    const size_t base = ((size_t)step * GB_PLANES * 4 + tb) * 64 + lane;   // plane p at + p * 4 * 64
+    xb[base] = u32x4{pk(p1[0], p1[1]), pk(p1[2], p1[3]), pk(p1[4], p1[5]), pk(p1[6], p1[7])};
+    xb[base + 256] = u32x4{pk(p2[0], p2[1]), pk(p2[2], p2[3]), pk(p2[4], p2[5]), pk(p2[6], p2[7])};
+    // sum of the step's 32 scaled activations of token t (fixed order: the lane's 8 in sequence, then the 4 column groups)
+    float sum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    if (g == 0) aux[(size_t)step * GB_TOK + t] = sum;
+}
+
+// ---- per-format weight operand ---------------------------------------------------------------------------------------------
+// The raw GGUF rows travel HBM -> registers -> a per-wave LDS image in UNITS of whole blocks (Q8_0: 4 blocks = 136 B, K-quants:
+// one 256-column super-block), as 16-byte pieces of the 16-byte-aligned window that covers the unit: 16 bytes per lane and
+// NCH consecutive lanes per row, i.e. >= 144 contiguous bytes per row and request (a lane-per-slot gather of 4-byte pieces,
+// 16 bytes per row and request, tops out near 2.4 TB/s in the address coalescer).  Each 32-column step then reads its slot
+// (row i, columns {4g..4g+3, 16+4g..16+4g+3}) out of the image with 2-byte-aligned LDS dword reads.  STRIDE (bytes between row
+// images) = 4 x an odd number of dwords... chosen so that the 16 rows x 4 column groups of one read hit 64 different banks.
+struct AOp {
+    u32x4 a;            // 8 FP16 integers
+    float s0, s1;       // scale of the slot's low / high 4 columns (equal unless the format scales per 16 columns)
+    float mn;           // K-quant minimum term factor (dmin * m), 0 otherwise
+};
+template <bool AL> __device__ __forceinline__ uint32_t lds32(const uint8_t* p) {   // LDS dword: 4-byte aligned (AL) or 2-byte aligned (slow)
+    if constexpr (AL) return *reinterpret_cast<const uint32_t*>(p);
+    else return *reinterpret_cast<const u32_a2*>(p);
+}
+__device__ __forceinline__ uint32_t lds16(const uint8_t* p) { return *reinterpret_cast<const u16_a2*>(p); }
+// bytes [2, 6) of the 8 bytes (lo, hi): the dword that sits 2 bytes past a 4-byte boundary.  (A misaligned ds_read_b32 works and
+// costs several hundred cycles per wave-instruction -- the step timeline of round 3, profiles/r03_prompt_gemm_f16.txt -- so
+// every LDS dword read of the decoders is aligned and the misaligned ones are two aligned dwords + one v_alignbyte.)
+__device__ __forceinline__ uint32_t mid32(uint32_t lo, uint32_t hi) { return __builtin_amdgcn_alignbyte(hi, lo, 2u); }
+template <int DT> struct DeqI;
+
+// A step's weight operand is made in two stages one step apart, so that no VALU instruction inside a step's MFMA chain waits for an
+// LDS read of the same step: load() -- the slot's raw dwords out of the wave's image (and whatever needs the unit's header, which
+// changes a step before the unit's last operand is converted) -- runs two steps ahead of the MFMAs, convert() one step ahead.
+// j = step within the unit, k = parity of the unit (both compile-time after unrolling).  row = the row's image + the unit's
+// shift (4-byte aligned: the launch checks the row pitch), rowg = row + 4 g.
+
+template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
+    static constexpr int BW = 32, BB = 34;
+    static constexpr int SPU = 4, UB = 136, NCH = 10, STRIDE = 176;   // window: shift (0, 4, 8 or 12) + 136 <= 160
+    static constexpr int ROW_ALIGN = 4;                               // row pitch: in_features a multiple of 64
+    static constexpr int NRING = 2;                                   // units in flight per wave (register ring): 8 steps ahead of the MFMAs
+    static constexpr bool SPLIT16 = false, HAS_MIN = false, PF = true;
+    struct Hdr {};
+    struct Raw { uint32_t w0, w1, w2, w3, d; };
+    __device__ static Hdr header(const uint8_t*, const uint8_t*) { return Hdr{}; }
+    template <bool AL> __device__ static Raw load(const uint8_t* row, const uint8_t* rowg, const Hdr&, int j, int) {
+        Raw r;   // the block's quants start 34 j + 2 bytes into the unit: on a dword boundary for odd j, 2 bytes past one for even j
+        if (!AL || (j & 1)) { r.w0 = lds32<AL>(rowg + 34 * j + 2); r.w2 = lds32<AL>(rowg + 34 * j + 18); r.w1 = r.w3 = 0; }
+        else { r.w0 = lds32<AL>(rowg + 34 * j); r.w1 = lds32<AL>(rowg + 34 * j + 4); r.w2 = lds32<AL>(rowg + 34 * j + 16); r.w3 = lds32<AL>(rowg + 34 * j + 20); }
+        r.d = lds16(row + 34 * j);
+        return r;
+    }
+    template <bool AL> __device__ static AOp convert(const Raw& r, int j, int) {
+        const bool whole = !AL || (j & 1);
+        const uint32_t lo = whole ? r.w0 : mid32(r.w0, r.w1), hi = whole ? r.w2 : mid32(r.w2, r.w3);
+        AOp o;
+        o.a = u32x4{pack_f16(sb2f(lo, 0), sb2f(lo, 1)), pack_f16(sb2f(lo, 2), sb2f(lo, 3)),
+                    pack_f16(sb2f(hi, 0), sb2f(hi, 1)), pack_f16(sb2f(hi, 2), sb2f(hi, 3))};
+        o.s0 = o.s1 = h2f((uint16_t)r.d);
+        o.mn = 0.0f;
+        return o;
+    }
+};
+
+template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 packed 6-bit (scale, min); 128 bytes of nibbles
+    static constexpr int BW = 256, BB = 144;
+    static constexpr int SPU = 8, UB = 144, NCH = 9, STRIDE = 144;     // rows are 16-byte aligned: no shift
+    static constexpr int ROW_ALIGN = 16, NRING = 1;
+    static constexpr bool SPLIT16 = false, HAS_MIN = true, PF = true;
+    struct Hdr { u32x4 h; };   // d | dmin, 12 scale bytes
+    struct Raw { uint32_t lo, hi; float s0, mn; };
+    __device__ static Hdr header(const uint8_t* row, const uint8_t*) { return Hdr{*reinterpret_cast<const u32x4*>(row)}; }
+    template <bool AL> __device__ static Raw load(const uint8_t*, const uint8_t* rowg, const Hdr& hd, int j, int) {
+        float sc, mn;
+        kq_scale_min(hd.h.y, hd.h.z, hd.h.w, j, sc, mn);                       // gemm.cu:206-222
+        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu)), dmin = h2f((uint16_t)(hd.h.x >> 16));
+        return Raw{lds32<true>(rowg + 16 + 32 * (j >> 1)), lds32<true>(rowg + 32 + 32 * (j >> 1)), d * sc, dmin * mn};
+    }
+    template <bool AL> __device__ static AOp convert(const Raw& r, int j, int) {
+        const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
+        const uint32_t lo = (r.lo >> sh) & 0x0F0F0F0Fu, hi = (r.hi >> sh) & 0x0F0F0F0Fu;
+        AOp o;
+        o.a = u32x4{pack_f16(ub2f(lo, 0), ub2f(lo, 1)), pack_f16(ub2f(lo, 2), ub2f(lo, 3)),
+                    pack_f16(ub2f(hi, 0), ub2f(hi, 1)), pack_f16(ub2f(hi, 2), ub2f(hi, 3))};
+        o.s0 = o.s1 = r.s0;
+        o.mn = r.mn;
+        return o;
+    }
+};
+
+template <> struct DeqI<NTK_DT_Q5_K> {   // types.h:122-128: half d, dmin; 12 packed 6-bit (scale, min); qh[32]; ql[128]
+    static constexpr int BW = 256, BB = 176;
+    static constexpr int SPU = 8, UB = 176, NCH = 11, STRIDE = 176;    // rows are 16-byte aligned: no shift
+    static constexpr int ROW_ALIGN = 16, NRING = 1;
+    static constexpr bool SPLIT16 = false, HAS_MIN = true, PF = true;
+    struct Hdr { u32x4 h; uint32_t qh_lo, qh_hi; };   // d | dmin, 12 scale bytes; the lane's 8 bytes of fifth bits (all 8 steps)
+    struct Raw { uint32_t lo, hi, b5lo, b5hi; float s0, mn; };
+    __device__ static Hdr header(const uint8_t* row, const uint8_t* rowg) { return Hdr{*reinterpret_cast<const u32x4*>(row), lds32<true>(rowg + 16), lds32<true>(rowg + 32)}; }
+    template <bool AL> __device__ static Raw load(const uint8_t*, const uint8_t* rowg, const Hdr& hd, int j, int) {
+        float sc, mn;
+        kq_scale_min(hd.h.y, hd.h.z, hd.h.w, j, sc, mn);                       // gemm.cu:206-222 (same packing as Q4_K)
+        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu)), dmin = h2f((uint16_t)(hd.h.x >> 16));
+        // fifth bit of column l of sub-block j: bit j of qh[l]   (gemm.cu:297-354: u1 = 1 << 2c, u2 = 2 << 2c)
+        return Raw{lds32<true>(rowg + 48 + 32 * (j >> 1)), lds32<true>(rowg + 64 + 32 * (j >> 1)), ((hd.qh_lo >> j) & 0x01010101u) << 4, ((hd.qh_hi >> j) & 0x01010101u) << 4,
+                   d * sc, dmin * mn};
+    }
+    template <bool AL> __device__ static AOp convert(const Raw& r, int j, int) {
+        const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
+        const uint32_t lo = ((r.lo >> sh) & 0x0F0F0F0Fu) | r.b5lo, hi = ((r.hi >> sh) & 0x0F0F0F0Fu) | r.b5hi;
+        AOp o;
+        o.a = u32x4{pack_f16(ub2f(lo, 0), ub2f(lo, 1)), pack_f16(ub2f(lo, 2), ub2f(lo, 3)),
+                    pack_f16(ub2f(hi, 0), ub2f(hi, 1)), pack_f16(ub2f(hi, 2), ub2f(hi, 3))};
+        o.s0 = o.s1 = r.s0;
+        o.mn = r.mn;
+        return o;
+    }
+};
+
+template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], int8 scales[16], half d
+    static constexpr int BW = 256, BB = 210;
+    static constexpr int SPU = 8, UB = 210, NCH = 14, STRIDE = 240;    // window: shift (even, <= 14) + 210 <= 224
+    static constexpr int ROW_ALIGN = 4, NRING = 1;                     // row pitch: in_features a multiple of 512
+    static constexpr bool SPLIT16 = true, HAS_MIN = false, PF = false;   // (PF: 23 registers over the 256 of two waves per SIMD)
+    struct Hdr { float d; };
+    struct Raw { uint32_t ql0, ql1, ql2, ql3, qh0, qh1, qh2, qh3, sc; float d; };
+    __device__ static Hdr header(const uint8_t* row, const uint8_t*) { return Hdr{h2f((uint16_t)lds16(row + 208))}; }
+    // blocks are 210 bytes: with a 4-byte aligned row, the units of even parity start on a dword boundary and those of odd
+    // parity 2 bytes past one (k = the unit's parity: K ranges start at even units) -- `row` is the 4-byte aligned address at or
+    // 2 bytes below the unit's first byte
+    // (!AL: any row pitch -- `row` is the unit's first byte and the dword reads are 2-byte aligned)
+    template <bool AL> __device__ static Raw load(const uint8_t* row, const uint8_t* rowg, const Hdr& hd, int j, int k) {
+        if (!AL) k = 0;
+        const int hf = j >> 2, t = j & 3;
+        const uint8_t* ql = rowg + 64 * hf + 32 * (t & 1);
+        const uint8_t* qh = rowg + 128 + 32 * hf;
+        Raw r;
+        r.ql0 = lds32<AL>(ql); r.ql2 = lds32<AL>(ql + 16); r.qh0 = lds32<AL>(qh); r.qh2 = lds32<AL>(qh + 16);
+        if (k) { r.ql1 = lds32<AL>(ql + 4); r.ql3 = lds32<AL>(ql + 20); r.qh1 = lds32<AL>(qh + 4); r.qh3 = lds32<AL>(qh + 20); }
+        else r.ql1 = r.ql3 = r.qh1 = r.qh3 = 0;
+        r.sc = lds16(row + 2 * k + 192 + 8 * hf + 2 * t);   // the two int8 sub-scales of the step's 16-column halves
+        r.d = hd.d;
+        return r;
+    }
+    template <bool AL> __device__ static AOp convert(const Raw& r, int j, int k) {
+        if (!AL) k = 0;
+        const int t = j & 3;
+        const int sl = 4 * (t >> 1), sh = 2 * t;
+        const uint32_t ql_lo = k ? mid32(r.ql0, r.ql1) : r.ql0, ql_hi = k ? mid32(r.ql2, r.ql3) : r.ql2;
+        const uint32_t qh_lo = k ? mid32(r.qh0, r.qh1) : r.qh0, qh_hi = k ? mid32(r.qh2, r.qh3) : r.qh2;
+        const uint32_t lo = ((ql_lo >> sl) & 0x0F0F0F0Fu) | (((qh_lo >> sh) & 0x03030303u) << 4);         // gemm.cu:421-459
+        const uint32_t hi = ((ql_hi >> sl) & 0x0F0F0F0Fu) | (((qh_hi >> sh) & 0x03030303u) << 4);
+        AOp o;   // q - 32: exact small integers
+        o.a = u32x4{pack_f16(ub2f(lo, 0) - 32.0f, ub2f(lo, 1) - 32.0f), pack_f16(ub2f(lo, 2) - 32.0f, ub2f(lo, 3) - 32.0f),
+                    pack_f16(ub2f(hi, 0) - 32.0f, ub2f(hi, 1) - 32.0f), pack_f16(ub2f(hi, 2) - 32.0f, ub2f(hi, 3) - 32.0f)};
+        o.s0 = r.d * (float)(int)(int8_t)(r.sc & 0xFF);
+        o.s1 = r.d * (float)(int)(int8_t)(r.sc >> 8);
+        o.mn = 0.0f;
+        return o;
+    }
+};
+
+// Step timeline (tuning builds only: make trace): lane 0 of every wave of workgroup 0 records the shader clock before the step's
+// wait, after its barrier and (level 2) once the step's LDS reads have returned; read back with ntk_debug_gemm_f16_trace(),
+// printed by tools/gemm_f16_trace.py.  The stamps sit in LDS (a global store would join the vmcnt arithmetic).
+#ifdef NTK_GEMM_TRACE
+constexpr int GBT_STEPS = 96, GBT_EV = 3;
+__device__ unsigned long long g_gemm_f16_trace[4][GBT_STEPS][GBT_EV];
+constexpr int GB_TRACE_LDS = 4 * GBT_STEPS * GBT_EV * 8;
+#define GB_STAMP(step, ev) do { if (gbt_on && (step) < GBT_STEPS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if (lane == 0) gbt[((size_t)wave * GBT_STEPS + (step)) * GBT_EV + (ev)] = t_; } } while (0)
+#else
+constexpr int GB_TRACE_LDS = 0;
+#define GB_STAMP(step, ev) do {} while (0)
+#endif
+
+constexpr int GB_UPT = 2;     // units per loop trip (Q6_K: the parity of a unit, which decides its alignment, is then a compile-time constant)
+constexpr int GB_SLOTS = 4;   // LDS ring of activation step records (8 KB each), filled by LDS-DMA GB_SLOTS - 1 steps ahead
+constexpr int GB_XS_OFF = GB_SLOTS * GB_STEP_BYTES;   // then [GB_SLOTS][128] floats: the steps' per-token sums of x and inverse scales
+constexpr int GB_STAGE_OFF = GB_XS_OFF + GB_SLOTS * GB_AUX_BYTES;   // then the 4 waves' weight images
+template <int DT, int RT> constexpr int gb_lds_bytes() { return GB_STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS; }
+
+constexpr int GB_MAX_SEG = 3;   // matrices sharing X in one launch (Q | K | V, gate | up)
+struct GemmBSeg {
+    const uint8_t* W;
+    float* Y;               // [T][out]
+    float* part;            // K split: [split][T][out] partial sums of this matrix
+    int out, tile0;         // rows; first row tile of this matrix in the launch's tile numbering
+    unsigned w_last;        // out * row_bytes - 16: the last 16-byte piece of the matrix (requests past the end re-read it)
+};
+struct GemmBParams {
+    GemmBSeg seg[GB_MAX_SEG];
+    int nseg;
+    const uint8_t* xb;      // operand planes [steps + 1][2][4][64] x 16 B
+    const float* aux;       // [steps + 1][64]: sums of x s (K-quant minimum term)
+    const float* inv;       // [T]: 1 / s of the launch's tokens
+    const float* resid;     // optional [T][out] (single matrix only), may alias Y
+    int T, in, steps;       // T = tokens of the launch (<= 16 chunks of 64)
+    unsigned row_bytes;
+    int nsplit, steps_per_split;   // blockIdx.y = K split; nsplit > 1: partial sums go to seg.part, summed by reduce_splits
+    int chunks, row_wgs;    // 64-token chunks of this launch (blockIdx.x enumerates (row tile, chunk), see below); row tiles of all matrices
+    size_t chunk_bytes;     // between the planes (and sums) of consecutive chunks
+};
+
+// 16 B per lane, global -> LDS without passing through registers (gfx950 LDS-DMA, b128 form): lane l's 16 bytes land at
+// M0 + imm + 16 l, read from gsrc + imm.  The compiler does not count these requests: the waits on them are explicit (vmcnt).
+__device__ __forceinline__ void gb_dma16(uint32_t lds_dst, const uint8_t* gsrc) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void gb_dma16x2(uint32_t lds_dst, const uint8_t* gsrc) {   // 2 KB per wave: +0, +1024 on both sides
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// block = 256 threads = 4 waves; wave w of workgroup b owns weight rows (4 b + w) * 16 RT ... + 16 RT and all 64 tokens.
+// MFMA roles: the activation planes are the A operand (M = 16 tokens), the weights the B operand (N = 16 weight rows), so the
+// accumulator of lane (i, g) holds weight row i for tokens 4 g + e -- the row's scale is the one this lane decoded (no
+// cross-lane traffic), and the step's sums of x / inverse scales come as float4s from LDS.
+// One loop trip = GB_UPT units of SPU steps, straight-line (no exits inside: the s_waitcnt counts are exact).  Per step s:
+//   wait until the DMA of step s + 1 has landed | barrier | at a unit's last step: the next unit's raw rows go from their ring
+//   registers to the wave's LDS image and the ring slot is re-requested NRING units ahead | DMA step s + GB_SLOTS - 1 into the slot
+//   whose planes were consumed a step ago | read + decode the next step's weight slot, read the next step's activation planes into
+//   the second register set (PF; without it: this step's planes, ahead of its own MFMAs) | 8 RT MFMAs | scale-FMAs.
+template <int DT, int RT, bool PF, bool AL>
+__global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParams p) {
+    using D = DeqI<DT>;
+    constexpr int SPU = D::SPU, NCH = D::NCH, STRIDE = D::STRIDE;
+    constexpr int ROWS = 16 * RT, PIECES = ROWS * NCH, NLD = (PIECES + 63) / 64;   // 16-byte pieces of a unit; requests per lane
+    constexpr int NRING = D::NRING;
+    static_assert((GB_UPT * SPU) % GB_SLOTS == 0 && GB_UPT % NRING == 0, "a trip must cover whole turns of the activation ring and of the weight ring");
+    extern __shared__ __attribute__((aligned(16))) uint8_t gb_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    // blockIdx.x -> (row tile, token chunk).  Workgroups go to the 8 XCDs round-robin; the `chunks` workgroups that share a row
+    // tile's weights get ids 8 apart (same XCD, same L2, dispatched back to back): id = 8 * (chunks * (tile / 8) + chunk) + tile % 8
+    const int bid = (int)blockIdx.x;
+    const int xcd = bid & 7, within = bid >> 3;
+    const int chunk = within % p.chunks, tile = (within / p.chunks) * 8 + xcd;
+    if (tile >= p.row_wgs) return;   // row tiles are padded to a multiple of 8
+#ifdef NTK_GEMM_TRACE
+    unsigned long long* gbt = reinterpret_cast<unsigned long long*>(gb_lds + GB_STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE);
+    const bool gbt_on = bid == 0 && blockIdx.y == 0;
+    if (gbt_on) for (int q = tid; q < 4 * GBT_STEPS * GBT_EV; q += 256) gbt[q] = 0;
+#endif
+    // which matrix of the launch this row tile belongs to (workgroup-uniform)
+    int sidx = 0;
+    if (p.nseg > 1 && tile >= p.seg[1].tile0) sidx = 1;
+    if (p.nseg > 2 && tile >= p.seg[2].tile0) sidx = 2;
+    const uint8_t* const segW = p.seg[sidx].W;
+    float* const segY = p.seg[sidx].Y;
+    float* const segPart = p.seg[sidx].part;
+    const int seg_out = p.seg[sidx].out;
+    const unsigned seg_w_last = p.seg[sidx].w_last;
+    const int Tc = min(GB_TOK, p.T - chunk * GB_TOK);
+    const int row0 = ((tile - p.seg[sidx].tile0) * 4 + wave) * ROWS;
+    f32x4 acc[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) acc[rt][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // this workgroup's K range (split-K: blockIdx.y), in steps of 32 columns; whole trips of GB_UPT * SPU steps
+    const int step_lo = (int)blockIdx.y * p.steps_per_split, step_hi = min(p.steps, step_lo + p.steps_per_split);
+    const int nsteps = step_hi - step_lo;
+    const int unit_lo = step_lo / SPU, nunits = (nsteps + SPU - 1) / SPU;
+
+    // weight pieces of this lane: piece q = 64 n + lane of the wave's unit -> row q / NCH, 16-byte piece q % NCH of the 16-byte
+    // aligned window that covers the row's unit (rows need not be 16-byte aligned: every row has its own window start and shift)
+    uint8_t* stage = gb_lds + GB_STAGE_OFF + (size_t)wave * (ROWS * STRIDE);
+    uint32_t w_row[NLD], s_pk[NLD];   // s_pk: offset of the piece in the wave's image | 16 c << 16 (unpacked once per unit: registers are the scarcer resource)
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+        const int q = min(64 * n + lane, PIECES - 1), r = q / NCH, c = q - r * NCH;
+        w_row[n] = (uint32_t)min(row0 + r, seg_out - 1) * p.row_bytes;
+        s_pk[n] = (uint32_t)(r * STRIDE + 16 * c) | ((uint32_t)(16 * c) << 16);
+    }
+    u32x4 ring[NRING][NLD];
+    auto load_unit = [&](int k, int urel) {   // unit `urel` of this split (past the end: the last one again, multiplied by zeros)
+        const uint32_t uoff = (uint32_t)(unit_lo + min(urel, nunits - 1)) * D::UB;
+#pragma unroll
+        for (int n = 0; n < NLD; ++n)
+            ring[k][n] = *reinterpret_cast<const u32x4*>(segW + min(((w_row[n] + uoff) & ~15u) + (s_pk[n] >> 16), seg_w_last));
+    };
+    auto stage_unit = [&](int k) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) *reinterpret_cast<u32x4*>(stage + (s_pk[n] & 0xFFFFu)) = ring[k][n];
+    };
+
+    const uint32_t lds0 = (uint32_t)(uintptr_t)gb_lds;   // generic -> LDS address: the low 32 bits
+    const uint8_t* xb_thread = p.xb + (size_t)chunk * p.chunk_bytes + (size_t)wave * 2048 + (size_t)lane * 16;   // wave w copies bytes [2048 w, 2048 w + 2048) of a step record
+    const uint8_t* aux_thread = reinterpret_cast<const uint8_t*>(p.aux) + (size_t)chunk * p.chunk_bytes + (size_t)wave * 64 + (size_t)(lane & 3) * 16;   // and 64 of its 256 aux bytes
+    constexpr int ND = D::HAS_MIN ? 3 : 2;               // DMA requests per step and wave
+    auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros)
+        const int s = rel < nsteps ? step_lo + rel : p.steps;
+        gb_dma16x2(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * GB_STEP_BYTES + (uint32_t)wave * 2048u), xb_thread + (size_t)s * GB_STEP_BYTES);
+        if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave (one request: the vmcnt arithmetic counts it for every lane)
+            gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + GB_XS_OFF + (uint32_t)slot * GB_AUX_BYTES + (uint32_t)wave * 64u), aux_thread + (size_t)s * GB_AUX_BYTES);
+    };
+    const uint8_t* img[RT];      // this lane's row images (row rt*16 + i of the wave's tile)
+    uint32_t my_row[RT];         // and the rows' byte offsets in W: the unit's bytes start `(my_row + unit offset) & 15` into the image
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        img[rt] = stage + (rt * 16 + i) * STRIDE;
+        my_row[rt] = (uint32_t)min(row0 + rt * 16 + i, seg_out - 1) * p.row_bytes;
+    }
+    typename D::Hdr hdr[RT];
+    const uint8_t* cur[RT];      // img + the staged unit's shift (AL: rounded down to a dword boundary)
+    auto enter_unit = [&](int unit) {   // the image now holds `unit`
+        const uint32_t uoff = (uint32_t)(unit_lo + min(unit, nunits - 1)) * D::UB;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const uint8_t* first = img[rt] + ((my_row[rt] + uoff) & 15u);
+            hdr[rt] = D::header(first, first + 4 * g);
+            cur[rt] = AL ? img[rt] + ((my_row[rt] + uoff) & 12u) : first;
+        }
+    };
+    auto read_planes = [&](u32x4 (&b)[GB_PLANES][4], int slot) {
+        const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * GB_STEP_BYTES);
+#pragma unroll
+        for (int pl = 0; pl < GB_PLANES; ++pl)
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) b[pl][tb] = bs[(pl * 4 + tb) * 64 + lane];
+    };
+    // Prologue, in the steady state's request order (the waits below count requests): the ring; unit 0 staged and its ring slot
+    // re-requested; DMA 0, 1, 2; step 0 loaded and converted, step 1 loaded (and, PF, the planes of step 0 read).
+#pragma unroll
+    for (int k = 0; k < NRING; ++k) load_unit(k, k);
+    stage_unit(0);
+    load_unit(0, NRING);
+    dma_step(0, 0);
+    dma_step(1, 1);
+    dma_step(2, 2);
+    static_assert(GB_SLOTS == 4 && SPU >= 4, "the prologue is written out for an activation ring of 4 and units of >= 4 steps");
+    enter_unit(0);
+    AOp a[RT];
+    typename D::Raw rawn[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        a[rt] = D::template convert<AL>(D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], 0, 0), 0, 0);
+        rawn[rt] = D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], 1, 0);
+    }
+    u32x4 b[GB_PLANES][4];
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND) : "memory");   // DMA 0 has landed (younger: DMA 1, 2)
+    if constexpr (PF) read_planes(b, 0);
+
+    for (int trip = 0; trip * (GB_UPT * SPU) < nsteps; ++trip) {
+#pragma unroll
+        for (int k = 0; k < GB_UPT; ++k) {
+#pragma unroll
+            for (int j = 0; j < SPU; ++j) {
+                const int rel = (trip * GB_UPT + k) * SPU + j;        // step relative to the split's start
+                const int slot = (k * SPU + j) % GB_SLOTS;           // its ring slot (compile time)
+                GB_STAMP(rel, 0);
+                // The next unit's weight requests go out in a unit's step SPU - 2, ahead of that step's DMA.
+                // PF: the DMA of step rel + 1 must have landed (its planes are read in this step); younger requests: the DMA of step
+                // rel + 2 and, if that one went out in a step SPU - 2, the weight requests ahead of it.
+                // !PF: the DMA of step rel; the DMAs of two steps are younger, and the weight requests count for two steps.
+                if constexpr (PF) {
+                    if (j == SPU - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ND + NLD) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ND) : "memory");
+                } else {
+                    if (j == SPU - 1 || j == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND + NLD) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND) : "memory");
+                }
+                GB_STAMP(rel, 1);
+                if (j == SPU - 2) {   // the raw dwords of this unit's last step were read a step ago: the image is free for the next unit
+                    stage_unit((k + 1) % NRING);
+                    load_unit((k + 1) % NRING, trip * GB_UPT + k + 1 + NRING);
+                    enter_unit(trip * GB_UPT + k + 1);
+                }
+                // into the slot of step rel - 1: its planes were read a step (PF: two steps) ago and consumed before this barrier
+                dma_step(rel + GB_SLOTS - 1, (slot + GB_SLOTS - 1) % GB_SLOTS);
+                // ---- one scheduling region from here to the end of the step ----
+                // LDS reads, in the order their consumers come: this step's sums, the raw weight dwords of the step after next, the next
+                // step's activation planes
+                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + GB_XS_OFF + (size_t)slot * GB_AUX_BYTES);
+                f32x4 xsum_t[4];   // tokens tb*16 + 4g + e
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) xsum_t[tb] = D::HAS_MIN ? xs[tb * 4 + g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                typename D::Raw raw2[RT];
+                {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int j2 = (j + 2) % SPU, k2 = (j + 2 >= SPU) ? (k + 1) % GB_UPT : k;   // (cur / hdr already belong to the next unit from step SPU - 2 on)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) raw2[rt] = D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], j2, k2);
+                }
+                u32x4 bn[GB_PLANES][4];
+                if constexpr (PF) read_planes(bn, (slot + 1) % GB_SLOTS);
+                else read_planes(b, slot);
+#if defined(NTK_GEMM_TRACE) && NTK_GEMM_TRACE > 1
+                GB_STAMP(rel, 2);
+#endif
+                // the next step's operand out of the dwords read a step ago: VALU work with no LDS read of this step behind it
+                AOp an[RT];
+                {
+                    const int j1 = (j + 1) % SPU, k1 = (j + 1 >= SPU) ? (k + 1) % GB_UPT : k;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) an[rt] = D::template convert<AL>(rawn[rt], j1, k1);
+                }
+                // MFMAs token block by token block; a block's scale-FMAs follow its chains and hide under the next block's MFMAs
+                if constexpr (D::SPLIT16) {   // two 16-column groups with their own scale: K = 16 MFMAs on the operand halves
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) {
+                        f32x4 cl[RT], ch[RT];
+#pragma unroll
+                        for (int pl = 0; pl < GB_PLANES; ++pl) {
+                            const f16x4 xl = __builtin_bit_cast(f16x4, (uint64_t)b[pl][tb].x | ((uint64_t)b[pl][tb].y << 32));
+                            const f16x4 xh = __builtin_bit_cast(f16x4, (uint64_t)b[pl][tb].z | ((uint64_t)b[pl][tb].w << 32));
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const f16x4 wl = __builtin_bit_cast(f16x4, (uint64_t)a[rt].a.x | ((uint64_t)a[rt].a.y << 32));
+                                const f16x4 wh = __builtin_bit_cast(f16x4, (uint64_t)a[rt].a.z | ((uint64_t)a[rt].a.w << 32));
+                                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                                cl[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(xl, wl, pl ? cl[rt] : z, 0, 0, 0);
+                                ch[rt] = __builtin_amdgcn_mfma_f32_16x16x16f16(xh, wh, pl ? ch[rt] : z, 0, 0, 0);
+                            }
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                acc[rt][tb][e] = fmaf(a[rt].s1, ch[rt][e], fmaf(a[rt].s0, cl[rt][e], acc[rt][tb][e]));
+                    }
+                } else {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) {
+                        f32x4 cc[RT];
+#pragma unroll
+                        for (int pl = 0; pl < GB_PLANES; ++pl)
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                                cc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[pl][tb]), __builtin_bit_cast(f16x8, a[rt].a),
+                                                                                pl ? cc[rt] : z, 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float v = fmaf(a[rt].s0, cc[rt][e], acc[rt][tb][e]);
+                                if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[tb][e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
+                                acc[rt][tb][e] = v;
+                            }
+                    }
+                }
+                // issue order of the region: every LDS read first, then the MFMAs with VALU work in their shadow
+                {
+                    constexpr int NMF = (D::SPLIT16 ? 8 : 4) * GB_PLANES * RT;
+                    __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
+#pragma unroll
+                    for (int n = 0; n < NMF; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, D::SPLIT16 ? 2 : 4, 0);
+                    }
+                }
+                // the accumulators and the next operands are complete HERE: without this anchor the instruction selector parks every
+                // step's scale-FMAs at the end of the trip (they have no memory dependence) and the products of 16 steps sit in
+                // registers until then
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int tb = 0; tb < 4; ++tb) asm volatile("" : "+v"(acc[rt][tb]));
+                    a[rt] = an[rt];
+                    asm volatile("" : "+v"(a[rt].a), "+v"(a[rt].s0), "+v"(a[rt].s1), "+v"(a[rt].mn));
+                    rawn[rt] = raw2[rt];
+                }
+                if constexpr (PF) {
+#pragma unroll
+                    for (int pl = 0; pl < GB_PLANES; ++pl)
+#pragma unroll
+                        for (int tb = 0; tb < 4; ++tb) { b[pl][tb] = bn[pl][tb]; asm volatile("" : "+v"(b[pl][tb])); }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // no motion of memory requests across steps (the waits count them in order)
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be in flight towards LDS when the workgroup retires
+#ifdef NTK_GEMM_TRACE
+    if (gbt_on) {
+        __syncthreads();
+        for (int q = tid; q < 4 * GBT_STEPS * GBT_EV; q += 256) (&g_gemm_f16_trace[0][0][0])[q] = gbt[q];
+    }
+#endif
+    // ---- epilogue: accumulator element e of lane (i = weight row of the tile, g) is token tb*16 + 4g + e of the chunk; 1 / s ------
+    const size_t tok0 = (size_t)chunk * GB_TOK;
+    f32x4 inv_t[4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) inv_t[tb] = *reinterpret_cast<const f32x4*>(p.inv + tok0 + tb * 16 + 4 * g);   // (the array is padded to whole chunks)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int r = row0 + rt * 16 + i;
+        if (r >= seg_out) continue;
+        if (p.nsplit > 1) {   // K split: this workgroup's partial sums, combined (fixed order) by reduce_splits_kernel
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = tb * 16 + 4 * g + e;
+                    if (t < Tc) segPart[((size_t)blockIdx.y * p.T + tok0 + t) * seg_out + r] = acc[rt][tb][e] * inv_t[tb][e];
+                }
+            continue;
+        }
+        float rs[4][4];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = tb * 16 + 4 * g + e;
+                rs[tb][e] = (p.resid && t < Tc) ? p.resid[(tok0 + t) * seg_out + r] : 0.0f;
+            }
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = tb * 16 + 4 * g + e;
+                if (t < Tc) segY[(tok0 + t) * seg_out + r] = acc[rt][tb][e] * inv_t[tb][e] + rs[tb][e];
+            }
+    }
+}
+
+// Y[t][r] = sum over splits (in order) of part[s][t][r] (+ resid): one float4 per thread, blockIdx.y = matrix of the launch
+struct ReduceArgs {
+    float* Y[GB_MAX_SEG];
+    const float* part[GB_MAX_SEG];
+    int out[GB_MAX_SEG];
+    const float* resid;
+    int nseg, T, nsplit;
+};
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const ReduceArgs a) {
+    const int sg = blockIdx.y;
+    float* Y = a.Y[0];
+    const float* part = a.part[0];
+    int out = a.out[0];
+    if (sg == 1) { Y = a.Y[1]; part = a.part[1]; out = a.out[1]; }
+    if (sg == 2) { Y = a.Y[2]; part = a.part[2]; out = a.out[2]; }
+    const size_t idx = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx >= (size_t)a.T * out) return;
+    float4 v = *reinterpret_cast<const float4*>(part + idx);
+    for (int s = 1; s < a.nsplit; ++s) {
+        const float4 q = *reinterpret_cast<const float4*>(part + (size_t)s * a.T * out + idx);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    if (a.resid) {
+        const float4 q = *reinterpret_cast<const float4*>(a.resid + idx);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+    }
+    *reinterpret_cast<float4*>(Y + idx) = v;
+}
+
+// one chunk's planes + sums (+ the record of zeros), rounded to 256 B
+static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * (GB_STEP_BYTES + GB_AUX_BYTES) + 255) / 256 * 256; }
+
+constexpr size_t GB_SCALE_BYTES = 2 * GB_MAX_CHUNKS * GB_TOK * sizeof(float);   // the launch's 1 / s and s
+
+struct HostSeg { float* Y; const void* W; int out; };
+
+// T <= GB_MAX_CHUNKS * 64 = 1024 tokens in one launch; nseg matrices [out_s][in] of one format sharing X
+template <int DT>
+static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T, int in, const float* resid, void* ws, int reuse_x,
+                            hipStream_t st) {
+    using D = DeqI<DT>;
+    constexpr int TRIP = GB_UPT * D::SPU;   // steps per loop trip: K ranges are whole trips
+    if (nseg < 1 || nseg > GB_MAX_SEG || (resid && nseg != 1) || in % D::BW != 0) return NTK_E_SHAPE;
+    const size_t row_bytes = (size_t)in / D::BW * D::BB;
+    long out_total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].out <= 0 || segs[i].out % 16 != 0 || (size_t)segs[i].out * row_bytes > 0xFFFFFF00ull) return NTK_E_SHAPE;   // 32-bit piece offsets
+        if ((reinterpret_cast<uintptr_t>(segs[i].W) & 15) || (reinterpret_cast<uintptr_t>(segs[i].Y) & 15)) return NTK_E_ALIGN;
+        out_total += segs[i].out;
+    }
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (resid && (reinterpret_cast<uintptr_t>(resid) & 15))) return NTK_E_ALIGN;
+    GemmBParams p{};
+    p.nseg = nseg;
+    p.T = T; p.in = in; p.steps = in / 32;
+    p.chunks = (T + GB_TOK - 1) / GB_TOK;
+    p.chunk_bytes = ws_chunk_bytes(in);
+    p.row_bytes = (unsigned)row_bytes;
+    uint8_t* wsb = static_cast<uint8_t*>(ws);
+    p.xb = wsb;
+    p.aux = reinterpret_cast<const float*>(wsb + (size_t)(p.steps + 1) * GB_STEP_BYTES);
+    float* scales = reinterpret_cast<float*>(wsb + (size_t)GB_MAX_CHUNKS * p.chunk_bytes);   // [inv: 1024][scale: 1024]
+    p.inv = scales;
+    p.resid = resid;
+    if (!reuse_x) {
+        hipLaunchKernelGGL(row_scale_kernel, dim3((T + 3) / 4), dim3(256), 0, st, X, T, in, scales + GB_MAX_CHUNKS * GB_TOK, scales);
+        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 1, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.aux),
+                           p.chunk_bytes, scales + GB_MAX_CHUNKS * GB_TOK);
+    }
+    // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
+    // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) while fewer than one workgroup per CU exists.
+    static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
+    static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 256; }();
+    int rt = out_total >= 2048 ? 2 : 1;
+    if (force_rt == 1 || force_rt == 2) rt = force_rt;
+    int tiles = 0;
+    float* part = reinterpret_cast<float*>(wsb + (size_t)GB_MAX_CHUNKS * p.chunk_bytes + GB_SCALE_BYTES);
+    for (int i = 0; i < nseg; ++i) {
+        p.seg[i].W = static_cast<const uint8_t*>(segs[i].W);
+        p.seg[i].Y = segs[i].Y;
+        p.seg[i].out = segs[i].out;
+        p.seg[i].w_last = (unsigned)((size_t)segs[i].out * row_bytes - 16);
+        p.seg[i].tile0 = tiles;
+        tiles += (segs[i].out + 64 * rt - 1) / (64 * rt);
+    }
+    p.row_wgs = tiles;
+    const int trips = (p.steps + TRIP - 1) / TRIP;
+    int nsplit = 1;
+    while (nsplit * 2 * p.chunks <= GB_MAX_SPLIT && p.row_wgs * p.chunks * nsplit < want_wgs && trips / (nsplit * 2) >= 1) nsplit *= 2;
+    const int tps = (trips + nsplit - 1) / nsplit;   // trips per split
+    nsplit = (trips + tps - 1) / tps;                // no empty split
+    p.nsplit = nsplit;
+    p.steps_per_split = tps * TRIP;
+    for (int i = 0; i < nseg; ++i) {                 // partial-sum areas, one after the other: nsplit x T x out_i floats each
+        p.seg[i].part = part;
+        part += (size_t)nsplit * T * segs[i].out;
+    }
+    const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
+    const size_t lds2 = gb_lds_bytes<DT, 2>(), lds1 = gb_lds_bytes<DT, 1>();
+    static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
+    // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0: in a multiple of 64, Q6_K: of
+    // 512 -- every projection of the target models; other row pitches take the same kernel with 2-byte aligned reads, slower)
+    const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
+    auto go = [&](auto pf, auto alc) {
+        constexpr bool PFc = decltype(pf)::value, ALc = decltype(alc)::value;
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, PFc, ALc>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, PFc, ALc>), grid, dim3(256), lds1, st, p);
+    };
+    const bool pf = DeqI<DT>::PF && !no_pf;
+    if (pf && al) go(std::true_type{}, std::true_type{});
+    else if (pf) go(std::true_type{}, std::false_type{});
+    else if (al) go(std::false_type{}, std::true_type{});
+    else go(std::false_type{}, std::false_type{});
+    if (nsplit > 1) {
+        ReduceArgs ra{};
+        ra.nseg = nseg; ra.T = T; ra.nsplit = nsplit; ra.resid = resid;
+        size_t biggest = 0;
+        for (int i = 0; i < nseg; ++i) {
+            ra.Y[i] = segs[i].Y; ra.part[i] = p.seg[i].part; ra.out[i] = segs[i].out;
+            biggest = std::max(biggest, ((size_t)T * segs[i].out + 3) / 4);
+        }
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((biggest + 255) / 256), nseg), dim3(256), 0, st, ra);
+    }
+    return last_launch_status();
+}
+
+}  // namespace ntk
+
+extern "C" {
+
+#ifdef NTK_GEMM_TRACE
+int ntk_debug_gemm_f16_trace(unsigned long long* out, size_t n) {   // n <= 4 * GBT_STEPS * GBT_EV
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemm_f16_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features) {
+    if (in_features <= 0 || out_features < 0) return 0;
+    return (size_t)ntk::GB_MAX_CHUNKS * ntk::ws_chunk_bytes((in_features + 31) / 32 * 32) + ntk::GB_SCALE_BYTES +
+           (size_t)ntk::GB_MAX_SPLIT * ntk::GB_TOK * (size_t)out_features * sizeof(float) + 256;
+}
+
+static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, int n_tokens, int in_features, int weight_dtype, const float* resid,
+                            void* workspace, int reuse_x, hipStream_t st) {
+    constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
+    if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (1024 tokens) at a time
+    for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 16 x 64 tokens per launch: the chunks share the weights in L2
+        const int T = std::min(PASS, n_tokens - t0);
+        ntk::HostSeg sg[ntk::GB_MAX_SEG];
+        for (int i = 0; i < nseg; ++i) sg[i] = ntk::HostSeg{segs[i].Y + (size_t)t0 * segs[i].out, segs[i].W, segs[i].out};
+        const float* x = X + (size_t)t0 * in_features;
+        const float* rs = resid ? resid + (size_t)t0 * segs[0].out : nullptr;
+        int rc;
+        switch (weight_dtype) {
+            case NTK_DT_Q8_0: rc = ntk::launch_gemm_f16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q4_K: rc = ntk::launch_gemm_f16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q5_K: rc = ntk::launch_gemm_f16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            default: rc = ntk::launch_gemm_f16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+        }
+        if (rc != NTK_OK) return rc;
+    }
+    return NTK_OK;
+}
+
+int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
+                      const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream) {
+    if (!Y || !W || !X || !workspace) return NTK_E_NULL;
+    if (n_tokens < 0 || out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
+    if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
+    if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (n_tokens == 0 || out_features == 0) return NTK_OK;
+    const ntk::HostSeg sg{Y, W, out_features};
+    return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, ntk::resolve_stream(stream));
+}
+
+// several matrices of one format sharing X (Q | K | V, gate | up) in ONE launch: segs[i] = {Y_i [n_tokens][rows_i], W_i, rows_i}
+// (ntk_gemv_seg: y, W, rows, dtype -- the dtypes must agree).  workspace: ntk_gemm_quant_workspace_bytes(in, sum of rows).
+int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                            size_t workspace_bytes, int reuse_x, void* stream) {
+    if (!segs || !X || !workspace) return NTK_E_NULL;
+    if (nseg < 1 || nseg > ntk::GB_MAX_SEG || n_tokens < 0 || in_features <= 0) return NTK_E_SHAPE;
+    ntk::HostSeg sg[ntk::GB_MAX_SEG];
+    long total = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!segs[i].W || !segs[i].y) return NTK_E_NULL;
+        if (segs[i].rows <= 0 || segs[i].dtype != segs[0].dtype) return NTK_E_SHAPE;
+        sg[i] = ntk::HostSeg{segs[i].y, segs[i].W, segs[i].rows};
+        total += segs[i].rows;
+    }
+    const int dt = segs[0].dtype;
+    if (dt != NTK_DT_Q8_0 && dt != NTK_DT_Q4_K && dt != NTK_DT_Q5_K && dt != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, (int)total) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
+    if (n_tokens == 0) return NTK_OK;
+    return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, ntk::resolve_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Step timeline of the FP16 prompt GEMM (needs the trace build: make -C ntransformer_amd/csrc trace [GEMM_TRACE=2], run with
+NTK_LIB_PATH=ntransformer_amd/libntransformer_hip_trace.so).  For every wave of workgroup 0: shader-clock ticks spent per step
+waiting (s_waitcnt + barrier) and in the step's body, and (GEMM_TRACE=2) until the step's LDS reads have returned."""
+import ctypes as C, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntransformer_amd import _lib, gguf as G, ops
+from ntransformer_amd.ops import DeviceBuffer as DB
+
+ops.init(0)
+L = _lib.lib()
+L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+L.ntk_gemm_quant_ws.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+L.ntk_debug_gemm_f16_trace.argtypes = [C.c_void_p, C.c_size_t]
+STEPS, EV = 96, 3
+rng = np.random.default_rng(0)
+cases = [("Q8_0", G.GGML_Q8_0, 14336, 4096, 64), ("Q8_0", G.GGML_Q8_0, 14336, 4096, 1024), ("Q4_K", G.GGML_Q4_K, 14336, 4096, 1024), ("Q8_0", G.GGML_Q8_0, 4096, 14336, 1024)]
+for dname, gt, out_f, in_f, T in cases:
+    dt = G.GGML_TO_DT[gt]
+    rb = G.row_bytes(gt, in_f)
+    W = DB.from_numpy(rng.integers(0, 60, out_f * rb, dtype=np.uint8))
+    X = DB.from_numpy(rng.standard_normal((T, in_f)).astype(np.float32))
+    Y = DB.zeros(T * out_f * 4)
+    n = int(L.ntk_gemm_quant_workspace_bytes(in_f, out_f)); ws = DB(n)
+    for _ in range(3): assert L.ntk_gemm_quant_ws(Y.ptr, W.ptr, X.ptr, T, out_f, in_f, int(dt), None, ws.ptr, n, 0, None) == 0
+    ops.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10): L.ntk_gemm_quant_ws(Y.ptr, W.ptr, X.ptr, T, out_f, in_f, int(dt), None, ws.ptr, n, 0, None)
+    ops.synchronize()
+    us = (time.perf_counter() - t0) / 10 * 1e6
+    buf = (C.c_ulonglong * (4 * STEPS * EV))()
+    assert L.ntk_debug_gemm_f16_trace(buf, 4 * STEPS * EV) == 0
+    t = np.array(buf[:], dtype=np.uint64).astype(np.int64).reshape(4, STEPS, EV)
+    print("%s %dx%d, %d tokens: %.1f us per call (pre-pass + main [+ reduce])" % (dname, out_f, in_f, T, us))
+    for w in range(4):
+        a, b, c = t[w, :, 0], t[w, :, 1], t[w, :, 2]
+        ok = (a[1:] > 0) & (a[:-1] > 0)
+        nst = int(ok.sum())
+        if nst < 8: print("  wave %d: no stamps" % w); continue
+        wait = (b - a)[:nst]
+        body = (a[1:nst + 1] - b[:nst])
+        line = "  wave %d: %d steps, %.0f ticks/step = wait %.0f (median %.0f, max %d) + body %.0f (median %.0f)" % (
+            w, nst, (a[nst] - a[0]) / nst, wait.mean(), np.median(wait), wait.max(), body.mean(), np.median(body))
+        if c[:nst].min() > 0: line += "; LDS reads returned %.0f ticks after the barrier" % (c - b)[:nst].mean()
+        print(line)
+    w = 0
+    print("  wave 0 steps 16..31 (wait/body): " + " ".join("%d/%d" % (t[w, s, 1] - t[w, s, 0], t[w, s + 1, 0] - t[w, s, 1]) for s in range(16, 32)))
