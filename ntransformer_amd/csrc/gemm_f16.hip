@@ -54,6 +54,30 @@ constexpr int GB_AUX_BYTES = GB_TOK * 4;                  // per step: the 64 to
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {   // two small integers -> FP16 pair (exact)
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));
 }
+// bytes k, k + 1 of a dword -> an FP16 pair, one SDWA conversion each (through F32 it is two conversions and a pack per pair: the
+// VALU slots of a step are what the kernel runs out of first)
+template <int K> __device__ __forceinline__ uint32_t cvt2_s8_f16(uint32_t q) {
+    uint32_t r;
+    if constexpr (K == 0)
+        asm("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0\n\t"
+            "v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "=&v"(r) : "v"(q));
+    else
+        asm("v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2\n\t"
+            "v_cvt_f16_i16_sdwa %0, sext(%1) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "=&v"(r) : "v"(q));
+    return r;
+}
+template <int K> __device__ __forceinline__ uint32_t cvt2_u8_f16(uint32_t q) {
+    uint32_t r;
+    if constexpr (K == 0)
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_0\n\t"
+            "v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "=&v"(r) : "v"(q));
+    else
+        asm("v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:BYTE_2\n\t"
+            "v_cvt_f16_u16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "=&v"(r) : "v"(q));
+    return r;
+}
+__device__ __forceinline__ u32x4 cvt8_s8_f16(uint32_t lo, uint32_t hi) { return u32x4{cvt2_s8_f16<0>(lo), cvt2_s8_f16<2>(lo), cvt2_s8_f16<0>(hi), cvt2_s8_f16<2>(hi)}; }
+__device__ __forceinline__ u32x4 cvt8_u8_f16(uint32_t lo, uint32_t hi) { return u32x4{cvt2_u8_f16<0>(lo), cvt2_u8_f16<2>(lo), cvt2_u8_f16<0>(hi), cvt2_u8_f16<2>(hi)}; }
 typedef uint32_t __attribute__((aligned(2))) u32_a2;
 typedef uint16_t __attribute__((aligned(2))) u16_a2;
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const u32_a2*>(p); }   // 2-byte aligned global dword
@@ -177,8 +201,7 @@ template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
         const bool whole = !AL || (j & 1);
         const uint32_t lo = whole ? r.w0 : mid32(r.w0, r.w1), hi = whole ? r.w2 : mid32(r.w2, r.w3);
         AOp o;
-        o.a = u32x4{pack_f16(sb2f(lo, 0), sb2f(lo, 1)), pack_f16(sb2f(lo, 2), sb2f(lo, 3)),
-                    pack_f16(sb2f(hi, 0), sb2f(hi, 1)), pack_f16(sb2f(hi, 2), sb2f(hi, 3))};
+        o.a = cvt8_s8_f16(lo, hi);
         o.s0 = o.s1 = h2f((uint16_t)r.d);
         o.mn = 0.0f;
         return o;
@@ -203,8 +226,7 @@ template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 pa
         const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
         const uint32_t lo = (r.lo >> sh) & 0x0F0F0F0Fu, hi = (r.hi >> sh) & 0x0F0F0F0Fu;
         AOp o;
-        o.a = u32x4{pack_f16(ub2f(lo, 0), ub2f(lo, 1)), pack_f16(ub2f(lo, 2), ub2f(lo, 3)),
-                    pack_f16(ub2f(hi, 0), ub2f(hi, 1)), pack_f16(ub2f(hi, 2), ub2f(hi, 3))};
+        o.a = cvt8_u8_f16(lo, hi);
         o.s0 = o.s1 = r.s0;
         o.mn = r.mn;
         return o;
@@ -231,8 +253,7 @@ template <> struct DeqI<NTK_DT_Q5_K> {   // types.h:122-128: half d, dmin; 12 pa
         const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
         const uint32_t lo = ((r.lo >> sh) & 0x0F0F0F0Fu) | r.b5lo, hi = ((r.hi >> sh) & 0x0F0F0F0Fu) | r.b5hi;
         AOp o;
-        o.a = u32x4{pack_f16(ub2f(lo, 0), ub2f(lo, 1)), pack_f16(ub2f(lo, 2), ub2f(lo, 3)),
-                    pack_f16(ub2f(hi, 0), ub2f(hi, 1)), pack_f16(ub2f(hi, 2), ub2f(hi, 3))};
+        o.a = cvt8_u8_f16(lo, hi);
         o.s0 = o.s1 = r.s0;
         o.mn = r.mn;
         return o;
@@ -243,7 +264,7 @@ template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], in
     static constexpr int BW = 256, BB = 210;
     static constexpr int SPU = 8, UB = 210, NCH = 14, STRIDE = 240;    // window: shift (even, <= 14) + 210 <= 224
     static constexpr int ROW_ALIGN = 4, NRING = 1;                     // row pitch: in_features a multiple of 512
-    static constexpr bool SPLIT16 = true, HAS_MIN = false, PF = false;   // (PF: 23 registers over the 256 of two waves per SIMD)
+    static constexpr bool SPLIT16 = true, HAS_MIN = false, PF = false;
     struct Hdr { float d; };
     struct Raw { uint32_t ql0, ql1, ql2, ql3, qh0, qh1, qh2, qh3, sc; float d; };
     __device__ static Hdr header(const uint8_t* row, const uint8_t*) { return Hdr{h2f((uint16_t)lds16(row + 208))}; }
@@ -273,8 +294,10 @@ template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], in
         const uint32_t lo = ((ql_lo >> sl) & 0x0F0F0F0Fu) | (((qh_lo >> sh) & 0x03030303u) << 4);         // gemm.cu:421-459
         const uint32_t hi = ((ql_hi >> sl) & 0x0F0F0F0Fu) | (((qh_hi >> sh) & 0x03030303u) << 4);
         AOp o;   // q - 32: exact small integers
-        o.a = u32x4{pack_f16(ub2f(lo, 0) - 32.0f, ub2f(lo, 1) - 32.0f), pack_f16(ub2f(lo, 2) - 32.0f, ub2f(lo, 3) - 32.0f),
-                    pack_f16(ub2f(hi, 0) - 32.0f, ub2f(hi, 1) - 32.0f), pack_f16(ub2f(hi, 2) - 32.0f, ub2f(hi, 3) - 32.0f)};
+        const u32x4 qa = cvt8_u8_f16(lo, hi);
+        const f16x2 m32 = {(_Float16)-32.0f, (_Float16)-32.0f};
+        auto sub32 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, (f16x2)(__builtin_bit_cast(f16x2, w) + m32)); };
+        o.a = u32x4{sub32(qa.x), sub32(qa.y), sub32(qa.z), sub32(qa.w)};
         o.s0 = r.d * (float)(int)(int8_t)(r.sc & 0xFF);
         o.s1 = r.d * (float)(int)(int8_t)(r.sc >> 8);
         o.mn = 0.0f;
@@ -288,6 +311,7 @@ template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], in
 #ifdef NTK_GEMM_TRACE
 constexpr int GBT_STEPS = 96, GBT_EV = 3;
 __device__ unsigned long long g_gemm_f16_trace[4][GBT_STEPS][GBT_EV];
+__device__ unsigned long long g_gemm_f16_clock[4];   // workgroup 0: shader clock and the constant 100 MHz clock at its first and last step
 constexpr int GB_TRACE_LDS = 4 * GBT_STEPS * GBT_EV * 8;
 #define GB_STAMP(step, ev) do { if (gbt_on && (step) < GBT_STEPS) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
         if (lane == 0) gbt[((size_t)wave * GBT_STEPS + (step)) * GBT_EV + (ev)] = t_; } } while (0)
@@ -296,11 +320,24 @@ constexpr int GB_TRACE_LDS = 0;
 #define GB_STAMP(step, ev) do {} while (0)
 #endif
 
+// Ablation switches of tuning builds (wrong results, timing only): 1 = no MFMAs, 2 = no scale-FMAs (the MFMAs accumulate straight
+// into the accumulators), 4 = no conversion of the raw weight dwords, 8 = no LDS reads of the activation planes, 16 = no activation
+// DMA, 32 = no weight loads / staging.  0 in the product.
+#ifndef NTK_GEMM_ABLATE
+#define NTK_GEMM_ABLATE 0
+#endif
+constexpr int kGbAblate = NTK_GEMM_ABLATE;
+
 constexpr int GB_UPT = 2;     // units per loop trip (Q6_K: the parity of a unit, which decides its alignment, is then a compile-time constant)
-constexpr int GB_SLOTS = 4;   // LDS ring of activation step records (8 KB each), filled by LDS-DMA GB_SLOTS - 1 steps ahead
-constexpr int GB_XS_OFF = GB_SLOTS * GB_STEP_BYTES;   // then [GB_SLOTS][128] floats: the steps' per-token sums of x and inverse scales
-constexpr int GB_STAGE_OFF = GB_XS_OFF + GB_SLOTS * GB_AUX_BYTES;   // then the 4 waves' weight images
-template <int DT, int RT> constexpr int gb_lds_bytes() { return GB_STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS; }
+// LDS of a workgroup: a ring of NS activation step records (8 KB each, filled by LDS-DMA NS - 1 steps ahead), the ring of the steps'
+// per-token sums, the 4 waves' weight images.  NS = as many slots as leave room for two workgroups per CU (160 KB): a record that
+// misses the XCD's L2 takes ~2 us to arrive, and the records in flight are what hides it (a step consumes one in 0.3-0.4 us)
+constexpr int GB_LDS_WG = 80 * 1024;
+template <int DT, int RT> constexpr int gb_slots() {
+    const int n = (GB_LDS_WG - 4 * 16 * RT * DeqI<DT>::STRIDE - GB_TRACE_LDS) / (GB_STEP_BYTES + GB_AUX_BYTES);
+    return n > 8 ? 8 : n;
+}
+template <int DT, int RT> constexpr int gb_lds_bytes() { return gb_slots<DT, RT>() * (GB_STEP_BYTES + GB_AUX_BYTES) + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS; }
 
 constexpr int GB_MAX_SEG = 3;   // matrices sharing X in one launch (Q | K | V, gate | up)
 struct GemmBSeg {
@@ -343,17 +380,19 @@ __device__ __forceinline__ void gb_dma16x2(uint32_t lds_dst, const uint8_t* gsrc
 // accumulator of lane (i, g) holds weight row i for tokens 4 g + e -- the row's scale is the one this lane decoded (no
 // cross-lane traffic), and the step's sums of x / inverse scales come as float4s from LDS.
 // One loop trip = GB_UPT units of SPU steps, straight-line (no exits inside: the s_waitcnt counts are exact).  Per step s:
-//   wait until the DMA of step s + 1 has landed | barrier | at a unit's last step: the next unit's raw rows go from their ring
-//   registers to the wave's LDS image and the ring slot is re-requested NRING units ahead | DMA step s + GB_SLOTS - 1 into the slot
-//   whose planes were consumed a step ago | read + decode the next step's weight slot, read the next step's activation planes into
-//   the second register set (PF; without it: this step's planes, ahead of its own MFMAs) | 8 RT MFMAs | scale-FMAs.
-template <int DT, int RT, bool PF, bool AL>
+//   wait until the DMA of step s has landed | barrier | at a unit's last step but one: the next unit's raw rows go from their ring
+//   registers to the wave's LDS image and the ring slot is re-requested NRING units ahead | DMA step s + NS - 1 into the slot whose
+//   planes were consumed a step ago | LDS reads: the step's sums, the raw weight dwords of step s + 2, the step's activation planes |
+//   4 x (2 RT MFMAs, the token block's scale-FMAs), the conversion of step s + 1's weight operand in their shadow.
+template <int DT, int RT, bool AL, bool PF>
 __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParams p) {
     using D = DeqI<DT>;
     constexpr int SPU = D::SPU, NCH = D::NCH, STRIDE = D::STRIDE;
     constexpr int ROWS = 16 * RT, PIECES = ROWS * NCH, NLD = (PIECES + 63) / 64;   // 16-byte pieces of a unit; requests per lane
     constexpr int NRING = D::NRING;
-    static_assert((GB_UPT * SPU) % GB_SLOTS == 0 && GB_UPT % NRING == 0, "a trip must cover whole turns of the activation ring and of the weight ring");
+    constexpr int NS = gb_slots<DT, RT>();                  // activation ring: slots
+    constexpr int XS_OFF = NS * GB_STEP_BYTES, STAGE_OFF = XS_OFF + NS * GB_AUX_BYTES;
+    static_assert(GB_UPT % NRING == 0 && NS >= 4 && NS - 2 <= GB_UPT * SPU, "a trip must cover whole turns of the weight ring");
     extern __shared__ __attribute__((aligned(16))) uint8_t gb_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,9 +404,10 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
     const int chunk = within % p.chunks, tile = (within / p.chunks) * 8 + xcd;
     if (tile >= p.row_wgs) return;   // row tiles are padded to a multiple of 8
 #ifdef NTK_GEMM_TRACE
-    unsigned long long* gbt = reinterpret_cast<unsigned long long*>(gb_lds + GB_STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE);
+    unsigned long long* gbt = reinterpret_cast<unsigned long long*>(gb_lds + STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE);
     const bool gbt_on = bid == 0 && blockIdx.y == 0;
     if (gbt_on) for (int q = tid; q < 4 * GBT_STEPS * GBT_EV; q += 256) gbt[q] = 0;
+    if (gbt_on && tid == 0) { g_gemm_f16_clock[0] = __builtin_amdgcn_s_memtime(); g_gemm_f16_clock[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     // which matrix of the launch this row tile belongs to (workgroup-uniform)
     int sidx = 0;
@@ -393,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
 
     // weight pieces of this lane: piece q = 64 n + lane of the wave's unit -> row q / NCH, 16-byte piece q % NCH of the 16-byte
     // aligned window that covers the row's unit (rows need not be 16-byte aligned: every row has its own window start and shift)
-    uint8_t* stage = gb_lds + GB_STAGE_OFF + (size_t)wave * (ROWS * STRIDE);
+    uint8_t* stage = gb_lds + STAGE_OFF + (size_t)wave * (ROWS * STRIDE);
     uint32_t w_row[NLD], s_pk[NLD];   // s_pk: offset of the piece in the wave's image | 16 c << 16 (unpacked once per unit: registers are the scarcer resource)
 #pragma unroll
     for (int n = 0; n < NLD; ++n) {
@@ -401,27 +441,38 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
         w_row[n] = (uint32_t)min(row0 + r, seg_out - 1) * p.row_bytes;
         s_pk[n] = (uint32_t)(r * STRIDE + 16 * c) | ((uint32_t)(16 * c) << 16);
     }
+    // The ring's loads and the stores that consume them are inline asm: a load the compiler tracks makes it wait, at the consumer, for
+    // "all but the tracked loads younger than it" -- it does not see the LDS-DMA requests in between, so that wait drained the whole
+    // activation ring at every unit boundary (round 3, the ISA of the first deep-ring build).  Here every wait is explicit and exact.
+    // (The ring registers appear in no compiler-generated instruction: tools/check_gemm_isa.py checks the build for that.)
     u32x4 ring[NRING][NLD];
     auto load_unit = [&](int k, int urel) {   // unit `urel` of this split (past the end: the last one again, multiplied by zeros)
+        if (kGbAblate & 32) { if (urel >= 2) return; }
         const uint32_t uoff = (uint32_t)(unit_lo + min(urel, nunits - 1)) * D::UB;
 #pragma unroll
-        for (int n = 0; n < NLD; ++n)
-            ring[k][n] = *reinterpret_cast<const u32x4*>(segW + min(((w_row[n] + uoff) & ~15u) + (s_pk[n] >> 16), seg_w_last));
+        for (int n = 0; n < NLD; ++n) {
+            const uint32_t off = min(((w_row[n] + uoff) & ~15u) + (s_pk[n] >> 16), seg_w_last);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ring[k][n]) : "v"(off), "s"(segW) : "memory");
+        }
     };
+    // (the caller waits first: s_waitcnt vmcnt(requests issued after the unit's loads))
     auto stage_unit = [&](int k) {
+        if (kGbAblate & 32) return;
 #pragma unroll
-        for (int n = 0; n < NLD; ++n) *reinterpret_cast<u32x4*>(stage + (s_pk[n] & 0xFFFFu)) = ring[k][n];
+        for (int n = 0; n < NLD; ++n)
+            asm volatile("ds_write_b128 %0, %1" ::"v"((uint32_t)(uintptr_t)(stage + (s_pk[n] & 0xFFFFu))), "v"(ring[k][n]) : "memory");
     };
 
     const uint32_t lds0 = (uint32_t)(uintptr_t)gb_lds;   // generic -> LDS address: the low 32 bits
     const uint8_t* xb_thread = p.xb + (size_t)chunk * p.chunk_bytes + (size_t)wave * 2048 + (size_t)lane * 16;   // wave w copies bytes [2048 w, 2048 w + 2048) of a step record
     const uint8_t* aux_thread = reinterpret_cast<const uint8_t*>(p.aux) + (size_t)chunk * p.chunk_bytes + (size_t)wave * 64 + (size_t)(lane & 3) * 16;   // and 64 of its 256 aux bytes
     constexpr int ND = D::HAS_MIN ? 3 : 2;               // DMA requests per step and wave
-    auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros)
+    auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros) into ring slot `slot` (uniform)
+        if ((kGbAblate & 16) && rel >= NS - 1) return;
         const int s = rel < nsteps ? step_lo + rel : p.steps;
         gb_dma16x2(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * GB_STEP_BYTES + (uint32_t)wave * 2048u), xb_thread + (size_t)s * GB_STEP_BYTES);
         if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave (one request: the vmcnt arithmetic counts it for every lane)
-            gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + GB_XS_OFF + (uint32_t)slot * GB_AUX_BYTES + (uint32_t)wave * 64u), aux_thread + (size_t)s * GB_AUX_BYTES);
+            gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + XS_OFF + (uint32_t)slot * GB_AUX_BYTES + (uint32_t)wave * 64u), aux_thread + (size_t)s * GB_AUX_BYTES);
     };
     const uint8_t* img[RT];      // this lane's row images (row rt*16 + i of the wave's tile)
     uint32_t my_row[RT];         // and the rows' byte offsets in W: the unit's bytes start `(my_row + unit offset) & 15` into the image
@@ -441,23 +492,24 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
             cur[rt] = AL ? img[rt] + ((my_row[rt] + uoff) & 12u) : first;
         }
     };
-    auto read_planes = [&](u32x4 (&b)[GB_PLANES][4], int slot) {
-        const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * GB_STEP_BYTES);
+    auto read_planes = [&](u32x4 (&b)[GB_PLANES][4], int slot) {   // token block by token block: the order the MFMAs take them in
+        const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * GB_STEP_BYTES) + lane;
 #pragma unroll
-        for (int pl = 0; pl < GB_PLANES; ++pl)
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb) b[pl][tb] = bs[(pl * 4 + tb) * 64 + lane];
+            for (int pl = 0; pl < GB_PLANES; ++pl) b[pl][tb] = bs[(pl * 4 + tb) * 64];
     };
-    // Prologue, in the steady state's request order (the waits below count requests): the ring; unit 0 staged and its ring slot
-    // re-requested; DMA 0, 1, 2; step 0 loaded and converted, step 1 loaded (and, PF, the planes of step 0 read).
+    // Prologue: the weight ring; unit 0 staged and its ring slot re-requested; the DMAs of steps 0 .. NS - 2; everything landed (one
+    // memory round trip per workgroup: from here on the waits count the requests of the loop's own steps, which come in a fixed order);
+    // step 0 loaded and converted, step 1 loaded.
 #pragma unroll
     for (int k = 0; k < NRING; ++k) load_unit(k, k);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NRING - 1) * NLD) : "memory");
     stage_unit(0);
     load_unit(0, NRING);
-    dma_step(0, 0);
-    dma_step(1, 1);
-    dma_step(2, 2);
-    static_assert(GB_SLOTS == 4 && SPU >= 4, "the prologue is written out for an activation ring of 4 and units of >= 4 steps");
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q) dma_step(q, q);
+    static_assert(SPU >= 4, "units of >= 4 steps: steps 0 and 1 belong to unit 0");
     enter_unit(0);
     AOp a[RT];
     typename D::Raw rawn[RT];
@@ -466,9 +518,10 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
         a[rt] = D::template convert<AL>(D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], 0, 0), 0, 0);
         rawn[rt] = D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], 1, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    int slot = 0;   // ring slot of the current step (uniform)
     u32x4 b[GB_PLANES][4];
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND) : "memory");   // DMA 0 has landed (younger: DMA 1, 2)
-    if constexpr (PF) read_planes(b, 0);
+    if constexpr (PF) read_planes(b, 0);   // PF: a step's planes are read one step ahead of its MFMAs, into a second register set
 
     for (int trip = 0; trip * (GB_UPT * SPU) < nsteps; ++trip) {
 #pragma unroll
@@ -476,31 +529,37 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
 #pragma unroll
             for (int j = 0; j < SPU; ++j) {
                 const int rel = (trip * GB_UPT + k) * SPU + j;        // step relative to the split's start
-                const int slot = (k * SPU + j) % GB_SLOTS;           // its ring slot (compile time)
                 GB_STAMP(rel, 0);
-                // The next unit's weight requests go out in a unit's step SPU - 2, ahead of that step's DMA.
-                // PF: the DMA of step rel + 1 must have landed (its planes are read in this step); younger requests: the DMA of step
-                // rel + 2 and, if that one went out in a step SPU - 2, the weight requests ahead of it.
-                // !PF: the DMA of step rel; the DMAs of two steps are younger, and the weight requests count for two steps.
-                if constexpr (PF) {
-                    if (j == SPU - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ND + NLD) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(ND) : "memory");
-                } else {
-                    if (j == SPU - 1 || j == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND + NLD) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * ND) : "memory");
+                // The DMA of the step whose planes are read now (this step; PF: the next one) went out NS - 1 (NS - 2) steps ago.  Younger
+                // requests: the DMAs of the steps since and the next unit's weight requests of every step SPU - 2 among them (they go out
+                // ahead of that step's DMA).  (In the first steps of the launch the count is too high for what is really in flight -- but
+                // what they wait for landed in the prologue.)
+                {
+                    constexpr int T = GB_UPT * SPU, BACK = PF ? NS - 3 : NS - 2;
+                    int nload = 0;
+#pragma unroll
+                    for (int d = 1; d <= BACK; ++d) nload += (((k * SPU + j - d) % T + T) % T) % SPU == SPU - 2 ? 1 : 0;
+                    // (nload is a compile-time constant after unrolling: one asm statement per value)
+                    if (nload == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(BACK * ND) : "memory");
+                    else if (nload == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(BACK * ND + NLD) : "memory");
+                    else if (nload == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(BACK * ND + 2 * NLD) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(BACK * ND + 3 * NLD) : "memory");
+                    static_assert((BACK + SPU - 1) / SPU <= 3, "at most three weight request groups in flight behind a DMA");
                 }
                 GB_STAMP(rel, 1);
                 if (j == SPU - 2) {   // the raw dwords of this unit's last step were read a step ago: the image is free for the next unit
+                    // younger than the loads of the unit staged now: the DMAs of the NRING * SPU steps since, the loads of the other ring slots
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRING * SPU * ND + (NRING - 1) * NLD) : "memory");
                     stage_unit((k + 1) % NRING);
                     load_unit((k + 1) % NRING, trip * GB_UPT + k + 1 + NRING);
                     enter_unit(trip * GB_UPT + k + 1);
                 }
-                // into the slot of step rel - 1: its planes were read a step (PF: two steps) ago and consumed before this barrier
-                dma_step(rel + GB_SLOTS - 1, (slot + GB_SLOTS - 1) % GB_SLOTS);
+                // into the slot of step rel - 1: its planes were read a step ago and consumed before this barrier
+                dma_step(rel + NS - 1, slot == 0 ? NS - 1 : slot - 1);
                 // ---- one scheduling region from here to the end of the step ----
                 // LDS reads, in the order their consumers come: this step's sums, the raw weight dwords of the step after next, the next
                 // step's activation planes
-                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + GB_XS_OFF + (size_t)slot * GB_AUX_BYTES);
+                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + XS_OFF + (size_t)slot * GB_AUX_BYTES);
                 f32x4 xsum_t[4];   // tokens tb*16 + 4g + e
 #pragma unroll
                 for (int tb = 0; tb < 4; ++tb) xsum_t[tb] = D::HAS_MIN ? xs[tb * 4 + g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -512,8 +571,8 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
                     for (int rt = 0; rt < RT; ++rt) raw2[rt] = D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], j2, k2);
                 }
                 u32x4 bn[GB_PLANES][4];
-                if constexpr (PF) read_planes(bn, (slot + 1) % GB_SLOTS);
-                else read_planes(b, slot);
+                if constexpr (PF) read_planes(bn, slot == NS - 1 ? 0 : slot + 1);
+                else if (!(kGbAblate & 8) || rel == 0) read_planes(b, slot);
 #if defined(NTK_GEMM_TRACE) && NTK_GEMM_TRACE > 1
                 GB_STAMP(rel, 2);
 #endif
@@ -522,7 +581,15 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
                 {
                     const int j1 = (j + 1) % SPU, k1 = (j + 1 >= SPU) ? (k + 1) % GB_UPT : k;
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) an[rt] = D::template convert<AL>(rawn[rt], j1, k1);
+                    for (int rt = 0; rt < RT; ++rt) {
+                        if (kGbAblate & 4) {   // the raw dwords as they are
+                            uint32_t w[sizeof(typename D::Raw) / 4];
+                            __builtin_memcpy(w, &rawn[rt], sizeof(w));
+                            an[rt].a = u32x4{w[0], w[1], w[2 % (sizeof(w) / 4)], w[3 % (sizeof(w) / 4)]};
+                            an[rt].s0 = an[rt].s1 = __uint_as_float(w[sizeof(w) / 4 - 1]);
+                            an[rt].mn = __uint_as_float(w[sizeof(w) / 4 - 2]);
+                        } else an[rt] = D::template convert<AL>(rawn[rt], j1, k1);
+                    }
                 }
                 // MFMAs token block by token block; a block's scale-FMAs follow its chains and hide under the next block's MFMAs
                 if constexpr (D::SPLIT16) {   // two 16-column groups with their own scale: K = 16 MFMAs on the operand halves
@@ -557,9 +624,12 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
 #pragma unroll
                             for (int rt = 0; rt < RT; ++rt) {
                                 const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                                cc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[pl][tb]), __builtin_bit_cast(f16x8, a[rt].a),
+                                if (kGbAblate & 1) cc[rt] = __builtin_bit_cast(f32x4, b[pl][tb]);
+                                else if (kGbAblate & 2) acc[rt][tb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[pl][tb]), __builtin_bit_cast(f16x8, a[rt].a), acc[rt][tb], 0, 0, 0);
+                                else cc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[pl][tb]), __builtin_bit_cast(f16x8, a[rt].a),
                                                                                 pl ? cc[rt] : z, 0, 0, 0);
                             }
+                        if (!(kGbAblate & 2))
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -595,8 +665,9 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
 #pragma unroll
                     for (int pl = 0; pl < GB_PLANES; ++pl)
 #pragma unroll
-                        for (int tb = 0; tb < 4; ++tb) { b[pl][tb] = bn[pl][tb]; asm volatile("" : "+v"(b[pl][tb])); }
+                        for (int tb = 0; tb < 4; ++tb) b[pl][tb] = bn[pl][tb];
                 }
+                slot = slot == NS - 1 ? 0 : slot + 1;
                 __builtin_amdgcn_sched_barrier(0);   // no motion of memory requests across steps (the waits count them in order)
             }
         }
@@ -604,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no DMA may still be in flight towards LDS when the workgroup retires
 #ifdef NTK_GEMM_TRACE
     if (gbt_on) {
+        if (tid == 0) { g_gemm_f16_clock[2] = __builtin_amdgcn_s_memtime(); g_gemm_f16_clock[3] = __builtin_amdgcn_s_memrealtime(); }
         __syncthreads();
         for (int q = tid; q < 4 * GBT_STEPS * GBT_EV; q += 256) (&g_gemm_f16_trace[0][0][0])[q] = gbt[q];
     }
@@ -743,20 +815,33 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     }
     const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
     const size_t lds2 = gb_lds_bytes<DT, 2>(), lds1 = gb_lds_bytes<DT, 1>();
-    static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
     // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0: in a multiple of 64, Q6_K: of
     // 512 -- every projection of the target models; other row pitches take the same kernel with 2-byte aligned reads, slower)
     const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
-    auto go = [&](auto pf, auto alc) {
-        constexpr bool PFc = decltype(pf)::value, ALc = decltype(alc)::value;
-        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, PFc, ALc>), grid, dim3(256), lds2, st, p);
-        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, PFc, ALc>), grid, dim3(256), lds1, st, p);
-    };
-    const bool pf = DeqI<DT>::PF && !no_pf;
-    if (pf && al) go(std::true_type{}, std::true_type{});
-    else if (pf) go(std::true_type{}, std::false_type{});
-    else if (al) go(std::false_type{}, std::true_type{});
-    else go(std::false_type{}, std::false_type{});
+    static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
+    constexpr bool PFD = DeqI<DT>::PF;
+    static const bool lds_ok = [&] {   // more than 64 KB of dynamic LDS: opt in once per kernel
+        bool ok = true;
+        auto set = [&](const void* f, size_t n) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n) == hipSuccess; };
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, PFD>), lds2);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, false, PFD>), lds2);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, true, PFD>), lds1);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, false, PFD>), lds1);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, false>), lds2);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, true, false>), lds1);
+        return ok;
+    }();
+    if (!lds_ok) return NTK_E_LAUNCH;
+    if (al && (no_pf || !PFD)) {   // (NTK_GEMM_NO_PF=1: the A/B switch of the plane prefetch)
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, false>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, true, false>), grid, dim3(256), lds1, st, p);
+    } else if (al) {
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, PFD>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, true, PFD>), grid, dim3(256), lds1, st, p);
+    } else {
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, false, PFD>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, false, PFD>), grid, dim3(256), lds1, st, p);
+    }
     if (nsplit > 1) {
         ReduceArgs ra{};
         ra.nseg = nseg; ra.T = T; ra.nsplit = nsplit; ra.resid = resid;
@@ -777,6 +862,9 @@ extern "C" {
 #ifdef NTK_GEMM_TRACE
 int ntk_debug_gemm_f16_trace(unsigned long long* out, size_t n) {   // n <= 4 * GBT_STEPS * GBT_EV
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemm_f16_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
+int ntk_debug_gemm_f16_clock(unsigned long long* out) {   // 4 values
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemm_f16_clock), 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif
 

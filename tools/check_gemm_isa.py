@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Build-time check of gemm_f16.hip's weight ring (tools, not a product test): the ring registers are written by inline-asm
+global_load_dwordx4 and read by inline-asm ds_write_b128, with explicit s_waitcnt in between -- the compiler does not know the loads
+are asynchronous, so the build is only correct if NO compiler-generated instruction reads or copies those registers.  This script
+compiles the kernel to ISA and checks, per instantiation, that every VGPR written by a ring load appears in no other instruction
+than ring loads and the ds_write_b128 that consume them.
+usage: python tools/check_gemm_isa.py   (exit code 1 on a violation)"""
+import os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "ntransformer_amd", "csrc", "gemm_f16.hip")
+out = os.path.join(tempfile.gettempdir(), "gemm_f16_check.s")
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", src, "-o", out],
+                      cwd=tempfile.gettempdir(), stderr=subprocess.DEVNULL)
+txt = open(out).read()
+bad = 0
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+for m in re.finditer(r"^(_ZN3ntk21gemm_quant_f16_kernel\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
+    name, body = m.group(1), [l.split(";")[0].strip() for l in m.group(2).split("\n")]
+    # the main loop = the backward branch that encloses ring loads
+    labels = {l[:-1]: i for i, l in enumerate(body) if l.endswith(":")}
+    loop = None
+    for i, l in enumerate(body):
+        mb = re.match(r"s_c?branch\w* (\S+)", l)
+        if mb and mb.group(1) in labels and labels[mb.group(1)] < i and any("global_load_dwordx4" in x and "lds" not in x for x in body[labels[mb.group(1)]:i]):
+            loop = (labels[mb.group(1)], i)
+    assert loop, name
+    pending, viol, nring = {}, [], 0   # register -> line of the load that is in flight into it
+    def step(i, l):
+        global nring
+        if not l or l.startswith(".") or l.endswith(":"): return
+        ops = re.findall(r"v\[\d+:\d+\]|v\d+", l)
+        used = set().union(*[regs(o) for o in ops]) if ops else set()
+        if l.startswith("global_load_dwordx4") and "lds" not in l:
+            dst = regs(l.split()[1].rstrip(","))
+            if (used - dst) & set(pending): viol.append((i, l))
+            if dst & set(pending): viol.append((i, l))          # overwritten before it was consumed
+            for r in dst: pending[r] = i
+            nring += 1
+            return
+        if l.startswith("ds_write_b128"):
+            data = regs(ops[1]) if len(ops) > 1 else set()
+            if regs(ops[0]) & set(pending): viol.append((i, l))
+            for r in data: pending.pop(r, None)
+            return
+        if used & set(pending): viol.append((i, l))
+    for i in range(0, loop[1] + 1): step(i, body[i])
+    for i in range(loop[0], loop[1] + 1): step(i, body[i])   # once more around the loop, with what is in flight at the back edge
+    # after the loop nothing may consume the ring; the epilogue's own loads (residual) start after a full drain
+    print("%-70s %3d ring loads seen, in flight at the back edge: %2d registers: %s" % (name, nring, len(pending), "ok" if not viol else "%d VIOLATIONS" % len(viol)))
+    for i, l in viol[:6]: print("    line %d: %s" % (i, l))
+    bad += len(viol)
+sys.exit(1 if bad else 0)

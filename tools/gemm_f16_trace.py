@@ -32,7 +32,11 @@ for dname, gt, out_f, in_f, T in cases:
     buf = (C.c_ulonglong * (4 * STEPS * EV))()
     assert L.ntk_debug_gemm_f16_trace(buf, 4 * STEPS * EV) == 0
     t = np.array(buf[:], dtype=np.uint64).astype(np.int64).reshape(4, STEPS, EV)
-    print("%s %dx%d, %d tokens: %.1f us per call (pre-pass + main [+ reduce])" % (dname, out_f, in_f, T, us))
+    ck = (C.c_ulonglong * 4)()
+    assert L.ntk_debug_gemm_f16_clock(ck) == 0
+    ghz = (ck[2] - ck[0]) / max(1, (ck[3] - ck[1]) * 10.0)   # shader ticks per ns (the constant clock runs at 100 MHz)
+    print("%s %dx%d, %d tokens: %.1f us per call (pre-pass + main [+ reduce]); workgroup 0 ran %.1f us at %.2f GHz (s_memtime / s_memrealtime)"
+          % (dname, out_f, in_f, T, us, (ck[3] - ck[1]) / 100.0, ghz))
     for w in range(4):
         a, b, c = t[w, :, 0], t[w, :, 1], t[w, :, 2]
         ok = (a[1:] > 0) & (a[:-1] > 0)

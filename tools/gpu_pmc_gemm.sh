@@ -1,29 +1,34 @@
 #!/bin/bash
-# SQ counters of the BF16 prompt GEMM (gemm_quant_bf16_kernel): what do its waves wait on?  (PMC passes, kernel-trace only)
-TAG=${1:-pmcgemm}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+# Counters of the FP16 prompt GEMM (gemm_quant_f16_kernel) during a 1024-token 8B prompt: what do its waves wait on, how busy are
+# the LDS and matrix pipes, how many bytes leave HBM per launch.  (PMC passes, kernel-trace only; TCC counters in their own passes)
+TAG=${1:-pmcgemm}; MIX=${2:-Q8_0}; OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 pass() {  # name counters...
   local n=$1; shift
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o g -- python $R/tools/prefill_bench.py --no-kernels --tokens 1024 --modes 2 > $R/$OUT/$n.log 2> $R/$OUT/$n.err ); echo "pass $n exit $?"
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/$OUT/$n -o g -- python $R/tools/prefill_bench.py --no-kernels --mix $MIX --tokens 1024 --modes 2 > $R/$OUT/$n.log 2> $R/$OUT/$n.err ); echo "pass $n exit $?"
 }
 pass a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS
 pass b SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU
-python - $OUT <<'PY' | tee $OUT/summary.txt
+pass c FETCH_SIZE
+pass d TCC_HIT_sum TCC_MISS_sum
+python - $OUT $MIX <<'PY' | tee $OUT/summary_$MIX.txt
 import csv, sys, collections, re, glob
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if 'gemm_quant_bf16' not in k: continue
-        m = re.search(r'gemm_quant_bf16_kernel<(\d+), *(\d+)', k)
+        if 'gemm_quant_f16' not in k: continue
+        m = re.search(r'gemm_quant_f16_kernel<(\d+), *(\d+)', k)
         acc[(m.group(1), m.group(2), r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
-names = {'2': 'Q8_0', '4': 'Q4_K', '5': 'Q6_K'}
+names = {'2': 'Q8_0', '4': 'Q4_K', '5': 'Q6_K', '6': 'Q5_K'}
+print('# %s 8B, 1024-token prompt; per kernel geometry (grid in threads), averages over its launches' % sys.argv[2])
 for (k, rt, g), c in sorted(acc.items()):
     m = {n: sum(v) / len(v) for n, v in c.items()}
     wc = m.get('SQ_WAVE_CYCLES', 1)
     print('%-5s RT %s grid %-8s' % (names.get(k, k), rt, g), ' '.join('%s=%.3g' % (n.replace('SQ_', ''), v) for n, v in sorted(m.items())))
-    print('      per wave-cycle: wait_any %.0f%% wait_inst %.0f%% (lds %.0f%%) active %.0f%% (valu %.0f%% lds %.0f%%) mfma_busy/busy %.0f%% bank_conflict/lds_active %.0f%%' % (
+    print('      per wave-cycle: wait_any %.0f%% wait_inst %.0f%% (lds %.0f%%) active %.0f%% (valu %.0f%% lds %.0f%%) mfma_busy/busy %.0f%% bank_conflict/lds_active %.0f%%;  HBM fetch %.1f MB per launch (FETCH_SIZE KiB x 2, the gfx950 correction), L2 hit rate %.3f' % (
         100 * m.get('SQ_WAIT_ANY', 0) / wc, 100 * m.get('SQ_WAIT_INST_ANY', 0) / wc, 100 * m.get('SQ_WAIT_INST_LDS', 0) / wc,
         100 * m.get('SQ_ACTIVE_INST_ANY', 0) / wc, 100 * m.get('SQ_ACTIVE_INST_VALU', 0) / wc, 100 * m.get('SQ_ACTIVE_INST_LDS', 0) / wc,
-        100 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, m.get('SQ_BUSY_CYCLES', 1)), 100 * m.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, m.get('SQ_LDS_IDX_ACTIVE', 1))))
+        100 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(1, m.get('SQ_BUSY_CYCLES', 1)), 100 * m.get('SQ_LDS_BANK_CONFLICT', 0) / max(1, m.get('SQ_LDS_IDX_ACTIVE', 1)),
+        m.get('FETCH_SIZE', 0) * 1024 * 2 / 1e6, m.get('TCC_HIT_sum', 0) / max(1.0, m.get('TCC_HIT_sum', 0) + m.get('TCC_MISS_sum', 0))))
 PY
-rm -rf $OUT/a $OUT/b
+rm -rf $OUT/a $OUT/b $OUT/c $OUT/d
