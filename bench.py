@@ -207,7 +207,7 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     ms_fine, calls_fine = prof(False)
     res.update(ms=ms, calls=calls, ms_fine=ms_fine, calls_fine=calls_fine, gemv_bytes_tok=_gemv_bytes_per_token(spec, mix))
     # ---- prompt pass, outside the timed decode region: one 1024-token prompt through the batched
-    # projections (BF16 matrix cores) and the matrix-core prompt attention; second of two runs, host-timed around the sync
+    # projections (FP16 matrix cores) and the matrix-core prompt attention; second of two runs, host-timed around the sync
     res["prompt"] = None
     if getattr(args, "prompt_bench", 0) and args.ctx >= args.prompt_bench:
         try:
@@ -216,7 +216,8 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
             t0 = time.perf_counter()
             eng.forward(long_prompt, 0)
             dt = time.perf_counter() - t0
-            res["prompt"] = {"tokens": args.prompt_bench, "ms": round(dt * 1e3, 2), "tokens_per_s": round(args.prompt_bench / dt, 1)}
+            res["prompt"] = {"tokens": args.prompt_bench, "ms": round(dt * 1e3, 2), "tokens_per_s": round(args.prompt_bench / dt, 1),
+                             "activation_form": "two FP16 pieces per F32 activation, per-token power-of-two scale (|error| <= 2^-23 |x|: csrc/gemm_f16.hip)"}
         except Exception as e:   # never at the expense of the decode number
             res["prompt"] = {"tokens": args.prompt_bench, "error": repr(e)}
     eng.close()

@@ -208,13 +208,18 @@ int      ntk_ipc_close(void* devptr);
 int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features,
                    int weight_dtype, const float* resid, void* stream);
 
-/* The same projection on the BF16 matrix cores, up to 1024 tokens per pass over W (csrc/gemm_bf16.hip): the integer part of every
- * weight is exact in BF16, every F32 activation is split into three exact BF16 pieces, products accumulate in F32 and the block
- * scales / K-quant minima are applied to the F32 block sums -- no operand is rounded, only the summation order differs from ntk_gemv.
+/* The same projection on the FP16 matrix cores, up to 1024 tokens per pass over W (csrc/gemm_f16.hip).  Arithmetic: the integer part
+ * of every weight is exact in FP16; every F32 activation x is scaled by a power of two s (one per token: the token's largest |x| s
+ * lies in [2^14, 2^15)) and split into two FP16 pieces h1 = rn16(x s), h2 = rn16(x s - h1), so that |x s - h1 - h2| <= 2^-23 |x s|
+ * -- one F32 ulp of the activation (and <= 2^-39 of the token's largest |x| for activations more than 2^17 below it); the
+ * FP16 x FP16 products are exact in the F32 accumulator, block scales / K-quant minima are applied to the F32 block sums and 1 / s
+ * to the finished sum (exact).  Against ntk_gemv the summation order differs and the activations carry that one-ulp rounding.
  * Limits: Q8_0, Q4_K, Q5_K and Q6_K (NTK_E_DTYPE otherwise: use ntk_gemm_quant); in_features a multiple of the format's block (32 / 256),
  * out_features % 16 == 0 and out_features * row_bytes < 4 GiB (NTK_E_SHAPE); W, X, Y, resid 16-byte aligned (NTK_E_ALIGN).
- * workspace: ntk_gemm_quant_workspace_bytes(in_features, out_features) device bytes, 16-byte aligned, shared by every call (BF16
- * planes of up to sixteen 64-token chunks of X + the partial sums of the K splits); contents need no initialisation.
+ * (Row pitches that are not a multiple of 4 bytes -- Q8_0 with in_features % 64 != 0, Q6_K with in_features % 512 != 0 -- run the
+ * same kernel with 2-byte aligned LDS reads, several times slower; no projection of the target models has one.)
+ * workspace: ntk_gemm_quant_workspace_bytes(in_features, out_features) device bytes, 16-byte aligned, shared by every call (the FP16
+ * planes and scales of up to sixteen 64-token chunks of X + the partial sums of the K splits); contents need no initialisation.
  * reuse_x != 0: X (same pointer, n_tokens <= 1024) has not changed since the previous call with this workspace -- its planes are
  * not rebuilt (Q, K, V / gate, up share x).  Stream ordered, no allocation, no synchronisation. */
 size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features);

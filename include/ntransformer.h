@@ -60,7 +60,7 @@ typedef struct nt_synth_spec { /* seeded synthetic Llama-shaped model (no checkp
 
 int  nt_engine_load_ex(nt_engine_t e, const char* model_path, int max_context);
 int  nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_context);
-/* "fused" / "graph" / "device_sampling" / "batched_prefill" / "bf16_prefill" = "0" | "1"; "persistent" / "fuse_attention" are accepted
+/* "fused" / "graph" / "device_sampling" / "batched_prefill" / "f16_prefill" (alias "bf16_prefill") = "0" | "1"; "persistent" / "fuse_attention" are accepted
  * everywhere and take effect only in EXPERIMENTS=1 builds (include/ntk_experiments.h) */
 int  nt_engine_set_option(nt_engine_t e, const char* key, const char* value);
 const char* nt_engine_last_error(nt_engine_t e);

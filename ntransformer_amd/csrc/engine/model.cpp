@@ -443,11 +443,11 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
     const bool batched = batched_prefill_ && T > 1;
     // (a prompt of <= 16 tokens is one pass of the F32-MFMA GEMM, with no operand pre-pass: measured 2 217 vs 1 727 tok/s at 16)
     const bool bf16_now = bf16_prefill_ && gemm_ws_ && T > 16;
-    const float* planes_of = nullptr;   // the x whose BF16 planes sit in gemm_ws_ (Q, K, V and gate, up share one x)
+    const float* planes_of = nullptr;   // the x whose FP16 planes sit in gemm_ws_ (Q, K, V and gate, up share one x)
     auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
         if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
-            if (bf16_now)   // BF16 matrix cores, 256 tokens per pass (Q8_0 / Q4_K / Q6_K)
+            if (bf16_now)   // FP16 matrix cores, up to 1024 tokens per pass (Q8_0 / Q4_K / Q5_K / Q6_K)
                 st = ntk_gemm_quant_ws(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
                                        X == planes_of ? 1 : 0, s);
             if (st == NTK_OK) planes_of = X;
@@ -457,7 +457,7 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
         }
         for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, X + (size_t)t * xstride);
     };
-    // matrices that share X (Q | K | V, gate | up): those of one format go out as ONE launch of the BF16 GEMM, the rest one by one
+    // matrices that share X (Q | K | V, gate | up): those of one format go out as ONE launch of the FP16 GEMM, the rest one by one
     auto project_many = [&](float* const* Ys, const DevTensor* const* Ws, int n, const float* X) {
         bool done[3] = {false, false, false};
         if (batched && bf16_now) {

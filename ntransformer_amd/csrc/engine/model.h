@@ -83,7 +83,7 @@ public:
     // longer ones keep the launch path.  Turned off for good if the kernel ever reports a bounded wait that gave up.
     void set_persistent(bool on);   // EXPERIMENTS=1 builds only; otherwise stays off
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
-    void set_bf16_prefill(bool on) { bf16_prefill_ = on; }   // batched prompt: BF16-MFMA (64 tokens / pass) or the F32-MFMA form (16)
+    void set_bf16_prefill(bool on) { bf16_prefill_ = on; }   // batched prompt: FP16-MFMA (gemm_f16.hip; the option keeps its round-2 name) or the F32-MFMA form (16)
     bool persistent_available() const { return persistent_plan_ != nullptr; }
     void* persistent_plan() const { return persistent_plan_; }
     // which form decode_step_fused(…) emits at the current position: "persistent" / "fused launches"
@@ -173,7 +173,7 @@ private:
     int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
     int attn_regime_ = 0;            // regime enqueue_token() emits
     float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention
-    void* gemm_ws_ = nullptr;        // workspace of ntk_gemm_quant_ws (BF16 prompt projections), sized for max(H, I) columns
+    void* gemm_ws_ = nullptr;        // workspace of ntk_gemm_quant_ws (FP16 prompt projections), sized for max(H, I) columns
     size_t gemm_ws_bytes_ = 0;
     bool bf16_prefill_ = true;
     unsigned* attn_sync_ = nullptr;  // 3 words for ntk_attention_gemv_fused (attention producers inside the Wo launch)

@@ -358,6 +358,7 @@ struct GemmBParams {
     unsigned row_bytes;
     int nsplit, steps_per_split;   // blockIdx.y = K split; nsplit > 1: partial sums go to seg.part, summed by reduce_splits
     int chunks, row_wgs;    // 64-token chunks of this launch (blockIdx.x enumerates (row tile, chunk), see below); row tiles of all matrices
+    int map8;               // blockIdx.x -> (row tile, chunk) in 8 x 8 blocks per XCD
     size_t chunk_bytes;     // between the planes (and sums) of consecutive chunks
 };
 
@@ -397,11 +398,30 @@ __global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    // blockIdx.x -> (row tile, token chunk).  Workgroups go to the 8 XCDs round-robin; the `chunks` workgroups that share a row
-    // tile's weights get ids 8 apart (same XCD, same L2, dispatched back to back): id = 8 * (chunks * (tile / 8) + chunk) + tile % 8
+    // blockIdx.x -> (row tile, token chunk).  Workgroups go to the 8 XCDs round-robin and every XCD takes its share in id order, 64 at a
+    // time (2 per CU): XCD x owns the row tiles x, x + 8, ... and walks them in blocks of (8 row tiles) x (8 token chunks) -- the 64
+    // workgroups resident on an XCD then share 8 weight streams and 8 activation streams through its L2 (per 32-column step 8 x 4.4 KB
+    // + 8 x 8.3 KB leave the L2 towards the fabric; the round-2 order, all 16 chunks of 4 row tiles, 4 x 4.4 + 16 x 8.3 KB).
     const int bid = (int)blockIdx.x;
-    const int xcd = bid & 7, within = bid >> 3;
-    const int chunk = within % p.chunks, tile = (within / p.chunks) * 8 + xcd;
+    const int xcd = bid & 7;
+    int chunk, tile;
+    if (p.map8) {
+        int w = bid >> 3;
+        const int tiles_x = (p.row_wgs + 7) >> 3;                       // row tiles of this XCD (the grid is padded to whole eights)
+        const int ntg = (tiles_x + 7) >> 3, ncg = (p.chunks + 7) >> 3;
+        const int tg = min(w / (8 * p.chunks), ntg - 1);
+        w -= tg * 8 * p.chunks;
+        const int tsz = min(8, tiles_x - 8 * tg);
+        const int cg = min(w / (tsz * 8), ncg - 1);
+        w -= cg * tsz * 8;
+        const int csz = min(8, p.chunks - 8 * cg);
+        chunk = 8 * cg + w % csz;
+        tile = (8 * tg + w / csz) * 8 + xcd;
+    } else {   // (NTK_GEMM_MAP=0: the chunks of a row tile 8 ids apart, tile after tile)
+        const int within = bid >> 3;
+        chunk = within % p.chunks;
+        tile = (within / p.chunks) * 8 + xcd;
+    }
     if (tile >= p.row_wgs) return;   // row tiles are padded to a multiple of 8
 #ifdef NTK_GEMM_TRACE
     unsigned long long* gbt = reinterpret_cast<unsigned long long*>(gb_lds + STAGE_OFF + 4 * 16 * RT * DeqI<DT>::STRIDE);
@@ -787,6 +807,8 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     }
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
     // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) while fewer than one workgroup per CU exists.
+    static const int map8 = [] { const char* e = getenv("NTK_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    p.map8 = map8;
     static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
     static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 256; }();
     int rt = out_total >= 2048 ? 2 : 1;

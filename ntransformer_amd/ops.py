@@ -181,7 +181,7 @@ def gemm_quant_ws_multi(segs, X, n_tokens, in_features, stream=None):
 
 
 def gemm_quant_ws(Y, W, X, n_tokens, out_features, in_features, dtype, resid=None, stream=None):
-    """ntk_gemm_quant_ws: BF16-MFMA prompt projection, 64 tokens per pass (workspace allocated here)."""
+    """ntk_gemm_quant_ws: FP16-MFMA prompt projection, 64-token chunks, up to 1024 tokens per pass (workspace allocated here)."""
     L = _lib.lib()
     L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
     n = int(L.ntk_gemm_quant_workspace_bytes(C.c_int(in_features), C.c_int(out_features)))

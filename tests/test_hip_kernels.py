@@ -144,16 +144,16 @@ def gemm_ws_gpu(Wraw, X, out_f, in_f, dt, resid=None):
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048),
                                           (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672), (300, 64, 512), (520, 48, 1024), (1100, 32, 256)])
-def test_gemm_quant_bf16_matches_per_token_oracle(qname, T, out_f, in_f):
-    """ntk_gemm_quant_ws (BF16 matrix cores, integer weights x three exact BF16 pieces of every activation, 64 tokens per
+def test_gemm_quant_f16_matches_per_token_oracle(qname, T, out_f, in_f):
+    """ntk_gemm_quant_ws (FP16 matrix cores, integer weights x two FP16 pieces of every scaled activation, 64 tokens per
     pass) against the oracle's GEMV applied token by token -- what the reference's prefill loop computes
     (attention.cpp:144-162, ffn.cpp:96-133): ragged token counts, 1 / 2 row tiles per wave, both row-tile geometries,
-    K-quant sub-scales and minima, Q6_K's 16-column sub-scales.  Same tolerance as the F32-MFMA path: only the summation order
-    differs."""
+    K-quant sub-scales and minima, Q6_K's 16-column sub-scales, row pitches with and without dword alignment.  Same tolerance as
+    the F32-MFMA path: the summation order differs and every activation carries at most one F32 ulp of rounding."""
     gt = QUANT[qname]
     r = rng(T * 1000 + out_f * 7 + in_f + gt + 1)
     W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
-    X = (r.standard_normal((T, in_f)) * np.exp(r.uniform(-6, 6, (T, 1)))).astype(np.float32)   # token scales over e^+-6: the split must be exact at every magnitude
+    X = (r.standard_normal((T, in_f)) * np.exp(r.uniform(-6, 6, (T, 1)))).astype(np.float32)   # token scales over e^+-6: the per-token scale must absorb them
     dt = G.GGML_TO_DT[gt]
     ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
     Y = gemm_ws_gpu(W, X, out_f, in_f, dt)
@@ -166,9 +166,39 @@ def test_gemm_quant_bf16_matches_per_token_oracle(qname, T, out_f, in_f):
 
 
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+def test_gemm_quant_f16_outlier_channels_and_degenerate_tokens(qname):
+    """The per-token scale of the FP16 split (csrc/gemm_f16.hip) under the activations that stress it: outlier channels 10^4 above the
+    rest of the token (the small ones fall into the second piece's subnormal range: absolute error <= 2^-39 of the outlier), tokens
+    of all zeros, tokens at the ends of the F32 range, one element per token.  Against the oracle's F32 GEMV; the bound is the
+    split's: 2^-22 sum |w x| (both pieces' roundings, with room) plus the summation-order term of every other GEMM test."""
+    gt = QUANT[qname]
+    dt = G.GGML_TO_DT[gt]
+    r = rng(4242 + gt)
+    T, out_f, in_f = 70, 96, 2048
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    X[0:20, ::97] *= 1e4                       # outlier channels
+    X[20] = 0.0                                # a token of zeros
+    X[21] = 0.0; X[21, 5] = 3.0                # one element
+    X[22] *= 1e30; X[23] *= 1e-30              # ends of the F32 range (no overflow in s x: s = 2^(14 - exponent))
+    X[24:30] *= np.exp(r.uniform(-20, 20, (6, in_f))).astype(np.float32)   # 17 orders of magnitude inside one token
+    Wf = np.stack([O.embed_row(W, row, in_f, dt) for row in range(out_f)]).astype(np.float64)   # the dequantised weights (oracle's row decoder)
+    ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
+    Y = gemm_ws_gpu(W, X, out_f, in_f, dt)
+    assert np.isfinite(Y[:22]).all() and np.isfinite(Y[23:]).all()
+    for t in range(T):
+        if t == 22: continue   # (|w x| sums beyond the F32 range for some rows: compared below where finite)
+        bound = 2.0 ** -22 * (np.abs(Wf) @ np.abs(X[t].astype(np.float64))) + tol_for(ref[t], in_f)
+        assert (np.abs(Y[t] - ref[t]) <= bound).all(), (t, np.abs(Y[t] - ref[t]).max(), bound.min())
+    fin = np.isfinite(ref[22])
+    assert np.allclose(Y[22][fin], ref[22][fin], rtol=1e-5, atol=0)
+    assert np.array_equal(Y[20], np.zeros(out_f, np.float32))
+
+
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
 @pytest.mark.parametrize("T,outs,in_f", [(20, (64, 32, 32), 512), (70, (4096, 1024, 1024), 4096), (300, (208, 208), 2048)])
-def test_gemm_quant_bf16_several_matrices_one_launch(qname, T, outs, in_f):
-    """Q | K | V and gate | up as ONE launch of the BF16 GEMM (ntk_gemm_quant_ws_multi): every matrix against its own
+def test_gemm_quant_f16_several_matrices_one_launch(qname, T, outs, in_f):
+    """Q | K | V and gate | up as ONE launch of the FP16 GEMM (ntk_gemm_quant_ws_multi): every matrix against its own
     single-matrix launch, bit for bit (same tiles, same summation order), and against the oracle."""
     gt = QUANT[qname]
     dt = G.GGML_TO_DT[gt]
@@ -191,8 +221,8 @@ def test_gemm_quant_bf16_several_matrices_one_launch(qname, T, outs, in_f):
     assert ops.gemm_quant_ws_multi([(Wd[0], Yd[0], outs[0], dt), (Wd[1], Yd[1], outs[1], G.DT_Q4_0)], Xd, T, in_f) == -2   # mixed formats
 
 
-def test_gemm_quant_bf16_full_size_and_rejections():
-    """8B gate/up-sized matrix (14336 x 4096: the 2-row-tile geometry with 112 workgroups) and what the BF16 path refuses."""
+def test_gemm_quant_f16_full_size_and_rejections():
+    """8B gate/up-sized matrix (14336 x 4096: the 2-row-tile geometry with 112 workgroups) and what the FP16 path refuses."""
     gt = G.GGML_Q8_0
     r = rng(99)
     out_f, in_f, T = 14336, 4096, 64
@@ -203,7 +233,7 @@ def test_gemm_quant_bf16_full_size_and_rejections():
         ref = O.gemv(W, X[t], out_f, in_f, G.GGML_TO_DT[gt])
         assert np.abs(Y[t] - ref).max() <= tol_for(ref, in_f)
     Wd, Xd, Yd = DB.zeros(1 << 16), DB.zeros(1 << 16), DB.zeros(1 << 16)
-    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_Q4_0) == -1      # format outside the BF16 path: caller uses ntk_gemm_quant
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_Q4_0) == -1      # format outside the FP16 path: caller uses ntk_gemm_quant
     assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 10, 256, G.DT_Q8_0) == -2      # out_features not a multiple of 16
 
 

@@ -66,7 +66,7 @@ def test_ranks_sharing_a_process_match_the_unsliced_engine(name, shape, mix, wor
     path, z = golden_model(name, shape, mix, tmp_path)
     ctx = int(z["ctx"])
     r = np.random.Generator(np.random.Philox(key=[20260925, 7]))
-    prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, 20)]   # > 16 tokens: the BF16 prompt GEMM under slices
+    prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, 20)]   # > 16 tokens: the FP16 prompt GEMM under slices
     fed = [int(t) for t in r.integers(0, 256, 5)]
     ref_logits, ref_toks, _ = _single(path, ctx, prompt, fed, graph)
     want = _oracle_logits(path, ctx, prompt, fed)

@@ -27,6 +27,7 @@ for m in re.finditer(r"^(_ZN3ntk21gemm_quant_f16_kernel\w+):[^\n]*\n(.*?)s_endpg
         mb = re.match(r"s_c?branch\w* (\S+)", l)
         if mb and mb.group(1) in labels and labels[mb.group(1)] < i and any("global_load_dwordx4" in x and "lds" not in x for x in body[labels[mb.group(1)]:i]):
             loop = (labels[mb.group(1)], i)
+            break   # the first such branch closes the main loop (later ones belong to out-of-line blocks placed behind the epilogue)
     assert loop, name
     pending, viol, nring = {}, [], 0   # register -> line of the load that is in flight into it
     def step(i, l):
@@ -49,6 +50,24 @@ for m in re.finditer(r"^(_ZN3ntk21gemm_quant_f16_kernel\w+):[^\n]*\n(.*?)s_endpg
         if used & set(pending): viol.append((i, l))
     for i in range(0, loop[1] + 1): step(i, body[i])
     for i in range(loop[0], loop[1] + 1): step(i, body[i])   # once more around the loop, with what is in flight at the back edge
+    # blocks placed out of line (behind the epilogue) that the loop branches to and back from: no ring register at all in them
+    ring_all = set()
+    for i in range(loop[0], loop[1] + 1):
+        l = body[i]
+        if l.startswith("global_load_dwordx4") and "lds" not in l: ring_all |= regs(l.split()[1].rstrip(","))
+    for i in range(loop[0], loop[1] + 1):
+        mb = re.match(r"s_c?branch\w* (\S+)", body[i])
+        if mb and labels.get(mb.group(1), 0) > loop[1]:
+            q = labels[mb.group(1)] + 1
+            blk = []
+            while q < len(body) and not body[q].startswith("s_branch") and not body[q].startswith("s_endpgm"):
+                blk.append(q); q += 1
+            back = re.match(r"s_branch (\S+)", body[q]) if q < len(body) else None
+            if not (back and loop[0] <= labels.get(back.group(1), -1) <= loop[1]): continue   # the loop's exit, not an out-of-line block
+            for q in blk:
+                ops = re.findall(r"v\[\d+:\d+\]|v\d+", body[q])
+                used = set().union(*[regs(o) for o in ops]) if ops else set()
+                if used & ring_all: viol.append((q, body[q]))
     # after the loop nothing may consume the ring; the epilogue's own loads (residual) start after a full drain
     print("%-70s %3d ring loads seen, in flight at the back edge: %2d registers: %s" % (name, nring, len(pending), "ok" if not viol else "%d VIOLATIONS" % len(viol)))
     for i, l in viol[:6]: print("    line %d: %s" % (i, l))

@@ -37,8 +37,8 @@ def main():
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-matrix table")
     ap.add_argument("--mixes", default="Q8_0,Q4_K,Q6_K", help="per-matrix table: weight formats")
     ap.add_argument("--tokens", default="16,64,256,1024", help="engine part: prompt lengths")
-    ap.add_argument("--modes", default="2,1,0", help="engine part: 2 = BF16 GEMM, 1 = F32-MFMA GEMM, 0 = per-token loop (<= 64 tokens only)")
-    ap.add_argument("--bf16-only", action="store_true", help="per-matrix table: only the BF16 GEMM launches (profiling)")
+    ap.add_argument("--modes", default="2,1,0", help="engine part: 2 = FP16 GEMM, 1 = F32-MFMA GEMM, 0 = per-token loop (<= 64 tokens only)")
+    ap.add_argument("--bf16-only", action="store_true", help="per-matrix table: only the FP16 GEMM launches (profiling; the flag keeps its round-2 name)")
     a = ap.parse_args()
     ops.init(0)
     import ctypes as C
@@ -57,7 +57,7 @@ def main():
             X = DB.from_numpy(rng.standard_normal((T, in_f)).astype(np.float32))
             Y = DB.zeros(T * out_f * 4)
             t_gemm = 0.0 if a.bf16_only else timed(lambda: ops.gemm_quant(Y, W, X, T, out_f, in_f, dt), 20)
-            if dname in ("Q8_0", "Q4_K", "Q6_K") and out_f % 16 == 0:   # BF16 matrix cores, 64 tokens per pass
+            if dname in ("Q8_0", "Q4_K", "Q6_K") and out_f % 16 == 0:   # FP16 matrix cores, 64-token chunks
                 ws_n = int(L.ntk_gemm_quant_workspace_bytes(in_f, out_f))
                 ws = DB(ws_n)
                 for TT in (64, 256):
@@ -85,7 +85,7 @@ def main():
         for T in [int(t) for t in a.tokens.split(',')]:
             modes = [m for m in want_modes if m > 0 or T <= 64]
             prompt = [128000] + [int(t) for t in r.integers(0, 128000, T - 1)]
-            for batched in modes:   # 2: BF16 MFMA, 64 tokens per pass; 1: F32 MFMA, 16 per pass; 0: the reference's per-token loop
+            for batched in modes:   # 2: FP16 MFMA, 64-token chunks; 1: F32 MFMA, 16 per pass; 0: the reference's per-token loop
                 eng.set_option("batched_prefill", batched > 0)
                 eng.set_option("bf16_prefill", batched == 2)
                 eng.forward(prompt, 0)
