@@ -49,6 +49,11 @@ constexpr int GB_MAX_CHUNKS = 16;   // 64-token chunks per launch (32 measured n
 constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
 constexpr int GB_PLANES = 2;         // FP16 pieces of an activation
 constexpr int GB_STEP_BYTES = GB_PLANES * 4 * GB_PIECE;   // 8 KB of activation operands per step
+#ifdef NTK_GEMM_OCC3   // tuning build: three workgroups (12 waves) per CU -- 168 VGPRs, 53 KB of LDS each (Q8_0 without the plane prefetch fits)
+constexpr int GB_WG_PER_CU = 3, GB_LDS_WG = 53 * 1024, GB_NRING_Q8 = 1;
+#else
+constexpr int GB_WG_PER_CU = 2, GB_LDS_WG = 80 * 1024, GB_NRING_Q8 = 2;
+#endif
 constexpr int GB_AUX_BYTES = GB_TOK * 4;                  // per step: the 64 tokens' sums of x s (K-quant minimum term)
 
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {   // two small integers -> FP16 pair (exact)
@@ -185,7 +190,7 @@ template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
     static constexpr int BW = 32, BB = 34;
     static constexpr int SPU = 4, UB = 136, NCH = 10, STRIDE = 176;   // window: shift (0, 4, 8 or 12) + 136 <= 160
     static constexpr int ROW_ALIGN = 4;                               // row pitch: in_features a multiple of 64
-    static constexpr int NRING = 2;                                   // units in flight per wave (register ring): 8 steps ahead of the MFMAs
+    static constexpr int NRING = GB_NRING_Q8;                         // units in flight per wave (register ring): 8 steps ahead of the MFMAs
     static constexpr bool SPLIT16 = false, HAS_MIN = false, PF = true;
     struct Hdr {};
     struct Raw { uint32_t w0, w1, w2, w3, d; };
@@ -332,10 +337,9 @@ constexpr int GB_UPT = 2;     // units per loop trip (Q6_K: the parity of a unit
 // LDS of a workgroup: a ring of NS activation step records (8 KB each, filled by LDS-DMA NS - 1 steps ahead), the ring of the steps'
 // per-token sums, the 4 waves' weight images.  NS = as many slots as leave room for two workgroups per CU (160 KB): a record that
 // misses the XCD's L2 takes ~2 us to arrive, and the records in flight are what hides it (a step consumes one in 0.3-0.4 us)
-constexpr int GB_LDS_WG = 80 * 1024;
 template <int DT, int RT> constexpr int gb_slots() {
     const int n = (GB_LDS_WG - 4 * 16 * RT * DeqI<DT>::STRIDE - GB_TRACE_LDS) / (GB_STEP_BYTES + GB_AUX_BYTES);
-    return n > 8 ? 8 : n;
+    return n > 8 ? 8 : (n < 3 ? 3 : n);
 }
 template <int DT, int RT> constexpr int gb_lds_bytes() { return gb_slots<DT, RT>() * (GB_STEP_BYTES + GB_AUX_BYTES) + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS; }
 
@@ -386,14 +390,14 @@ __device__ __forceinline__ void gb_dma16x2(uint32_t lds_dst, const uint8_t* gsrc
 //   planes were consumed a step ago | LDS reads: the step's sums, the raw weight dwords of step s + 2, the step's activation planes |
 //   4 x (2 RT MFMAs, the token block's scale-FMAs), the conversion of step s + 1's weight operand in their shadow.
 template <int DT, int RT, bool AL, bool PF>
-__global__ __launch_bounds__(256, 2) void gemm_quant_f16_kernel(const GemmBParams p) {
+__global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const GemmBParams p) {
     using D = DeqI<DT>;
     constexpr int SPU = D::SPU, NCH = D::NCH, STRIDE = D::STRIDE;
     constexpr int ROWS = 16 * RT, PIECES = ROWS * NCH, NLD = (PIECES + 63) / 64;   // 16-byte pieces of a unit; requests per lane
     constexpr int NRING = D::NRING;
     constexpr int NS = gb_slots<DT, RT>();                  // activation ring: slots
     constexpr int XS_OFF = NS * GB_STEP_BYTES, STAGE_OFF = XS_OFF + NS * GB_AUX_BYTES;
-    static_assert(GB_UPT % NRING == 0 && NS >= 4 && NS - 2 <= GB_UPT * SPU, "a trip must cover whole turns of the weight ring");
+    static_assert(GB_UPT % NRING == 0 && NS >= 3 && NS - 2 <= GB_UPT * SPU, "a trip must cover whole turns of the weight ring");
     extern __shared__ __attribute__((aligned(16))) uint8_t gb_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -185,13 +185,10 @@ def test_gemm_quant_f16_outlier_channels_and_degenerate_tokens(qname):
     Wf = np.stack([O.embed_row(W, row, in_f, dt) for row in range(out_f)]).astype(np.float64)   # the dequantised weights (oracle's row decoder)
     ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
     Y = gemm_ws_gpu(W, X, out_f, in_f, dt)
-    assert np.isfinite(Y[:22]).all() and np.isfinite(Y[23:]).all()
+    assert np.isfinite(Y).all() and np.isfinite(ref).all()
     for t in range(T):
-        if t == 22: continue   # (|w x| sums beyond the F32 range for some rows: compared below where finite)
         bound = 2.0 ** -22 * (np.abs(Wf) @ np.abs(X[t].astype(np.float64))) + tol_for(ref[t], in_f)
-        assert (np.abs(Y[t] - ref[t]) <= bound).all(), (t, np.abs(Y[t] - ref[t]).max(), bound.min())
-    fin = np.isfinite(ref[22])
-    assert np.allclose(Y[22][fin], ref[22][fin], rtol=1e-5, atol=0)
+        assert (np.abs(Y[t].astype(np.float64) - ref[t]) <= bound).all(), (t, np.abs(Y[t] - ref[t]).max(), bound.min())
     assert np.array_equal(Y[20], np.zeros(out_f, np.float32))
 
 
