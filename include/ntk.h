@@ -214,7 +214,7 @@ int ntk_gemm_quant(float* Y, const void* W, const float* X, int n_tokens, int ou
  * -- one F32 ulp of the activation (and <= 2^-39 of the token's largest |x| for activations more than 2^17 below it); the
  * FP16 x FP16 products are exact in the F32 accumulator, block scales / K-quant minima are applied to the F32 block sums and 1 / s
  * to the finished sum (exact).  Against ntk_gemv the summation order differs and the activations carry that one-ulp rounding.
- * Limits: Q8_0, Q4_K, Q5_K and Q6_K (NTK_E_DTYPE otherwise: use ntk_gemm_quant); in_features a multiple of the format's block (32 / 256),
+ * Limits: Q8_0, Q4_0, Q4_K, Q5_K and Q6_K (NTK_E_DTYPE otherwise: use ntk_gemm_quant); in_features a multiple of 128 (Q8_0) / 256 (the others),
  * out_features % 16 == 0 and out_features * row_bytes < 4 GiB (NTK_E_SHAPE); W, X, Y, resid 16-byte aligned (NTK_E_ALIGN).
  * (Row pitches that are not a multiple of 4 bytes -- Q8_0 with in_features % 64 != 0, Q6_K with in_features % 512 != 0 -- run the
  * same kernel with 2-byte aligned LDS reads, several times slower; no projection of the target models has one.)

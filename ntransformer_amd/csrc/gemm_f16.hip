@@ -213,6 +213,36 @@ template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
     }
 };
 
+template <> struct DeqI<NTK_DT_Q4_0> {   // types.h:97-100: half d, 16 bytes of nibbles: w_j = d (lo_j - 8), w_{j+16} = d (hi_j - 8)  (gemm.cu:32-86)
+    static constexpr int BW = 32, BB = 18;
+    static constexpr int SPU = 8, UB = 144, NCH = 10, STRIDE = 176;   // unit = 8 blocks; window: shift (<= 14) + 144 <= 160
+    static constexpr int ROW_ALIGN = 4, NRING = 1;                    // row pitch: in_features a multiple of 64
+    static constexpr bool SPLIT16 = false, HAS_MIN = false, PF = true;
+    struct Hdr {};
+    struct Raw { uint32_t w0, w1, d; };
+    __device__ static Hdr header(const uint8_t*, const uint8_t*) { return Hdr{}; }
+    // the lane's columns {4g..4g+3} and {16+4g..16+4g+3} are the low and high nibbles of the SAME four bytes: one dword per step, 2 bytes
+    // past a dword boundary for even j (18 j + 2), on one for odd j
+    template <bool AL> __device__ static Raw load(const uint8_t* row, const uint8_t* rowg, const Hdr&, int j, int) {
+        Raw r;
+        if (!AL || (j & 1)) { r.w0 = lds32<AL>(rowg + 18 * j + 2); r.w1 = 0; }
+        else { r.w0 = lds32<AL>(rowg + 18 * j); r.w1 = lds32<AL>(rowg + 18 * j + 4); }
+        r.d = lds16(row + 18 * j);
+        return r;
+    }
+    template <bool AL> __device__ static AOp convert(const Raw& r, int j, int) {
+        const uint32_t q = (!AL || (j & 1)) ? r.w0 : mid32(r.w0, r.w1);
+        const u32x4 qa = cvt8_u8_f16(q & 0x0F0F0F0Fu, (q >> 4) & 0x0F0F0F0Fu);
+        const f16x2 m8 = {(_Float16)-8.0f, (_Float16)-8.0f};
+        auto sub8 = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, (f16x2)(__builtin_bit_cast(f16x2, w) + m8)); };
+        AOp o;   // n - 8: exact small integers
+        o.a = u32x4{sub8(qa.x), sub8(qa.y), sub8(qa.z), sub8(qa.w)};
+        o.s0 = o.s1 = h2f((uint16_t)r.d);
+        o.mn = 0.0f;
+        return o;
+    }
+};
+
 template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 packed 6-bit (scale, min); 128 bytes of nibbles
     static constexpr int BW = 256, BB = 144;
     static constexpr int SPU = 8, UB = 144, NCH = 9, STRIDE = 144;     // rows are 16-byte aligned: no shift
@@ -783,7 +813,9 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
                             hipStream_t st) {
     using D = DeqI<DT>;
     constexpr int TRIP = GB_UPT * D::SPU;   // steps per loop trip: K ranges are whole trips
-    if (nseg < 1 || nseg > GB_MAX_SEG || (resid && nseg != 1) || in % D::BW != 0) return NTK_E_SHAPE;
+    // whole units only (Q8_0: in a multiple of 128, Q4_0 and the K-quants: of 256): a partial last unit would decode the next row's bytes as
+    // scales -- any bit pattern, NaNs included -- against the zero activations of the padding steps
+    if (nseg < 1 || nseg > GB_MAX_SEG || (resid && nseg != 1) || in % (32 * D::SPU) != 0) return NTK_E_SHAPE;
     const size_t row_bytes = (size_t)in / D::BW * D::BB;
     long out_total = 0;
     for (int i = 0; i < nseg; ++i) {
@@ -913,6 +945,7 @@ static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, 
         int rc;
         switch (weight_dtype) {
             case NTK_DT_Q8_0: rc = ntk::launch_gemm_f16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q4_0: rc = ntk::launch_gemm_f16<NTK_DT_Q4_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
             case NTK_DT_Q4_K: rc = ntk::launch_gemm_f16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
             case NTK_DT_Q5_K: rc = ntk::launch_gemm_f16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
             default: rc = ntk::launch_gemm_f16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
@@ -927,7 +960,7 @@ int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int
     if (!Y || !W || !X || !workspace) return NTK_E_NULL;
     if (n_tokens < 0 || out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
-    if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
     const ntk::HostSeg sg{Y, W, out_features};
     return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, ntk::resolve_stream(stream));
@@ -948,7 +981,7 @@ int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, 
         total += segs[i].rows;
     }
     const int dt = segs[0].dtype;
-    if (dt != NTK_DT_Q8_0 && dt != NTK_DT_Q4_K && dt != NTK_DT_Q5_K && dt != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (dt != NTK_DT_Q8_0 && dt != NTK_DT_Q4_0 && dt != NTK_DT_Q4_K && dt != NTK_DT_Q5_K && dt != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, (int)total) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
     if (n_tokens == 0) return NTK_OK;
     return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, ntk::resolve_stream(stream));

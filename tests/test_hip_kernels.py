@@ -141,8 +141,8 @@ def gemm_ws_gpu(Wraw, X, out_f, in_f, dt, resid=None):
     return Yd.numpy(np.float32).reshape(T, out_f)
 
 
-@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q5_K", "Q6_K"])
-@pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048),
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q5_K", "Q6_K"])
+@pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048), (9, 32, 768),
                                           (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672), (300, 64, 512), (520, 48, 1024), (1100, 32, 256)])
 def test_gemm_quant_f16_matches_per_token_oracle(qname, T, out_f, in_f):
     """ntk_gemm_quant_ws (FP16 matrix cores, integer weights x two FP16 pieces of every scaled activation, 64 tokens per
@@ -165,7 +165,7 @@ def test_gemm_quant_f16_matches_per_token_oracle(qname, T, out_f, in_f):
     assert np.array_equal(Y2, (R + Y).astype(np.float32)) or np.abs(Y2 - (R + Y)).max() <= 1e-6 * np.abs(Y).max()
 
 
-@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q6_K"])
 def test_gemm_quant_f16_outlier_channels_and_degenerate_tokens(qname):
     """The per-token scale of the FP16 split (csrc/gemm_f16.hip) under the activations that stress it: outlier channels 10^4 above the
     rest of the token (the small ones fall into the second piece's subnormal range: absolute error <= 2^-39 of the outlier), tokens
@@ -192,7 +192,7 @@ def test_gemm_quant_f16_outlier_channels_and_degenerate_tokens(qname):
     assert np.array_equal(Y[20], np.zeros(out_f, np.float32))
 
 
-@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q6_K"])
 @pytest.mark.parametrize("T,outs,in_f", [(20, (64, 32, 32), 512), (70, (4096, 1024, 1024), 4096), (300, (208, 208), 2048)])
 def test_gemm_quant_f16_several_matrices_one_launch(qname, T, outs, in_f):
     """Q | K | V and gate | up as ONE launch of the FP16 GEMM (ntk_gemm_quant_ws_multi): every matrix against its own
@@ -215,7 +215,8 @@ def test_gemm_quant_f16_several_matrices_one_launch(qname, T, outs, in_f):
             ref = O.gemv(Ws[i], X[t], o, in_f, dt)
             assert np.abs(got[t] - ref).max() <= tol_for(ref, in_f)
         assert np.abs(got - alone).max() <= 1e-6 * max(1.0, np.abs(alone).max())   # (K split counts may differ between the two launches)
-    assert ops.gemm_quant_ws_multi([(Wd[0], Yd[0], outs[0], dt), (Wd[1], Yd[1], outs[1], G.DT_Q4_0)], Xd, T, in_f) == -2   # mixed formats
+    other = G.DT_Q4_K if dt == G.DT_Q4_0 else G.DT_Q4_0
+    assert ops.gemm_quant_ws_multi([(Wd[0], Yd[0], outs[0], dt), (Wd[1], Yd[1], outs[1], other)], Xd, T, in_f) == -2   # mixed formats
 
 
 def test_gemm_quant_f16_full_size_and_rejections():
@@ -230,8 +231,10 @@ def test_gemm_quant_f16_full_size_and_rejections():
         ref = O.gemv(W, X[t], out_f, in_f, G.GGML_TO_DT[gt])
         assert np.abs(Y[t] - ref).max() <= tol_for(ref, in_f)
     Wd, Xd, Yd = DB.zeros(1 << 16), DB.zeros(1 << 16), DB.zeros(1 << 16)
-    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_Q4_0) == -1      # format outside the FP16 path: caller uses ntk_gemm_quant
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 256, G.DT_F16) == -1       # format outside the FP16 path: caller uses ntk_gemm_quant
     assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 10, 256, G.DT_Q8_0) == -2      # out_features not a multiple of 16
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 320, G.DT_Q8_0) == -2      # in_features not whole units (Q8_0: 128 columns): the F32-MFMA path takes it
+    assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 288, G.DT_Q4_0) == -2
 
 
 @pytest.mark.parametrize("qname", sorted(QUANT))
