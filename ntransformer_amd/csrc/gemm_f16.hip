@@ -367,11 +367,14 @@ constexpr int GB_UPT = 2;     // units per loop trip (Q6_K: the parity of a unit
 // LDS of a workgroup: a ring of NS activation step records (8 KB each, filled by LDS-DMA NS - 1 steps ahead), the ring of the steps'
 // per-token sums, the 4 waves' weight images.  NS = as many slots as leave room for two workgroups per CU (160 KB): a record that
 // misses the XCD's L2 takes ~2 us to arrive, and the records in flight are what hides it (a step consumes one in 0.3-0.4 us)
-template <int DT, int RT> constexpr int gb_slots() {
-    const int n = (GB_LDS_WG - 4 * 16 * RT * DeqI<DT>::STRIDE - GB_TRACE_LDS) / (GB_STEP_BYTES + GB_AUX_BYTES);
+// CW = 64-token chunks per workgroup (1 or 2: a slot then holds the records of both)
+template <int DT, int RT, int CW> constexpr int gb_slots() {
+    const int n = (GB_LDS_WG - 4 * 16 * RT * DeqI<DT>::STRIDE - GB_TRACE_LDS) / (CW * (GB_STEP_BYTES + GB_AUX_BYTES));
     return n > 8 ? 8 : (n < 3 ? 3 : n);
 }
-template <int DT, int RT> constexpr int gb_lds_bytes() { return gb_slots<DT, RT>() * (GB_STEP_BYTES + GB_AUX_BYTES) + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS; }
+template <int DT, int RT, int CW> constexpr int gb_lds_bytes() {
+    return gb_slots<DT, RT, CW>() * CW * (GB_STEP_BYTES + GB_AUX_BYTES) + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS;
+}
 
 constexpr int GB_MAX_SEG = 3;   // matrices sharing X in one launch (Q | K | V, gate | up)
 struct GemmBSeg {
@@ -419,14 +422,18 @@ __device__ __forceinline__ void gb_dma16x2(uint32_t lds_dst, const uint8_t* gsrc
 //   registers to the wave's LDS image and the ring slot is re-requested NRING units ahead | DMA step s + NS - 1 into the slot whose
 //   planes were consumed a step ago | LDS reads: the step's sums, the raw weight dwords of step s + 2, the step's activation planes |
 //   4 x (2 RT MFMAs, the token block's scale-FMAs), the conversion of step s + 1's weight operand in their shadow.
-template <int DT, int RT, bool AL, bool PF>
+// CW = 2: the workgroup takes two consecutive 64-token chunks (128 tokens against every decoded weight: conversion, staging, barriers
+// and weight traffic per MFMA halve); its planes are read a token-block pair at a time, one pair ahead of the MFMAs.
+template <int DT, int RT, bool AL, bool PF, int CW>
 __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const GemmBParams p) {
     using D = DeqI<DT>;
     constexpr int SPU = D::SPU, NCH = D::NCH, STRIDE = D::STRIDE;
     constexpr int ROWS = 16 * RT, PIECES = ROWS * NCH, NLD = (PIECES + 63) / 64;   // 16-byte pieces of a unit; requests per lane
     constexpr int NRING = D::NRING;
-    constexpr int NS = gb_slots<DT, RT>();                  // activation ring: slots
-    constexpr int XS_OFF = NS * GB_STEP_BYTES, STAGE_OFF = XS_OFF + NS * GB_AUX_BYTES;
+    constexpr int NS = gb_slots<DT, RT, CW>();              // activation ring: slots
+    constexpr int SLOT_BYTES = CW * GB_STEP_BYTES, AUX_BYTES = CW * GB_AUX_BYTES, NTB = 4 * CW;
+    constexpr int XS_OFF = NS * SLOT_BYTES, STAGE_OFF = XS_OFF + NS * AUX_BYTES;
+    static_assert(CW == 1 || (CW == 2 && !PF && !D::SPLIT16), "two chunks per workgroup: the pairwise plane pipeline, 32-column scales");
     static_assert(GB_UPT % NRING == 0 && NS >= 3 && NS - 2 <= GB_UPT * SPU, "a trip must cover whole turns of the weight ring");
     extern __shared__ __attribute__((aligned(16))) uint8_t gb_lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -472,13 +479,14 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
     float* const segPart = p.seg[sidx].part;
     const int seg_out = p.seg[sidx].out;
     const unsigned seg_w_last = p.seg[sidx].w_last;
-    const int Tc = min(GB_TOK, p.T - chunk * GB_TOK);
+    chunk *= CW;   // the workgroup's first 64-token chunk (p.chunks counts workgroup-sized groups)
+    const int Tc = min(CW * GB_TOK, p.T - chunk * GB_TOK);
     const int row0 = ((tile - p.seg[sidx].tile0) * 4 + wave) * ROWS;
-    f32x4 acc[RT][4];
+    f32x4 acc[RT][NTB];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) acc[rt][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int tb = 0; tb < NTB; ++tb) acc[rt][tb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // this workgroup's K range (split-K: blockIdx.y), in steps of 32 columns; whole trips of GB_UPT * SPU steps
     const int step_lo = (int)blockIdx.y * p.steps_per_split, step_hi = min(p.steps, step_lo + p.steps_per_split);
@@ -520,13 +528,18 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
     const uint32_t lds0 = (uint32_t)(uintptr_t)gb_lds;   // generic -> LDS address: the low 32 bits
     const uint8_t* xb_thread = p.xb + (size_t)chunk * p.chunk_bytes + (size_t)wave * 2048 + (size_t)lane * 16;   // wave w copies bytes [2048 w, 2048 w + 2048) of a step record
     const uint8_t* aux_thread = reinterpret_cast<const uint8_t*>(p.aux) + (size_t)chunk * p.chunk_bytes + (size_t)wave * 64 + (size_t)(lane & 3) * 16;   // and 64 of its 256 aux bytes
-    constexpr int ND = D::HAS_MIN ? 3 : 2;               // DMA requests per step and wave
+    constexpr int ND = CW * (D::HAS_MIN ? 3 : 2);        // DMA requests per step and wave
     auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros) into ring slot `slot` (uniform)
         if ((kGbAblate & 16) && rel >= NS - 1) return;
         const int s = rel < nsteps ? step_lo + rel : p.steps;
-        gb_dma16x2(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * GB_STEP_BYTES + (uint32_t)wave * 2048u), xb_thread + (size_t)s * GB_STEP_BYTES);
-        if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave (one request: the vmcnt arithmetic counts it for every lane)
-            gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + XS_OFF + (uint32_t)slot * GB_AUX_BYTES + (uint32_t)wave * 64u), aux_thread + (size_t)s * GB_AUX_BYTES);
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {   // (a second chunk past the end of the launch reads planes nobody wrote: its tokens are never stored)
+            gb_dma16x2(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * SLOT_BYTES + (uint32_t)c * GB_STEP_BYTES + (uint32_t)wave * 2048u),
+                       xb_thread + (size_t)c * p.chunk_bytes + (size_t)s * GB_STEP_BYTES);
+            if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave (one request: the vmcnt arithmetic counts it for every lane)
+                gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + XS_OFF + (uint32_t)slot * AUX_BYTES + (uint32_t)c * GB_AUX_BYTES + (uint32_t)wave * 64u),
+                         aux_thread + (size_t)c * p.chunk_bytes + (size_t)s * GB_AUX_BYTES);
+        }
     };
     const uint8_t* img[RT];      // this lane's row images (row rt*16 + i of the wave's tile)
     uint32_t my_row[RT];         // and the rows' byte offsets in W: the unit's bytes start `(my_row + unit offset) & 15` into the image
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
         }
     };
     auto read_planes = [&](u32x4 (&b)[GB_PLANES][4], int slot) {   // token block by token block: the order the MFMAs take them in
-        const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * GB_STEP_BYTES) + lane;
+        const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * SLOT_BYTES) + lane;
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
@@ -576,6 +589,14 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
     int slot = 0;   // ring slot of the current step (uniform)
     u32x4 b[GB_PLANES][4];
     if constexpr (PF) read_planes(b, 0);   // PF: a step's planes are read one step ahead of its MFMAs, into a second register set
+    // CW = 2: token blocks 2 q, 2 q + 1 of a slot -> one of two register sets of 4 operands ([plane][block of the pair])
+    auto read_pair = [&](u32x4 (&bq)[GB_PLANES][2], int slot, int q) {
+        const u32x4* bs = reinterpret_cast<const u32x4*>(gb_lds + (size_t)slot * SLOT_BYTES + (size_t)(q >> 1) * GB_STEP_BYTES) + lane;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int pl = 0; pl < GB_PLANES; ++pl) bq[pl][t2] = bs[(pl * 4 + (q & 1) * 2 + t2) * 64];
+    };
 
     for (int trip = 0; trip * (GB_UPT * SPU) < nsteps; ++trip) {
 #pragma unroll
@@ -613,10 +634,10 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                 // ---- one scheduling region from here to the end of the step ----
                 // LDS reads, in the order their consumers come: this step's sums, the raw weight dwords of the step after next, the next
                 // step's activation planes
-                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + XS_OFF + (size_t)slot * GB_AUX_BYTES);
-                f32x4 xsum_t[4];   // tokens tb*16 + 4g + e
+                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + XS_OFF + (size_t)slot * AUX_BYTES);
+                f32x4 xsum_t[NTB];   // tokens tb*16 + 4g + e
 #pragma unroll
-                for (int tb = 0; tb < 4; ++tb) xsum_t[tb] = D::HAS_MIN ? xs[tb * 4 + g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int tb = 0; tb < NTB; ++tb) xsum_t[tb] = D::HAS_MIN ? xs[tb * 4 + g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 typename D::Raw raw2[RT];
                 {
                     constexpr int dummy = 0; (void)dummy;
@@ -625,7 +646,9 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                     for (int rt = 0; rt < RT; ++rt) raw2[rt] = D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], j2, k2);
                 }
                 u32x4 bn[GB_PLANES][4];
-                if constexpr (PF) read_planes(bn, slot == NS - 1 ? 0 : slot + 1);
+                u32x4 bq[2][GB_PLANES][2];
+                if constexpr (CW == 2) read_pair(bq[0], slot, 0);
+                else if constexpr (PF) read_planes(bn, slot == NS - 1 ? 0 : slot + 1);
                 else if (!(kGbAblate & 8) || rel == 0) read_planes(b, slot);
 #if defined(NTK_GEMM_TRACE) && NTK_GEMM_TRACE > 1
                 GB_STAMP(rel, 2);
@@ -669,6 +692,41 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                             for (int e = 0; e < 4; ++e)
                                 acc[rt][tb][e] = fmaf(a[rt].s1, ch[rt][e], fmaf(a[rt].s0, cl[rt][e], acc[rt][tb][e]));
                     }
+                } else if constexpr (CW == 2) {
+                    // four pairs of token blocks: the next pair's planes are requested before this pair's MFMAs go out
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q < 3) read_pair(bq[(q + 1) & 1], slot, q + 1);
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            const int tb = 2 * q + t2;
+                            f32x4 cc[RT];
+#pragma unroll
+                            for (int pl = 0; pl < GB_PLANES; ++pl)
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt) {
+                                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                                    cc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bq[q & 1][pl][t2]), __builtin_bit_cast(f16x8, a[rt].a),
+                                                                                    pl ? cc[rt] : z, 0, 0, 0);
+                                }
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float v = fmaf(a[rt].s0, cc[rt][e], acc[rt][tb][e]);
+                                    if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[tb][e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
+                                    acc[rt][tb][e] = v;
+                                }
+                        }
+                        // the pair's region: its LDS reads (and, q = 0, the step's other reads) first, then MFMAs with VALU work in their shadow
+                        __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
+#pragma unroll
+                        for (int n = 0; n < 2 * GB_PLANES * RT; ++n) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 } else {
 #pragma unroll
                     for (int tb = 0; tb < 4; ++tb) {
@@ -695,7 +753,7 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                     }
                 }
                 // issue order of the region: every LDS read first, then the MFMAs with VALU work in their shadow
-                {
+                if constexpr (CW == 1) {
                     constexpr int NMF = (D::SPLIT16 ? 8 : 4) * GB_PLANES * RT;
                     __builtin_amdgcn_sched_group_barrier(0x100, 64, 0);
 #pragma unroll
@@ -710,7 +768,7 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-                    for (int tb = 0; tb < 4; ++tb) asm volatile("" : "+v"(acc[rt][tb]));
+                    for (int tb = 0; tb < NTB; ++tb) asm volatile("" : "+v"(acc[rt][tb]));
                     a[rt] = an[rt];
                     asm volatile("" : "+v"(a[rt].a), "+v"(a[rt].s0), "+v"(a[rt].s1), "+v"(a[rt].mn));
                     rawn[rt] = raw2[rt];
@@ -736,16 +794,16 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
 #endif
     // ---- epilogue: accumulator element e of lane (i = weight row of the tile, g) is token tb*16 + 4g + e of the chunk; 1 / s ------
     const size_t tok0 = (size_t)chunk * GB_TOK;
-    f32x4 inv_t[4];
+    f32x4 inv_t[NTB];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) inv_t[tb] = *reinterpret_cast<const f32x4*>(p.inv + tok0 + tb * 16 + 4 * g);   // (the array is padded to whole chunks)
+    for (int tb = 0; tb < NTB; ++tb) inv_t[tb] = *reinterpret_cast<const f32x4*>(p.inv + tok0 + tb * 16 + 4 * g);   // (the array is padded to whole chunks)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
         const int r = row0 + rt * 16 + i;
         if (r >= seg_out) continue;
         if (p.nsplit > 1) {   // K split: this workgroup's partial sums, combined (fixed order) by reduce_splits_kernel
 #pragma unroll
-            for (int tb = 0; tb < 4; ++tb)
+            for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int t = tb * 16 + 4 * g + e;
@@ -753,16 +811,16 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                 }
             continue;
         }
-        float rs[4][4];
+        float rs[NTB][4];
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
+        for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = tb * 16 + 4 * g + e;
                 rs[tb][e] = (p.resid && t < Tc) ? p.resid[(tok0 + t) * seg_out + r] : 0.0f;
             }
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
+        for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int t = tb * 16 + 4 * g + e;
@@ -871,34 +929,44 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
         p.seg[i].part = part;
         part += (size_t)nsplit * T * segs[i].out;
     }
-    const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
-    const size_t lds2 = gb_lds_bytes<DT, 2>(), lds1 = gb_lds_bytes<DT, 1>();
-    // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0: in a multiple of 64, Q6_K: of
+    // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0 / Q4_0: in a multiple of 64, Q6_K: of
     // 512 -- every projection of the target models; other row pitches take the same kernel with 2-byte aligned reads, slower)
     const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
     static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
-    constexpr bool PFD = DeqI<DT>::PF;
+    static const int force_cw = [] { const char* e = getenv("NTK_GEMM_CW"); return e ? atoi(e) : 0; }();
+    constexpr bool PFD = DeqI<DT>::PF, CW2_OK = !DeqI<DT>::SPLIT16;
+    // two chunks (128 tokens) per workgroup when that still leaves two workgroups for every CU
+    const int chunks64 = p.chunks;
+    bool cw2 = CW2_OK && al && rt == 2 && nsplit == 1 && chunks64 >= 2 && (long)p.row_wgs * ((chunks64 + 1) / 2) >= 512;
+    if (force_cw == 1 || !CW2_OK) cw2 = false;
+    if (force_cw == 2 && CW2_OK && al && rt == 2 && nsplit == 1 && chunks64 >= 2) cw2 = true;
+    if (cw2) p.chunks = (chunks64 + 1) / 2;
+    const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
+    const size_t lds2 = gb_lds_bytes<DT, 2, 1>(), lds1 = gb_lds_bytes<DT, 1, 1>(), lds22 = gb_lds_bytes<DT, 2, 2>();
     static const bool lds_ok = [&] {   // more than 64 KB of dynamic LDS: opt in once per kernel
         bool ok = true;
         auto set = [&](const void* f, size_t n) { ok &= hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)n) == hipSuccess; };
-        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, PFD>), lds2);
-        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, false, PFD>), lds2);
-        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, true, PFD>), lds1);
-        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, false, PFD>), lds1);
-        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, false>), lds2);
-        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, true, false>), lds1);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, PFD, 1>), lds2);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, false, PFD, 1>), lds2);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, true, PFD, 1>), lds1);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, false, PFD, 1>), lds1);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, false, 1>), lds2);
+        set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 1, true, false, 1>), lds1);
+        if constexpr (CW2_OK) set(reinterpret_cast<const void*>(&gemm_quant_f16_kernel<DT, 2, true, false, 2>), lds22);
         return ok;
     }();
     if (!lds_ok) return NTK_E_LAUNCH;
-    if (al && (no_pf || !PFD)) {   // (NTK_GEMM_NO_PF=1: the A/B switch of the plane prefetch)
-        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, false>), grid, dim3(256), lds2, st, p);
-        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, true, false>), grid, dim3(256), lds1, st, p);
+    if (cw2) {
+        if constexpr (CW2_OK) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, false, 2>), grid, dim3(256), lds22, st, p);
+    } else if (al && (no_pf || !PFD)) {   // (NTK_GEMM_NO_PF=1: the A/B switch of the plane prefetch)
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, false, 1>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, true, false, 1>), grid, dim3(256), lds1, st, p);
     } else if (al) {
-        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, PFD>), grid, dim3(256), lds2, st, p);
-        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, true, PFD>), grid, dim3(256), lds1, st, p);
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, true, PFD, 1>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, true, PFD, 1>), grid, dim3(256), lds1, st, p);
     } else {
-        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, false, PFD>), grid, dim3(256), lds2, st, p);
-        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, false, PFD>), grid, dim3(256), lds1, st, p);
+        if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, false, PFD, 1>), grid, dim3(256), lds2, st, p);
+        else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, false, PFD, 1>), grid, dim3(256), lds1, st, p);
     }
     if (nsplit > 1) {
         ReduceArgs ra{};

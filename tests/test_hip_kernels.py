@@ -237,6 +237,25 @@ def test_gemm_quant_f16_full_size_and_rejections():
     assert ops.gemm_quant_ws(Yd, Wd, Xd, 2, 16, 288, G.DT_Q4_0) == -2
 
 
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q5_K"])
+def test_gemm_quant_f16_two_chunks_per_workgroup(qname):
+    """A launch big enough for the 128-tokens-per-workgroup form (224 row tiles x 3 chunk pairs >= 512 workgroups): 300 tokens = 5
+    chunks, so the last workgroup column has no second chunk (its planes are never written, its tokens never stored) and the last
+    chunk is ragged.  Tokens of both halves of a pair, of the lone chunk and the last token against the oracle."""
+    gt = QUANT[qname]
+    dt = G.GGML_TO_DT[gt]
+    r = rng(31 + gt)
+    T, out_f, in_f = 300, 28672, 4096
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = (r.standard_normal((T, in_f)) * np.exp(r.uniform(-3, 3, (T, 1)))).astype(np.float32)
+    R = r.standard_normal((T, out_f)).astype(np.float32)
+    Y = gemm_ws_gpu(W, X, out_f, in_f, dt, resid=R)
+    assert np.isfinite(Y).all()
+    for t in (0, 63, 64, 127, 130, 200, 256, 299):
+        ref = O.gemv(W, X[t], out_f, in_f, dt)
+        assert np.abs(Y[t] - (R[t] + ref)).max() <= tol_for(ref, in_f), (t, np.abs(Y[t] - (R[t] + ref)).max())
+
+
 @pytest.mark.parametrize("qname", sorted(QUANT))
 @pytest.mark.parametrize("off", [2, 6, 14])
 def test_gemm_quant_unaligned_weights_and_residual(qname, off):
