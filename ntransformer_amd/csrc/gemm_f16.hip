@@ -54,7 +54,8 @@ constexpr int GB_WG_PER_CU = 3, GB_LDS_WG = 53 * 1024, GB_NRING_Q8 = 1;
 #else
 constexpr int GB_WG_PER_CU = 2, GB_LDS_WG = 80 * 1024, GB_NRING_Q8 = 2;
 #endif
-constexpr int GB_AUX_BYTES = GB_TOK * 4;                  // per step: the 64 tokens' sums of x s (K-quant minimum term)
+constexpr int GB_AUX_BYTES = GB_TOK * 4;                  // per step: one eighth of its unit's record of sums (K-quant minimum term)
+constexpr int GB_MIN_UNIT_BYTES = 8 * GB_AUX_BYTES;       // per unit of 8 steps and 64-token chunk: 2 pieces x 4 token blocks x 2 x 16 tokens x 4 steps x FP16
 
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {   // two small integers -> FP16 pair (exact)
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
 }
 
 // ---- pre-pass 2: X -> FP16 planes in operand order + per-step sums ---------------------------------------------------------------
-// grid = (in / 32 steps + 1 (a record of zeros), 64-token chunks), block = 256 = 4 token blocks x 64 lanes
+// grid = (in / 32 steps + 8 (a record of zeros and a whole unit of zero sums), 64-token chunks), block = 256 = 4 token blocks x 64 lanes
 __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ X, int T, int in, u32x4* __restrict__ xb, float* __restrict__ aux,
                                                       size_t chunk_bytes, const float* __restrict__ scale) {
     const int step = blockIdx.x, tb = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -147,14 +148,25 @@ __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ 
         const f16x2 h = {(_Float16)lo, (_Float16)hi};
         return __builtin_bit_cast(uint32_t, h);
     };
-    const size_t base = ((size_t)step * GB_PLANES * 4 + tb) * 64 + lane;   // plane p at + p * 4 * 64
-    xb[base] = u32x4{pk(p1[0], p1[1]), pk(p1[2], p1[3]), pk(p1[4], p1[5]), pk(p1[6], p1[7])};
-    xb[base + 256] = u32x4{pk(p2[0], p2[1]), pk(p2[2], p2[3]), pk(p2[4], p2[5]), pk(p2[6], p2[7])};
-    // sum of the step's 32 scaled activations of token t (fixed order: the lane's 8 in sequence, then the 4 column groups)
+    if (step * 32 <= in) {   // (blocks in/32 + 1 .. in/32 + 7 only complete the all-zero unit of the sums below)
+        const size_t base = ((size_t)step * GB_PLANES * 4 + tb) * 64 + lane;   // plane p at + p * 4 * 64
+        xb[base] = u32x4{pk(p1[0], p1[1]), pk(p1[2], p1[3]), pk(p1[4], p1[5]), pk(p1[6], p1[7])};
+        xb[base + 256] = u32x4{pk(p2[0], p2[1]), pk(p2[2], p2[3]), pk(p2[4], p2[5]), pk(p2[6], p2[7])};
+    }
+    // sum of the step's 32 scaled activations of token t (fixed order: the lane's 8 in sequence, then the 4 column groups), as two FP16
+    // pieces of sum / 64 (|sum| <= 32 * 2^15) in the operand layout of the K-quant minimum MFMA: per unit of 8 steps a 2 KB record
+    // [piece][token block][step / 4][token] x (4 steps x FP16) -- lane (token, g < 2) of that MFMA reads its 8 bytes in one piece
     float sum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    if (g == 0) aux[(size_t)step * GB_TOK + t] = sum;
+    if (g == 0) {
+        const float y = sum * 0.015625f;
+        const _Float16 h1 = (_Float16)y, h2 = (_Float16)(y - (float)h1);
+        _Float16* rec = reinterpret_cast<_Float16*>(reinterpret_cast<uint8_t*>(aux) + (size_t)(step >> 3) * GB_MIN_UNIT_BYTES);
+        const int pos = ((tb * 2 + ((step >> 2) & 1)) * 64 + j * 4 + (step & 3));   // in FP16 units, piece 0; piece 1 at + 4 * 128
+        rec[pos] = h1;
+        rec[4 * 128 + pos] = h2;
+    }
 }
 
 // ---- per-format weight operand ---------------------------------------------------------------------------------------------
@@ -193,6 +205,8 @@ template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
     static constexpr int NRING = GB_NRING_Q8;                         // units in flight per wave (register ring): 8 steps ahead of the MFMAs
     static constexpr bool SPLIT16 = false, HAS_MIN = false, PF = true;
     struct Hdr {};
+    struct MinOp {};
+    __device__ static MinOp min_operand(const Hdr&, int) { return MinOp{}; }
     struct Raw { uint32_t w0, w1, w2, w3, d; };
     __device__ static Hdr header(const uint8_t*, const uint8_t*) { return Hdr{}; }
     template <bool AL> __device__ static Raw load(const uint8_t* row, const uint8_t* rowg, const Hdr&, int j, int) {
@@ -219,6 +233,8 @@ template <> struct DeqI<NTK_DT_Q4_0> {   // types.h:97-100: half d, 16 bytes of 
     static constexpr int ROW_ALIGN = 4, NRING = 1;                    // row pitch: in_features a multiple of 64
     static constexpr bool SPLIT16 = false, HAS_MIN = false, PF = true;
     struct Hdr {};
+    struct MinOp {};
+    __device__ static MinOp min_operand(const Hdr&, int) { return MinOp{}; }
     struct Raw { uint32_t w0, w1, d; };
     __device__ static Hdr header(const uint8_t*, const uint8_t*) { return Hdr{}; }
     // the lane's columns {4g..4g+3} and {16+4g..16+4g+3} are the low and high nibbles of the SAME four bytes: one dword per step, 2 bytes
@@ -249,6 +265,15 @@ template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 pa
     static constexpr int ROW_ALIGN = 16, NRING = 1;
     static constexpr bool SPLIT16 = false, HAS_MIN = true, PF = true;
     struct Hdr { u32x4 h; };   // d | dmin, 12 scale bytes
+    // the unit's 8 minima as the weight-side operand of the minimum-term MFMA: lane group g < 2 holds m_{4g} .. m_{4g+3} (FP16, exact),
+    // the others zeros; -64 dmin for the FMA behind it (the sums are stored divided by 64)   (6-bit packing: gemm.cu:206-222)
+    struct MinOp { uint32_t m0, m1; float ndmin64; };
+    template <typename H> __device__ static MinOp min_operand(const H& hd, int g) {
+        const uint32_t w0 = hd.h.z & 0x3F3F3F3Fu;
+        const uint32_t w1 = ((hd.h.w >> 4) & 0x0F0F0F0Fu) | (((hd.h.z >> 6) & 0x03030303u) << 4);
+        const uint32_t w = g == 0 ? w0 : (g == 1 ? w1 : 0u);
+        return MinOp{cvt2_u8_f16<0>(w), cvt2_u8_f16<2>(w), -64.0f * h2f((uint16_t)(hd.h.x >> 16))};
+    }
     struct Raw { uint32_t lo, hi; float s0, mn; };
     __device__ static Hdr header(const uint8_t* row, const uint8_t*) { return Hdr{*reinterpret_cast<const u32x4*>(row)}; }
     template <bool AL> __device__ static Raw load(const uint8_t*, const uint8_t* rowg, const Hdr& hd, int j, int) {
@@ -274,6 +299,15 @@ template <> struct DeqI<NTK_DT_Q5_K> {   // types.h:122-128: half d, dmin; 12 pa
     static constexpr int ROW_ALIGN = 16, NRING = 1;
     static constexpr bool SPLIT16 = false, HAS_MIN = true, PF = true;
     struct Hdr { u32x4 h; uint32_t qh_lo, qh_hi; };   // d | dmin, 12 scale bytes; the lane's 8 bytes of fifth bits (all 8 steps)
+    // the unit's 8 minima as the weight-side operand of the minimum-term MFMA: lane group g < 2 holds m_{4g} .. m_{4g+3} (FP16, exact),
+    // the others zeros; -64 dmin for the FMA behind it (the sums are stored divided by 64)   (6-bit packing: gemm.cu:206-222)
+    struct MinOp { uint32_t m0, m1; float ndmin64; };
+    template <typename H> __device__ static MinOp min_operand(const H& hd, int g) {
+        const uint32_t w0 = hd.h.z & 0x3F3F3F3Fu;
+        const uint32_t w1 = ((hd.h.w >> 4) & 0x0F0F0F0Fu) | (((hd.h.z >> 6) & 0x03030303u) << 4);
+        const uint32_t w = g == 0 ? w0 : (g == 1 ? w1 : 0u);
+        return MinOp{cvt2_u8_f16<0>(w), cvt2_u8_f16<2>(w), -64.0f * h2f((uint16_t)(hd.h.x >> 16))};
+    }
     struct Raw { uint32_t lo, hi, b5lo, b5hi; float s0, mn; };
     __device__ static Hdr header(const uint8_t* row, const uint8_t* rowg) { return Hdr{*reinterpret_cast<const u32x4*>(row), lds32<true>(rowg + 16), lds32<true>(rowg + 32)}; }
     template <bool AL> __device__ static Raw load(const uint8_t*, const uint8_t* rowg, const Hdr& hd, int j, int) {
@@ -301,6 +335,8 @@ template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], in
     static constexpr int ROW_ALIGN = 4, NRING = 1;                     // row pitch: in_features a multiple of 512
     static constexpr bool SPLIT16 = true, HAS_MIN = false, PF = false;
     struct Hdr { float d; };
+    struct MinOp {};
+    __device__ static MinOp min_operand(const Hdr&, int) { return MinOp{}; }
     struct Raw { uint32_t ql0, ql1, ql2, ql3, qh0, qh1, qh2, qh3, sc; float d; };
     __device__ static Hdr header(const uint8_t* row, const uint8_t*) { return Hdr{h2f((uint16_t)lds16(row + 208))}; }
     // blocks are 210 bytes: with a 4-byte aligned row, the units of even parity start on a dword boundary and those of odd
@@ -368,12 +404,13 @@ constexpr int GB_UPT = 2;     // units per loop trip (Q6_K: the parity of a unit
 // per-token sums, the 4 waves' weight images.  NS = as many slots as leave room for two workgroups per CU (160 KB): a record that
 // misses the XCD's L2 takes ~2 us to arrive, and the records in flight are what hides it (a step consumes one in 0.3-0.4 us)
 // CW = 64-token chunks per workgroup (1 or 2: a slot then holds the records of both)
+template <int DT, int CW> constexpr int gb_aux_lds() { return DeqI<DT>::HAS_MIN ? CW * 2 * GB_MIN_UNIT_BYTES : 0; }   // two units of sums per chunk
 template <int DT, int RT, int CW> constexpr int gb_slots() {
-    const int n = (GB_LDS_WG - 4 * 16 * RT * DeqI<DT>::STRIDE - GB_TRACE_LDS) / (CW * (GB_STEP_BYTES + GB_AUX_BYTES));
+    const int n = (GB_LDS_WG - 4 * 16 * RT * DeqI<DT>::STRIDE - GB_TRACE_LDS - gb_aux_lds<DT, CW>()) / (CW * GB_STEP_BYTES);
     return n > 8 ? 8 : (n < 3 ? 3 : n);
 }
 template <int DT, int RT, int CW> constexpr int gb_lds_bytes() {
-    return gb_slots<DT, RT, CW>() * CW * (GB_STEP_BYTES + GB_AUX_BYTES) + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS;
+    return gb_slots<DT, RT, CW>() * CW * GB_STEP_BYTES + gb_aux_lds<DT, CW>() + 4 * 16 * RT * DeqI<DT>::STRIDE + GB_TRACE_LDS;
 }
 
 constexpr int GB_MAX_SEG = 3;   // matrices sharing X in one launch (Q | K | V, gate | up)
@@ -431,8 +468,9 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
     constexpr int ROWS = 16 * RT, PIECES = ROWS * NCH, NLD = (PIECES + 63) / 64;   // 16-byte pieces of a unit; requests per lane
     constexpr int NRING = D::NRING;
     constexpr int NS = gb_slots<DT, RT, CW>();              // activation ring: slots
-    constexpr int SLOT_BYTES = CW * GB_STEP_BYTES, AUX_BYTES = CW * GB_AUX_BYTES, NTB = 4 * CW;
-    constexpr int XS_OFF = NS * SLOT_BYTES, STAGE_OFF = XS_OFF + NS * AUX_BYTES;
+    constexpr int SLOT_BYTES = CW * GB_STEP_BYTES, NTB = 4 * CW;
+    constexpr int XS_OFF = NS * SLOT_BYTES, STAGE_OFF = XS_OFF + gb_aux_lds<DT, CW>();
+    static_assert(!D::HAS_MIN || (SPU == 8 && NS <= 8), "the minimum term's sums: units of 8 steps, two of them in LDS");
     static_assert(CW == 1 || (CW == 2 && !PF && !D::SPLIT16), "two chunks per workgroup: the pairwise plane pipeline, 32-column scales");
     static_assert(GB_UPT % NRING == 0 && NS >= 3 && NS - 2 <= GB_UPT * SPU, "a trip must cover whole turns of the weight ring");
     extern __shared__ __attribute__((aligned(16))) uint8_t gb_lds[];
@@ -529,15 +567,18 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
     const uint8_t* xb_thread = p.xb + (size_t)chunk * p.chunk_bytes + (size_t)wave * 2048 + (size_t)lane * 16;   // wave w copies bytes [2048 w, 2048 w + 2048) of a step record
     const uint8_t* aux_thread = reinterpret_cast<const uint8_t*>(p.aux) + (size_t)chunk * p.chunk_bytes + (size_t)wave * 64 + (size_t)(lane & 3) * 16;   // and 64 of its 256 aux bytes
     constexpr int ND = CW * (D::HAS_MIN ? 3 : 2);        // DMA requests per step and wave
-    auto dma_step = [&](int rel, int slot) {             // step record `rel` (past the end: the record of zeros) into ring slot `slot` (uniform)
+    // dpos = the destination step's position in its pair of units (0..15, compile time at every call): the step's eighth of its unit's record
+    // of sums goes to buffer dpos / 8
+    auto dma_step = [&](int rel, int slot, int dpos) {   // step record `rel` (past the end: the record of zeros) into ring slot `slot` (uniform)
         if ((kGbAblate & 16) && rel >= NS - 1) return;
         const int s = rel < nsteps ? step_lo + rel : p.steps;
 #pragma unroll
         for (int c = 0; c < CW; ++c) {   // (a second chunk past the end of the launch reads planes nobody wrote: its tokens are never stored)
             gb_dma16x2(__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)slot * SLOT_BYTES + (uint32_t)c * GB_STEP_BYTES + (uint32_t)wave * 2048u),
                        xb_thread + (size_t)c * p.chunk_bytes + (size_t)s * GB_STEP_BYTES);
-            if (D::HAS_MIN && lane < 4)   // the step's 64 sums: 16 floats per wave (one request: the vmcnt arithmetic counts it for every lane)
-                gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + XS_OFF + (uint32_t)slot * AUX_BYTES + (uint32_t)c * GB_AUX_BYTES + (uint32_t)wave * 64u),
+            if (D::HAS_MIN && lane < 4)   // 64 of the eighth's 256 bytes per wave (one request: the vmcnt arithmetic counts it for every lane)
+                gb_dma16(__builtin_amdgcn_readfirstlane(lds0 + XS_OFF + (uint32_t)c * (2 * GB_MIN_UNIT_BYTES) + (uint32_t)(dpos >> 3) * GB_MIN_UNIT_BYTES +
+                                                        (uint32_t)(dpos & 7) * GB_AUX_BYTES + (uint32_t)wave * 64u),
                          aux_thread + (size_t)c * p.chunk_bytes + (size_t)s * GB_AUX_BYTES);
         }
     };
@@ -549,6 +590,7 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
         my_row[rt] = (uint32_t)min(row0 + rt * 16 + i, seg_out - 1) * p.row_bytes;
     }
     typename D::Hdr hdr[RT];
+    typename D::MinOp mcur[RT], mnext[RT];   // K-quant minima of the unit whose steps run / of the unit entered two steps before its first
     const uint8_t* cur[RT];      // img + the staged unit's shift (AL: rounded down to a dword boundary)
     auto enter_unit = [&](int unit) {   // the image now holds `unit`
         const uint32_t uoff = (uint32_t)(unit_lo + min(unit, nunits - 1)) * D::UB;
@@ -556,6 +598,7 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
         for (int rt = 0; rt < RT; ++rt) {
             const uint8_t* first = img[rt] + ((my_row[rt] + uoff) & 15u);
             hdr[rt] = D::header(first, first + 4 * g);
+            mnext[rt] = D::min_operand(hdr[rt], g);
             cur[rt] = AL ? img[rt] + ((my_row[rt] + uoff) & 12u) : first;
         }
     };
@@ -575,9 +618,11 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
     stage_unit(0);
     load_unit(0, NRING);
 #pragma unroll
-    for (int q = 0; q < NS - 1; ++q) dma_step(q, q);
+    for (int q = 0; q < NS - 1; ++q) dma_step(q, q, q);
     static_assert(SPU >= 4, "units of >= 4 steps: steps 0 and 1 belong to unit 0");
     enter_unit(0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) mcur[rt] = mnext[rt];
     AOp a[RT];
     typename D::Raw rawn[RT];
 #pragma unroll
@@ -630,14 +675,9 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                     enter_unit(trip * GB_UPT + k + 1);
                 }
                 // into the slot of step rel - 1: its planes were read a step ago and consumed before this barrier
-                dma_step(rel + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+                dma_step(rel + NS - 1, slot == 0 ? NS - 1 : slot - 1, (k * SPU + j + NS - 1) % (GB_UPT * SPU));
                 // ---- one scheduling region from here to the end of the step ----
-                // LDS reads, in the order their consumers come: this step's sums, the raw weight dwords of the step after next, the next
-                // step's activation planes
-                const f32x4* xs = reinterpret_cast<const f32x4*>(gb_lds + XS_OFF + (size_t)slot * AUX_BYTES);
-                f32x4 xsum_t[NTB];   // tokens tb*16 + 4g + e
-#pragma unroll
-                for (int tb = 0; tb < NTB; ++tb) xsum_t[tb] = D::HAS_MIN ? xs[tb * 4 + g] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                // LDS reads, in the order their consumers come: the raw weight dwords of the step after next, the activation planes
                 typename D::Raw raw2[RT];
                 {
                     constexpr int dummy = 0; (void)dummy;
@@ -714,7 +754,6 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
                                     float v = fmaf(a[rt].s0, cc[rt][e], acc[rt][tb][e]);
-                                    if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[tb][e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
                                     acc[rt][tb][e] = v;
                                 }
                         }
@@ -747,7 +786,6 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float v = fmaf(a[rt].s0, cc[rt][e], acc[rt][tb][e]);
-                                if (D::HAS_MIN) v = fmaf(-a[rt].mn, xsum_t[tb][e], v);   // - dmin * m * sum x   (gemm.cu:232-244)
                                 acc[rt][tb][e] = v;
                             }
                     }
@@ -760,6 +798,37 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                     for (int n = 0; n < NMF; ++n) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, D::SPLIT16 ? 2 : 4, 0);
+                    }
+                }
+                // K-quant minimum of the unit that ends here (gemm.cu:232-244: - dmin m_j sum_k x_k per sub-block j): sum_j m_j S_j over the
+                // unit's 8 sub-blocks is one K = 8 product per (row, token) -- two MFMAs per tile (the two FP16 pieces of S / 64: lane
+                // (token, g < 2) holds steps 4 g .. 4 g + 3; the weight-side operand holds m_j there and zeros elsewhere, so whatever
+                // finite values sit in the rest of the token-side operand do not count), then one FMA per element with -64 dmin.
+                // Per step that was 2 packed FMAs per tile and a 16-byte LDS read per token block.
+                if constexpr (D::HAS_MIN) {
+                    if (j == SPU - 1) {
+#pragma unroll
+                        for (int tb = 0; tb < NTB; ++tb) {
+                            const uint8_t* rec = gb_lds + XS_OFF + (tb >> 2) * (2 * GB_MIN_UNIT_BYTES) + k * GB_MIN_UNIT_BYTES + (((tb & 3) * 2 + (g & 1)) * 16 + i) * 8;
+                            f32x4 rr[RT];
+#pragma unroll
+                            for (int pl = 0; pl < GB_PLANES; ++pl) {
+                                const uint64_t sv = *reinterpret_cast<const uint64_t*>(rec + pl * (GB_MIN_UNIT_BYTES / 2));
+                                const u32x4 sa = {(uint32_t)sv, (uint32_t)(sv >> 32), (uint32_t)sv, (uint32_t)(sv >> 32)};
+#pragma unroll
+                                for (int rt = 0; rt < RT; ++rt) {
+                                    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                                    const u32x4 mb = {mcur[rt].m0, mcur[rt].m1, 0u, 0u};
+                                    rr[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sa), __builtin_bit_cast(f16x8, mb), pl ? rr[rt] : z, 0, 0, 0);
+                                }
+                            }
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[rt][tb][e] = fmaf(mcur[rt].ndmin64, rr[rt][e], acc[rt][tb][e]);
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) mcur[rt] = mnext[rt];
                     }
                 }
                 // the accumulators and the next operands are complete HERE: without this anchor the instruction selector parks every
@@ -859,7 +928,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const ReduceArgs a) 
 }
 
 // one chunk's planes + sums (+ the record of zeros), rounded to 256 B
-static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * (GB_STEP_BYTES + GB_AUX_BYTES) + 255) / 256 * 256; }
+static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * GB_STEP_BYTES + (size_t)(in / 32 + 8) * GB_AUX_BYTES + 255) / 256 * 256; }
 
 constexpr size_t GB_SCALE_BYTES = 2 * GB_MAX_CHUNKS * GB_TOK * sizeof(float);   // the launch's 1 / s and s
 
@@ -896,7 +965,7 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     p.resid = resid;
     if (!reuse_x) {
         hipLaunchKernelGGL(row_scale_kernel, dim3((T + 3) / 4), dim3(256), 0, st, X, T, in, scales + GB_MAX_CHUNKS * GB_TOK, scales);
-        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 1, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.aux),
+        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 8, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.aux),
                            p.chunk_bytes, scales + GB_MAX_CHUNKS * GB_TOK);
     }
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
