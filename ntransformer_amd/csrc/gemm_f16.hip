@@ -15,21 +15,24 @@
 //     and operand traffic for that last ulp;
 //   * sum_k q_k x_k over a 32-column block = two v_mfma_f32_16x16x32_f16 whose FP16 x FP16 products are exact in the F32
 //     accumulator; the per-block scale (FP16 d, 6-bit K-quant sub-scales, Q6_K's int8 sub-scales per 16 columns) multiplies
-//     the F32 block sum afterwards, the K-quant minimum enters as -dmin*m * s sum_k x_k, and 1 / s multiplies the finished sum
-//     (powers of two: exact) -- the same factorisation as reference gemm.cu:129-141, 190-244, 421-459.
+//     the F32 block sum afterwards and 1 / s the finished sum (powers of two: exact) -- the same factorisation as reference
+//     gemm.cu:129-141, 190-244, 421-459;
+//   * the K-quant minimum -dmin sum_j m_j S_j (S_j = sum_k (x s)_k of sub-block j) is a K = 8 product per super-block: the
+//     6-bit m_j exact in FP16, S_j / 64 as two FP16 pieces (the same <= 2^-23 relative rounding), two MFMAs per tile and
+//     super-block and one FMA with -64 dmin.
 //
 // Decomposition (gfx950, wave64):
 //   * pre-pass (row_scale_kernel, split_x_kernel): the tokens' scales; X[T,in] F32 -> two FP16 planes in MFMA operand order,
-//     1 KiB per (32-column step, plane, 16-token block), plus per (step, token) the sum of x s (K-quant minimum); written once
-//     per distinct X, read from L2 by every workgroup;
-//   * main kernel: workgroup = 4 waves, wave = 16*RT output rows x 64 tokens (RT*4 accumulator tiles of 16x16); the operand
-//     planes of a step (8 KB) reach a 4-slot LDS ring by LDS-DMA and are read by the 4 waves ONE STEP AHEAD of the MFMAs that
-//     use them (a second register set: the matrix instructions never wait for the LDS pipe); the raw GGUF rows travel
-//     HBM -> registers -> a per-wave LDS image in units of whole blocks and are decoded per step into FP16 integers;
+//     1 KiB per (32-column step, plane, 16-token block), plus per (step, token) the sum of x s as two FP16 pieces (K-quant
+//     minimum); written once per distinct X, read from L2 by every workgroup;
+//   * main kernel: workgroup = 4 waves, wave = 16*RT output rows x 64 (or, grid permitting, 128) tokens (RT*4 or RT*8
+//     accumulator tiles of 16x16); the operand planes of a step (8 KB per 64 tokens) reach an LDS ring of 3-8 slots by LDS-DMA
+//     with exact explicit waits; the raw GGUF rows travel HBM -> registers (inline-asm loads: see the ring below) -> a per-wave
+//     LDS image in units of whole blocks and become FP16 integers in two stages, two steps and one step ahead of their MFMAs;
 //   * MFMA operand slots: lane (i = lane % 16, g = lane / 16) holds columns {4g..4g+3} and {16+4g..16+4g+3} of the 32-column
 //     step for row / token i -- the same permutation on both operands, so the dot product is unchanged, and the two halves are
 //     the two 16-column sub-scale groups of Q6_K (which uses two K = 16 MFMAs per step).
-// Bound: MFMA (FP16 dense 2.5 PFLOP/s, two products per weight-token pair), the LDS reads of the activation planes co-critical.
+// Bound: instruction issue (MFMA + VALU of two waves per SIMD) under a 1.65-1.7 GHz clock; matrix pipe 41 % busy.
 #include "common.hip.h"
 #include <algorithm>
 #include <cstdlib>

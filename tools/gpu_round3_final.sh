@@ -27,6 +27,11 @@ for w in "8b Q8_0 32" "8b Q4_K_M 32" "70b Q4_K_M 16"; do set -- $w; M=$1; X=$2; 
 done
 timeout 300 python tools/gemv_bench.py --dtypes Q8_0,Q4_K,Q6_K > $OUT/gemv_bench.txt 2>&1; grep "Q8_0" $OUT/gemv_bench.txt
 timeout 300 python tools/attn_bench.py > $OUT/attention_by_context.txt 2>&1; grep "^8b" $OUT/attention_by_context.txt | head -8
-timeout 600 python tools/prefill_bench.py > $OUT/prefill_bench.txt 2>&1; grep "prompt of" $OUT/prefill_bench.txt
+timeout 600 python tools/prefill_bench.py --mixes Q8_0,Q4_K,Q6_K --tokens 64,256,1024 --modes 2 > $OUT/prefill_bench.txt 2>&1; grep "prompt of" $OUT/prefill_bench.txt
+timeout 300 python tools/prefill_bench.py --no-kernels --mix Q4_K_M --tokens 64,256,1024 --modes 2 2>&1 | grep "prompt of" | tee -a $OUT/prefill_bench.txt
+# the prompt pass: per-kernel time (rocprofv3 --kernel-trace --stats) and the counters of the GEMM (own PMC passes, kernel-trace only)
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/pp -o g -- python $R/tools/prefill_bench.py --no-kernels --mix Q8_0 --tokens 1024 --modes 2 > $R/$OUT/prompt_prof.log 2>&1 )
+f=$(find $OUT/pp -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/prompt_1024_8b_q8_0_kernel_stats.csv && head -8 $f | cut -c1-160; rm -rf $OUT/pp
+bash tools/gpu_pmc_gemm.sh $TAG/pmcgemm Q8_0 > $OUT/pmc_gemm.log 2>&1; cp $OUT/pmcgemm/summary_Q8_0.txt $OUT/prompt_gemm_pmc_8b_q8_0.txt 2>/dev/null; tail -2 $OUT/prompt_gemm_pmc_8b_q8_0.txt | cut -c1-300
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log
 tail -5 $OUT/bench.err; du -sh $OUT; ls $OUT
