@@ -9,10 +9,11 @@ lives here and not under tests/).  What it asserts:
     profiling slack below, the pooled GEMV rate recomputed from the trace agrees with the bench line's live HIP-event figure within
     12 % either way (events read high: they contain the boundaries inside a run of launches; profiled kernels read long), and the
     PMC traffic per GEMV launch is within [0.97, 1.08] x the algorithmic bytes.
-Slack on "trace kernel time vs un-profiled ms_per_step": 8 %.  A process under rocprofv3 runs its kernels at a lower clock
-(MI355X_MICROARCH.md, DVFS: profiled passes 1.89-1.95 GHz against 2.02 un-profiled) -- measured here +0.8 % on the HBM-bound Q8_0
-kernels, +2.7 % / +7 % on the VALU-bound K-quant ones (8B / 70B Q4_K_M) -- so the trace of a correct run can exceed the un-profiled
-step time by that much; a trace that exceeded it by more would mean the two files are not of the same tree."""
+Slack on "trace kernel time vs un-profiled ms_per_step": 10 %.  A process under rocprofv3 runs its kernels at a lower clock
+(MI355X_MICROARCH.md, DVFS: profiled passes 1.89-1.95 GHz against 2.02 un-profiled) -- measured in the final pass of round 3 (one box,
+one commit) +1.6 % on the HBM-bound Q8_0 kernels, +5.0 % / +8.5 % on the VALU-bound K-quant ones (8B / 70B Q4_K_M) -- so the trace of a
+correct run can exceed the un-profiled step time by that much; a trace that exceeded it by clearly more would mean the two files are
+not of the same tree."""
 import json
 import os
 import re
@@ -88,7 +89,7 @@ for name in sorted(os.listdir(PROF)):
             fail(name + ": summary lines not found")
         continue   # (summaries of rounds 1-2 predate the per-token line)
     busy_us = float(mt.group(1))
-    if busy_us > 1.08 * 1e3 * b["ms_per_step"]:
+    if busy_us > 1.10 * 1e3 * b["ms_per_step"]:
         fail("%s: kernel time per token %.1f us exceeds %s's ms_per_step %.1f us" % (name, busy_us, bname, 1e3 * b["ms_per_step"]))
     gbs = float(mg.group(4))
     live = b["roofline"]["achieved"]
