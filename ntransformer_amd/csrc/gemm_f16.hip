@@ -60,9 +60,6 @@ constexpr int GB_WG_PER_CU = 2, GB_LDS_WG = 80 * 1024, GB_NRING_Q8 = 2;
 constexpr int GB_AUX_BYTES = GB_TOK * 4;                  // per step: one eighth of its unit's record of sums (K-quant minimum term)
 constexpr int GB_MIN_UNIT_BYTES = 8 * GB_AUX_BYTES;       // per unit of 8 steps and 64-token chunk: 2 pieces x 4 token blocks x 2 x 16 tokens x 4 steps x FP16
 
-__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {   // two small integers -> FP16 pair (exact)
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));
-}
 // bytes k, k + 1 of a dword -> an FP16 pair, one SDWA conversion each (through F32 it is two conversions and a pack per pair: the
 // VALU slots of a step are what the kernel runs out of first)
 template <int K> __device__ __forceinline__ uint32_t cvt2_s8_f16(uint32_t q) {
@@ -89,8 +86,6 @@ __device__ __forceinline__ u32x4 cvt8_s8_f16(uint32_t lo, uint32_t hi) { return 
 __device__ __forceinline__ u32x4 cvt8_u8_f16(uint32_t lo, uint32_t hi) { return u32x4{cvt2_u8_f16<0>(lo), cvt2_u8_f16<2>(lo), cvt2_u8_f16<0>(hi), cvt2_u8_f16<2>(hi)}; }
 typedef uint32_t __attribute__((aligned(2))) u32_a2;
 typedef uint16_t __attribute__((aligned(2))) u16_a2;
-__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *reinterpret_cast<const u32_a2*>(p); }   // 2-byte aligned global dword
-__device__ __forceinline__ uint16_t ld16(const uint8_t* p) { return *reinterpret_cast<const u16_a2*>(p); }
 
 // ---- pre-pass 1: the tokens' scales --------------------------------------------------------------------------------------------
 // s = 2^(14 - floor(log2 m)), m = the token's largest |x|: m s in [2^14, 2^15) -- FP16's largest binade but one.  Exponent fields are
@@ -182,7 +177,6 @@ __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ 
 struct AOp {
     u32x4 a;            // 8 FP16 integers
     float s0, s1;       // scale of the slot's low / high 4 columns (equal unless the format scales per 16 columns)
-    float mn;           // K-quant minimum term factor (dmin * m), 0 otherwise
 };
 template <bool AL> __device__ __forceinline__ uint32_t lds32(const uint8_t* p) {   // LDS dword: 4-byte aligned (AL) or 2-byte aligned (slow)
     if constexpr (AL) return *reinterpret_cast<const uint32_t*>(p);
@@ -225,7 +219,6 @@ template <> struct DeqI<NTK_DT_Q8_0> {   // types.h:104-108: half d, int8 qs[32]
         AOp o;
         o.a = cvt8_s8_f16(lo, hi);
         o.s0 = o.s1 = h2f((uint16_t)r.d);
-        o.mn = 0.0f;
         return o;
     }
 };
@@ -257,7 +250,6 @@ template <> struct DeqI<NTK_DT_Q4_0> {   // types.h:97-100: half d, 16 bytes of 
         AOp o;   // n - 8: exact small integers
         o.a = u32x4{sub8(qa.x), sub8(qa.y), sub8(qa.z), sub8(qa.w)};
         o.s0 = o.s1 = h2f((uint16_t)r.d);
-        o.mn = 0.0f;
         return o;
     }
 };
@@ -277,13 +269,13 @@ template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 pa
         const uint32_t w = g == 0 ? w0 : (g == 1 ? w1 : 0u);
         return MinOp{cvt2_u8_f16<0>(w), cvt2_u8_f16<2>(w), -64.0f * h2f((uint16_t)(hd.h.x >> 16))};
     }
-    struct Raw { uint32_t lo, hi; float s0, mn; };
+    struct Raw { uint32_t lo, hi; float s0; };
     __device__ static Hdr header(const uint8_t* row, const uint8_t*) { return Hdr{*reinterpret_cast<const u32x4*>(row)}; }
     template <bool AL> __device__ static Raw load(const uint8_t*, const uint8_t* rowg, const Hdr& hd, int j, int) {
-        float sc, mn;
+        float sc, mn;   // (the minima go through min_operand() once per unit)
         kq_scale_min(hd.h.y, hd.h.z, hd.h.w, j, sc, mn);                       // gemm.cu:206-222
-        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu)), dmin = h2f((uint16_t)(hd.h.x >> 16));
-        return Raw{lds32<true>(rowg + 16 + 32 * (j >> 1)), lds32<true>(rowg + 32 + 32 * (j >> 1)), d * sc, dmin * mn};
+        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu));
+        return Raw{lds32<true>(rowg + 16 + 32 * (j >> 1)), lds32<true>(rowg + 32 + 32 * (j >> 1)), d * sc};
     }
     template <bool AL> __device__ static AOp convert(const Raw& r, int j, int) {
         const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
@@ -291,7 +283,6 @@ template <> struct DeqI<NTK_DT_Q4_K> {   // types.h:112-117: half d, dmin; 12 pa
         AOp o;
         o.a = cvt8_u8_f16(lo, hi);
         o.s0 = o.s1 = r.s0;
-        o.mn = r.mn;
         return o;
     }
 };
@@ -311,15 +302,15 @@ template <> struct DeqI<NTK_DT_Q5_K> {   // types.h:122-128: half d, dmin; 12 pa
         const uint32_t w = g == 0 ? w0 : (g == 1 ? w1 : 0u);
         return MinOp{cvt2_u8_f16<0>(w), cvt2_u8_f16<2>(w), -64.0f * h2f((uint16_t)(hd.h.x >> 16))};
     }
-    struct Raw { uint32_t lo, hi, b5lo, b5hi; float s0, mn; };
+    struct Raw { uint32_t lo, hi, b5lo, b5hi; float s0; };
     __device__ static Hdr header(const uint8_t* row, const uint8_t* rowg) { return Hdr{*reinterpret_cast<const u32x4*>(row), lds32<true>(rowg + 16), lds32<true>(rowg + 32)}; }
     template <bool AL> __device__ static Raw load(const uint8_t*, const uint8_t* rowg, const Hdr& hd, int j, int) {
-        float sc, mn;
+        float sc, mn;   // (the minima go through min_operand() once per unit)
         kq_scale_min(hd.h.y, hd.h.z, hd.h.w, j, sc, mn);                       // gemm.cu:206-222 (same packing as Q4_K)
-        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu)), dmin = h2f((uint16_t)(hd.h.x >> 16));
+        const float d = h2f((uint16_t)(hd.h.x & 0xFFFFu));
         // fifth bit of column l of sub-block j: bit j of qh[l]   (gemm.cu:297-354: u1 = 1 << 2c, u2 = 2 << 2c)
         return Raw{lds32<true>(rowg + 48 + 32 * (j >> 1)), lds32<true>(rowg + 64 + 32 * (j >> 1)), ((hd.qh_lo >> j) & 0x01010101u) << 4, ((hd.qh_hi >> j) & 0x01010101u) << 4,
-                   d * sc, dmin * mn};
+                   d * sc};
     }
     template <bool AL> __device__ static AOp convert(const Raw& r, int j, int) {
         const int sh = 4 * (j & 1);                                           // even sub-block: low nibbles, odd: high
@@ -327,7 +318,6 @@ template <> struct DeqI<NTK_DT_Q5_K> {   // types.h:122-128: half d, dmin; 12 pa
         AOp o;
         o.a = cvt8_u8_f16(lo, hi);
         o.s0 = o.s1 = r.s0;
-        o.mn = r.mn;
         return o;
     }
 };
@@ -374,7 +364,6 @@ template <> struct DeqI<NTK_DT_Q6_K> {   // types.h:132-137: ql[128], qh[64], in
         o.a = u32x4{sub32(qa.x), sub32(qa.y), sub32(qa.z), sub32(qa.w)};
         o.s0 = r.d * (float)(int)(int8_t)(r.sc & 0xFF);
         o.s1 = r.d * (float)(int)(int8_t)(r.sc >> 8);
-        o.mn = 0.0f;
         return o;
     }
 };
@@ -683,7 +672,6 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                 // LDS reads, in the order their consumers come: the raw weight dwords of the step after next, the activation planes
                 typename D::Raw raw2[RT];
                 {
-                    constexpr int dummy = 0; (void)dummy;
                     const int j2 = (j + 2) % SPU, k2 = (j + 2 >= SPU) ? (k + 1) % GB_UPT : k;   // (cur / hdr already belong to the next unit from step SPU - 2 on)
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) raw2[rt] = D::template load<AL>(cur[rt], cur[rt] + 4 * g, hdr[rt], j2, k2);
@@ -707,7 +695,6 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
                             __builtin_memcpy(w, &rawn[rt], sizeof(w));
                             an[rt].a = u32x4{w[0], w[1], w[2 % (sizeof(w) / 4)], w[3 % (sizeof(w) / 4)]};
                             an[rt].s0 = an[rt].s1 = __uint_as_float(w[sizeof(w) / 4 - 1]);
-                            an[rt].mn = __uint_as_float(w[sizeof(w) / 4 - 2]);
                         } else an[rt] = D::template convert<AL>(rawn[rt], j1, k1);
                     }
                 }
@@ -842,7 +829,7 @@ __global__ __launch_bounds__(256, GB_WG_PER_CU) void gemm_quant_f16_kernel(const
 #pragma unroll
                     for (int tb = 0; tb < NTB; ++tb) asm volatile("" : "+v"(acc[rt][tb]));
                     a[rt] = an[rt];
-                    asm volatile("" : "+v"(a[rt].a), "+v"(a[rt].s0), "+v"(a[rt].s1), "+v"(a[rt].mn));
+                    asm volatile("" : "+v"(a[rt].a), "+v"(a[rt].s0), "+v"(a[rt].s1));
                     rawn[rt] = raw2[rt];
                 }
                 if constexpr (PF) {
@@ -1006,7 +993,7 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
     static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
     static const int force_cw = [] { const char* e = getenv("NTK_GEMM_CW"); return e ? atoi(e) : 0; }();
-    constexpr bool PFD = DeqI<DT>::PF, CW2_OK = !DeqI<DT>::SPLIT16;
+    constexpr bool PFD = DeqI<DT>::PF, CW2_OK = !DeqI<DT>::SPLIT16 && DT != NTK_DT_Q5_K;   // (Q5_K: 15 registers over the budget in that form)
     // two chunks (128 tokens) per workgroup when that still leaves two workgroups for every CU
     const int chunks64 = p.chunks;
     bool cw2 = CW2_OK && al && rt == 2 && nsplit == 1 && chunks64 >= 2 && (long)p.row_wgs * ((chunks64 + 1) / 2) >= 512;
