@@ -47,7 +47,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int GB_TOK = 64;           // tokens per pass
-constexpr int GB_MAX_SPLIT = 8;     // K splits x token chunks of one launch never exceed this (size of the partial-sum area)
+constexpr int GB_MAX_SPLIT = 16;    // K splits x token chunks of one launch never exceed this (size of the partial-sum area)
 constexpr int GB_MAX_CHUNKS = 16;   // 64-token chunks per launch (32 measured no better: 15.1k vs 16.0k tok/s at 2048 tokens)
 constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
 constexpr int GB_PLANES = 2;         // FP16 pieces of an activation
@@ -963,7 +963,11 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     static const int map8 = [] { const char* e = getenv("NTK_GEMM_MAP"); return e ? atoi(e) : 1; }();
     p.map8 = map8;
     static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
-    static const int want_wgs = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 256; }();
+    // K is split (in whole trips) until every CU has two workgroups -- from 4 chunks (193 tokens) on; below that one per CU: the partial
+    // sums of many splits cost more than the idle half buys (same box, 8B Q8_0: 256 tokens 16 370 -> 17 000 tok/s, 512 19 830 -> 20 950;
+    // 64 tokens 8 090 -> 7 570 with the same rule, which is why it stops there)
+    static const int want_env = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 0; }();
+    const int want_wgs = want_env ? want_env : (p.chunks >= 4 ? 512 : 256);
     int rt = out_total >= 2048 ? 2 : 1;
     if (force_rt == 1 || force_rt == 2) rt = force_rt;
     int tiles = 0;
