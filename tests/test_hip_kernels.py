@@ -518,6 +518,30 @@ def test_rope(positions, interleaved):
     assert np.abs(kd.numpy() - rk).max() <= 1e-5
 
 
+@pytest.mark.parametrize("nh,nkv,hd", [(32, 8, 128), (8, 2, 64), (4, 4, 256)])
+@pytest.mark.parametrize("interleaved", [False, True])
+def test_rope_prompt_form_is_the_per_pair_kernel_bit_for_bit(nh, nkv, hd, interleaved):
+    """From 4 tokens on ntk_rope evaluates a token's (cos, sin) pairs once for all heads (rope_rows_kernel); below it re-evaluates
+    them per head and pair (rope_kernel, the 1:1 form).  Same frequency, same angle, same cosf / sinf: the prompt form, run token
+    by token through the per-pair kernel (one-token launches), must give the same bits -- and both the oracle's values."""
+    T = 37
+    r = rng(nh + hd + 5 * interleaved)
+    positions = [int(p_) for p_ in r.integers(0, 4096, T)]
+    q = r.standard_normal(T * nh * hd).astype(np.float32)
+    k = r.standard_normal(T * nkv * hd).astype(np.float32)
+    qd, kd, pd = DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(np.array(positions, np.int32))
+    ops.launch_rope(qd, kd, pd, 1, T, nh, nkv, hd, 500000.0, 1.0, interleaved)
+    got_q, got_k = qd.numpy().copy(), kd.numpy().copy()
+    one_q, one_k = np.empty_like(q), np.empty_like(k)
+    for t in range(T):   # one-token launches: the per-pair kernel
+        qt, kt = DB.from_numpy(q[t * nh * hd:(t + 1) * nh * hd]), DB.from_numpy(k[t * nkv * hd:(t + 1) * nkv * hd])
+        ops.launch_rope(qt, kt, DB.from_numpy(np.array([positions[t]], np.int32)), 1, 1, nh, nkv, hd, 500000.0, 1.0, interleaved)
+        one_q[t * nh * hd:(t + 1) * nh * hd] = qt.numpy(); one_k[t * nkv * hd:(t + 1) * nkv * hd] = kt.numpy()
+    assert np.array_equal(got_q, one_q) and np.array_equal(got_k, one_k)
+    rq, rk = O.rope(q, k, positions, nh, nkv, hd, 500000.0, 1.0, interleaved)
+    assert np.abs(got_q - rq).max() <= 2e-5 and np.abs(got_k - rk).max() <= 2e-5
+
+
 def test_copy_to_kv_cache_is_bit_exact():
     nkv, hd, max_seq, T, start = 2, 128, 16, 5, 9
     r = rng(77)
