@@ -89,21 +89,50 @@ __global__ __launch_bounds__(256, 2) void attention_prefill_mfma_kernel(float* _
     float m_run = -INFINITY, l_run = 0.0f;
 
     const int n_keys = start_pos + q0 + nq;   // cache rows 0 .. n_keys-1 are visible to the tile's last query
+    uint32_t k_ofs[4], v_ofs[4];               // this thread's pieces of a tile, in halves from the tile's first row (a tile spans < 2^32 halves)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int p = tid + 256 * n;
+        k_ofs[n] = (uint32_t)((p >> 4) * stride + (size_t)kv_head * AM_HD + 8 * (p & 15));
+        v_ofs[n] = (uint32_t)((4 * (tid >> 4) + n) * stride + (size_t)kv_head * AM_HD + 8 * (tid & 15));
+    }
     for (int k0 = 0; k0 < n_keys; k0 += AM_KT) {
         __syncthreads();                       // the previous tile has been consumed
         // ---- stage the tile: 16-byte pieces, 16 per cache row, rows past the end repeat the last one (masked below) ----
+        // K row-major: piece p -> row p / 16, piece p % 16.  V transposed: a thread takes piece c of the FOUR rows 4 rg .. 4 rg + 3 and
+        // writes, per head_dim value, the four rows' halves as one 8-byte store (V^T[8c + e][4 rg .. 4 rg + 3]) -- 8 stores per thread and
+        // tile where one store per half was 32.  (Row addresses: per-thread offsets fixed before the loop + a uniform k0 * stride; only
+        // the launch's last tile can run past the end and takes the clamped form.)
+        u32x4 kk[4], vv[4];
+        if (k0 + AM_KT <= n_keys) {
+            const size_t tile_ofs = (size_t)k0 * stride;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                kk[n] = *reinterpret_cast<const u32x4*>(kc + tile_ofs + k_ofs[n]);
+                vv[n] = *reinterpret_cast<const u32x4*>(vc + tile_ofs + v_ofs[n]);
+            }
+        } else {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int p = tid + 256 * n;
+                kk[n] = *reinterpret_cast<const u32x4*>(kc + (size_t)min(k0 + (p >> 4), n_keys - 1) * stride + (size_t)kv_head * AM_HD + 8 * (p & 15));
+                vv[n] = *reinterpret_cast<const u32x4*>(vc + (size_t)min(k0 + 4 * (tid >> 4) + n, n_keys - 1) * stride + (size_t)kv_head * AM_HD + 8 * (tid & 15));
+            }
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-            const int p = tid + 256 * n, r = p >> 4, c = p & 15;
-            const size_t gofs = (size_t)min(k0 + r, n_keys - 1) * stride + (size_t)kv_head * AM_HD + 8 * c;
-            const u32x4 kv = *reinterpret_cast<const u32x4*>(kc + gofs);
-            const u32x4 vv = *reinterpret_cast<const u32x4*>(vc + gofs);
-            *reinterpret_cast<u32x4*>(kt + r * AM_KSTR + 8 * c) = kv;
-            const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+            const int p = tid + 256 * n;
+            *reinterpret_cast<u32x4*>(kt + (p >> 4) * AM_KSTR + 8 * (p & 15)) = kk[n];
+        }
+        {
+            const int c = tid & 15, rg = tid >> 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {      // V^T[8c + 2j][r], V^T[8c + 2j + 1][r]
-                vt[(8 * c + 2 * j) * AM_VSTR + r] = (uint16_t)(w[j] & 0xFFFFu);
-                vt[(8 * c + 2 * j + 1) * AM_VSTR + r] = (uint16_t)(w[j] >> 16);
+            for (int e2 = 0; e2 < 4; ++e2) {   // dword e2 of the pieces holds head_dim values 8c + 2 e2 (low half) and 8c + 2 e2 + 1 (high half)
+                const uint32_t w0 = vv[0][e2], w1 = vv[1][e2], w2 = vv[2][e2], w3 = vv[3][e2];
+                const u32x2 lo = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u)};
+                const u32x2 hi = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u)};
+                *reinterpret_cast<u32x2*>(vt + (8 * c + 2 * e2) * AM_VSTR + 4 * rg) = lo;
+                *reinterpret_cast<u32x2*>(vt + (8 * c + 2 * e2 + 1) * AM_VSTR + 4 * rg) = hi;
             }
         }
         __syncthreads();
@@ -124,20 +153,30 @@ __global__ __launch_bounds__(256, 2) void attention_prefill_mfma_kernel(float* _
         }
         // ---- online softmax, one query per lane (its 16 scores here + the three other lanes of the query) --------------------
         float m_tile = -INFINITY;
+        if (k0 + AM_KT - 1 <= start_pos + wq0 && wq0 + 15 < T) {   // wave-uniform: the whole tile is visible to every query of the wave
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = k0 + 16 * mt + 4 * g + e;
-                s[mt][e] = key <= my_limit ? s[mt][e] : -INFINITY;
-                m_tile = fmaxf(m_tile, s[mt][e]);
-            }
+                for (int e = 0; e < 4; ++e) m_tile = fmaxf(m_tile, s[mt][e]);
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + 16 * mt + 4 * g + e;
+                    s[mt][e] = key <= my_limit ? s[mt][e] : -INFINITY;
+                    m_tile = fmaxf(m_tile, s[mt][e]);
+                }
+        }
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
         const float m_new = fmaxf(m_run, m_tile);
         // (rows of queries past T, or a tile wholly beyond this query's limit: everything masked, m_new may still be -inf)
         const float m_use = m_new == -INFINITY ? 0.0f : m_new;
-        const float alpha = expf(m_run - m_use);       // exp(-inf) = 0 on the first visible tile
+        // the hardware exponential (v_exp_f32 on x log2 e, ~1 ulp), like the decode walk of attention.hip: 17 per tile and lane, and libm's
+        // expf is ~15 instructions each where the kernel is bound by its VALU work (the reference's CUDA build evaluates expf the same
+        // way under --use_fast_math, CMakeLists.txt:20)
+        const float alpha = __expf(m_run - m_use);     // exp(-inf) = 0 on the first visible tile
         float l_tile = 0.0f;
         f16x8 ph[2], pl[2];                            // P^T operands of the two 32-key chunks
 #pragma unroll
@@ -145,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void attention_prefill_mfma_kernel(float* _
             float pv[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pv[e] = expf(s[2 * kc2][e] - m_use);           // keys 32 kc + 4g + e
-                pv[4 + e] = expf(s[2 * kc2 + 1][e] - m_use);   // keys 32 kc + 16 + 4g + e
+                pv[e] = __expf(s[2 * kc2][e] - m_use);         // keys 32 kc + 4g + e
+                pv[4 + e] = __expf(s[2 * kc2 + 1][e] - m_use); // keys 32 kc + 16 + 4g + e
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) l_tile += pv[e];
@@ -157,9 +196,13 @@ __global__ __launch_bounds__(256, 2) void attention_prefill_mfma_kernel(float* _
         l_run = l_run * alpha + l_tile;
         m_run = m_new;
         // ---- O^T = alpha O^T + V^T . P^T ------------------------------------------------------------------------------------------
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // (x * 1.0f is x: skipping the rescale where no lane's maximum moved is exact)
+#pragma unroll
+            for (int ht = 0; ht < 8; ++ht) o[ht] = o[ht] * alpha;
+        }
 #pragma unroll
         for (int ht = 0; ht < 8; ++ht) {
-            f32x4 acc = o[ht] * alpha;
+            f32x4 acc = o[ht];
 #pragma unroll
             for (int kc2 = 0; kc2 < 2; ++kc2) {
                 const uint16_t* vrow = vt + (16 * ht + i) * AM_VSTR + 32 * kc2 + 4 * g;
