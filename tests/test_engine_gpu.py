@@ -368,6 +368,24 @@ def test_device_sampling_gives_the_host_samplers_token_stream(cfg, tmp_path):
     assert len(set(outs[0])) > 3
 
 
+@pytest.mark.parametrize("switch", ["NTK_GEMM_CW=2", "NTK_GEMM_CW=1", "NTK_GEMM_NO_PF=1", "NTK_GEMM_MAP=0", "NTK_GEMM_WGS=4096"])
+def test_prompt_gemm_forms_behind_the_tuning_switches_keep_parity(switch):
+    """The prompt GEMM (csrc/gemm_f16.hip) picks among forms by launch size: one or two 64-token chunks per workgroup, the plane
+    prefetch, the (row tile, chunk) order per XCD, the K split.  The switches that force each form (read once per process) must give
+    the same parity: every FP16-GEMM kernel test and the engine's prompt tests, in a subprocess per switch."""
+    import subprocess
+    import sys
+    k, v = switch.split("=")
+    env = dict(os.environ, **{k: v})
+    here = os.path.dirname(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_kernels.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "gemm_quant_f16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_engine_gpu.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "batched_prefill_fills or logits_match_reference_host_code"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+
+
 def test_experiments_library_matches_the_launch_path():
     """`make EXPERIMENTS=1` (ntransformer_amd/libntransformer_hip_exp.so, include/ntk_experiments.h): the persistent token kernel and
     the attention-inside-the-Wo-launch form -- both slower than the shipping launch path, kept as opt-in records -- still reproduce
