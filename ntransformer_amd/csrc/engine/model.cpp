@@ -341,11 +341,15 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     if (h_ring_) memset(h_ring_, 0, 64);
     sample_scratch_ = dev(ntk_sample_scratch_bytes(cfg_.vocab_size), false);
     attn_sync_ = (unsigned*)dev(4096, true);
-    gemm_ws_bytes_ = ntk_gemm_quant_workspace_bytes(std::max(cfg_.hidden_size, cfg_.intermediate_size),   // (Q|K|V and gate|up go out as one launch)
-                                                    std::max({cfg_.hidden_size, 2 * cfg_.intermediate_size,
-                                                              (cfg_.n_heads + 2 * cfg_.n_kv_heads) * cfg_.head_dim}));
+    {   // one workspace for every projection: the largest need over the launches the prompt pass makes (Q|K|V and gate|up go out as one)
+        const int H = cfg_.hidden_size, I = cfg_.intermediate_size, qkv = (cfg_.n_heads + 2 * cfg_.n_kv_heads) * cfg_.head_dim;
+        const int shapes[][2] = {{H, qkv}, {H, cfg_.n_heads * cfg_.head_dim}, {H, cfg_.n_kv_heads * cfg_.head_dim}, {cfg_.n_heads * cfg_.head_dim, H},
+                                 {H, 2 * I}, {H, I}, {I, H}};
+        gemm_ws_bytes_ = 0;
+        for (const auto& sh : shapes) gemm_ws_bytes_ = std::max(gemm_ws_bytes_, ntk_gemm_quant_workspace_bytes(sh[0], sh[1]));
+    }
     gemm_ws_ = dev(gemm_ws_bytes_, false);
-    if (const char* e = getenv("NTK_BF16_PREFILL")) bf16_prefill_ = atoi(e) != 0;   // [0] heads done, [1] finished, [2] error, [64 + 64 g] release flags
+    if (const char* e = getenv("NTK_BF16_PREFILL")) bf16_prefill_ = atoi(e) != 0;
     if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
     if (tp_world_ > 1) {   // communication buffer: flags + two slots of one prompt's worth of hidden vectors
         tp_max_floats_ = S * H;

@@ -47,7 +47,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int GB_TOK = 64;           // tokens per pass
-constexpr int GB_MAX_SPLIT = 16;    // K splits x token chunks of one launch never exceed this (size of the partial-sum area)
+// K splits x 64-token chunks of one launch never exceed this (size of the partial-sum area): 32 for matrices of up to 8192 rows (the narrow
+// ones are the ones that need splits at many chunks), 16 above
+constexpr int gb_split_rows(int out_total) { return out_total <= 8192 ? 32 : 16; }
 constexpr int GB_MAX_CHUNKS = 16;   // 64-token chunks per launch (32 measured no better: 15.1k vs 16.0k tok/s at 2048 tokens)
 constexpr int GB_PIECE = 1024;       // bytes of one (step, plane, token block) operand record
 constexpr int GB_PLANES = 2;         // FP16 pieces of an activation
@@ -982,8 +984,28 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     }
     p.row_wgs = tiles;
     const int trips = (p.steps + TRIP - 1) / TRIP;
-    int nsplit = 1;
-    while (nsplit * 2 * p.chunks <= GB_MAX_SPLIT && p.row_wgs * p.chunks * nsplit < want_wgs && trips / (nsplit * 2) >= 1) nsplit *= 2;
+    // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0 / Q4_0: in a multiple of 64, Q6_K: of
+    // 512 -- every projection of the target models; other row pitches take the same kernel with 2-byte aligned reads, slower)
+    const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
+    static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
+    static const int force_cw = [] { const char* e = getenv("NTK_GEMM_CW"); return e ? atoi(e) : 0; }();
+    constexpr bool PFD = DeqI<DT>::PF, CW2_OK = !DeqI<DT>::SPLIT16 && DT != NTK_DT_Q5_K;   // (Q5_K: 15 registers over the budget in that form)
+    // K splits of a plan with `groups` workgroup columns: doubled while the grid is short of `want_wgs`, whole trips, and
+    // splits x 64-token chunks within the partial-sum area (gb_split_rows)
+    const int chunks64 = p.chunks, max_rows = gb_split_rows((int)out_total);
+    auto splits_for = [&](int groups) {
+        int n = 1;
+        while (n * 2 * chunks64 <= max_rows && (long)p.row_wgs * groups * n < want_wgs && trips / (n * 2) >= 1) n *= 2;
+        return n;
+    };
+    // two chunks (128 tokens) per workgroup when that still gives every CU two workgroups -- directly, or (narrow matrices: the 8B down /
+    // o / Q|K|V projections at 1024 tokens) with K split in two
+    int nsplit = splits_for(chunks64);
+    bool cw2 = false;
+    if (CW2_OK && al && rt == 2 && chunks64 >= 2 && force_cw != 1) {
+        const int pairs = (chunks64 + 1) / 2, n2 = splits_for(pairs);
+        if ((n2 <= 2 && (long)p.row_wgs * pairs * n2 >= 512) || force_cw == 2) { cw2 = true; nsplit = n2; p.chunks = pairs; }
+    }
     const int tps = (trips + nsplit - 1) / nsplit;   // trips per split
     nsplit = (trips + tps - 1) / tps;                // no empty split
     p.nsplit = nsplit;
@@ -992,18 +1014,6 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
         p.seg[i].part = part;
         part += (size_t)nsplit * T * segs[i].out;
     }
-    // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0 / Q4_0: in a multiple of 64, Q6_K: of
-    // 512 -- every projection of the target models; other row pitches take the same kernel with 2-byte aligned reads, slower)
-    const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
-    static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
-    static const int force_cw = [] { const char* e = getenv("NTK_GEMM_CW"); return e ? atoi(e) : 0; }();
-    constexpr bool PFD = DeqI<DT>::PF, CW2_OK = !DeqI<DT>::SPLIT16 && DT != NTK_DT_Q5_K;   // (Q5_K: 15 registers over the budget in that form)
-    // two chunks (128 tokens) per workgroup when that still leaves two workgroups for every CU
-    const int chunks64 = p.chunks;
-    bool cw2 = CW2_OK && al && rt == 2 && nsplit == 1 && chunks64 >= 2 && (long)p.row_wgs * ((chunks64 + 1) / 2) >= 512;
-    if (force_cw == 1 || !CW2_OK) cw2 = false;
-    if (force_cw == 2 && CW2_OK && al && rt == 2 && nsplit == 1 && chunks64 >= 2) cw2 = true;
-    if (cw2) p.chunks = (chunks64 + 1) / 2;
     const dim3 grid((unsigned)((p.row_wgs + 7) / 8 * 8 * p.chunks), nsplit);
     const size_t lds2 = gb_lds_bytes<DT, 2, 1>(), lds1 = gb_lds_bytes<DT, 1, 1>(), lds22 = gb_lds_bytes<DT, 2, 2>();
     static const bool lds_ok = [&] {   // more than 64 KB of dynamic LDS: opt in once per kernel
@@ -1060,7 +1070,7 @@ int ntk_debug_gemm_f16_clock(unsigned long long* out) {   // 4 values
 size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features) {
     if (in_features <= 0 || out_features < 0) return 0;
     return (size_t)ntk::GB_MAX_CHUNKS * ntk::ws_chunk_bytes((in_features + 31) / 32 * 32) + ntk::GB_SCALE_BYTES +
-           (size_t)ntk::GB_MAX_SPLIT * ntk::GB_TOK * (size_t)out_features * sizeof(float) + 256;
+           (size_t)ntk::gb_split_rows(out_features) * ntk::GB_TOK * (size_t)out_features * sizeof(float) + 256;
 }
 
 static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, int n_tokens, int in_features, int weight_dtype, const float* resid,
