@@ -10,8 +10,8 @@ lives here and not under tests/).  What it asserts:
     12 % either way (events read high: they contain the boundaries inside a run of launches; profiled kernels read long), and the
     PMC traffic per GEMV launch is within [0.97, 1.08] x the algorithmic bytes.
 Slack on "trace kernel time vs un-profiled ms_per_step": 10 %.  A process under rocprofv3 runs its kernels at a lower clock
-(MI355X_MICROARCH.md, DVFS: profiled passes 1.89-1.95 GHz against 2.02 un-profiled) -- measured in the final pass of round 3 (one box,
-one commit) +1.6 % on the HBM-bound Q8_0 kernels, +5.0 % / +8.5 % on the VALU-bound K-quant ones (8B / 70B Q4_K_M) -- so the trace of a
+(MI355X_MICROARCH.md, DVFS: profiled passes 1.89-1.95 GHz against 2.02 un-profiled) -- measured in the final passes of round 3 (each one box,
+one commit) +0.6...1.7 % on the HBM-bound Q8_0 kernels, +3...5 % / +7.5...8.5 % on the VALU-bound K-quant ones (8B / 70B Q4_K_M) -- so the trace of a
 correct run can exceed the un-profiled step time by that much; a trace that exceeded it by clearly more would mean the two files are
 not of the same tree."""
 import json
