@@ -920,7 +920,8 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const ReduceArgs a) 
 }
 
 // one chunk's planes + sums (+ the record of zeros), rounded to 256 B
-static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * GB_STEP_BYTES + (size_t)(in / 32 + 8) * GB_AUX_BYTES + 255) / 256 * 256; }
+// (the sums: whole units of 8 steps covering steps 0 .. in/32 + 7 -- the pre-pass writes a full unit of zeros behind the last step)
+static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * GB_STEP_BYTES + (size_t)((in / 32 + 15) / 8) * GB_MIN_UNIT_BYTES + 255) / 256 * 256; }
 
 constexpr size_t GB_SCALE_BYTES = 2 * GB_MAX_CHUNKS * GB_TOK * sizeof(float);   // the launch's 1 / s and s
 

@@ -165,6 +165,22 @@ def test_gemm_quant_f16_matches_per_token_oracle(qname, T, out_f, in_f):
     assert np.array_equal(Y2, (R + Y).astype(np.float32)) or np.abs(Y2 - (R + Y)).max() <= 1e-6 * np.abs(Y).max()
 
 
+@pytest.mark.parametrize("in_f", [128, 384, 640])
+def test_gemm_quant_f16_q8_0_column_counts_of_half_a_sum_unit(in_f):
+    """Q8_0 takes any multiple of 128 columns; the pre-pass lays the step sums out in units of 8 steps (256 columns) and writes a whole
+    unit of zeros behind the last step -- with 128 columns left over that unit starts half a unit further: several chunks, so that an
+    overrun of one chunk's area would land in the next chunk's planes."""
+    gt = QUANT["Q8_0"]
+    dt = G.GGML_TO_DT[gt]
+    r = rng(in_f)
+    T, out_f = 200, 48
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    ref = np.stack([O.gemv(W, X[t], out_f, in_f, dt) for t in range(T)])
+    Y = gemm_ws_gpu(W, X, out_f, in_f, dt)
+    assert np.abs(Y - ref).max() <= tol_for(ref, in_f), np.abs(Y - ref).max()
+
+
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q6_K"])
 def test_gemm_quant_f16_outlier_channels_and_degenerate_tokens(qname):
     """The per-token scale of the FP16 split (csrc/gemm_f16.hip) under the activations that stress it: outlier channels 10^4 above the
