@@ -165,6 +165,18 @@ def test_gemm_quant_f16_matches_per_token_oracle(qname, T, out_f, in_f):
     assert np.array_equal(Y2, (R + Y).astype(np.float32)) or np.abs(Y2 - (R + Y)).max() <= 1e-6 * np.abs(Y).max()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gemm_quant_f16_random_sweep(seed):
+    """tools/gemm_fuzz.py: 80 random (format, tokens, rows, columns, residual / several matrices) launches of the FP16 GEMM per seed
+    against the oracle's per-token GEMV -- ragged chunks, odd chunk counts, ragged row tiles, both row-tile heights."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r_ = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_fuzz.py"), "--cases", "80", "--seed", str(seed)], capture_output=True,
+                        text=True, timeout=600)
+    assert r_.returncode == 0 and "gemm fuzz ok" in r_.stdout, (r_.stdout[-2000:], r_.stderr[-2000:])
+
+
 @pytest.mark.parametrize("in_f", [128, 384, 640])
 def test_gemm_quant_f16_q8_0_column_counts_of_half_a_sum_unit(in_f):
     """Q8_0 takes any multiple of 128 columns; the pre-pass lays the step sums out in units of 8 steps (256 columns) and writes a whole
