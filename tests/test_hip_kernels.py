@@ -646,6 +646,29 @@ def test_attention_prefill_tiled_at_model_shapes(T, start, nh, nkv, hd):
     assert np.abs(got - ref).max() <= 2e-5, np.abs(got - ref).max()
 
 
+def test_attention_prefill_mfma_random_sweep():
+    """40 random (tokens, start position, head counts) launches of the matrix-core prompt attention against the oracle: every
+    combination of full / diagonal / ragged key tiles, waves with and without live queries, prefixes that end inside a tile (the
+    clamped staging path of the launch's last tile), large score offsets (the rescale of the accumulators is skipped while no
+    lane's maximum moves: it must not be skipped when one does)."""
+    r = rng(4711)
+    hd = 128
+    for case in range(40):
+        nkv = int(r.choice([1, 2, 8])); nh = nkv * int(r.choice([1, 2, 4]))
+        T = int(r.choice([1, 2, 15, 16, 17, 63, 64, 65, 100, 128, 129, 200, 333]))
+        start = int(r.choice([0, 0, 1, 7, 63, 64, 65, 100, 257]))
+        max_seq = start + T + int(r.integers(0, 70))
+        kc, vc = make_cache(r, start + T, max_seq, nkv, hd)
+        Q = (r.standard_normal(T * nh * hd) * float(r.choice([0.1, 1.0, 6.0]))).astype(np.float32)   # x 6: maxima that keep moving
+        scale = float(1 / np.sqrt(hd))
+        ref = O.attention_prefill(Q, kc, vc, T, start, nh, nkv, hd, max_seq, scale)
+        od = DB.from_numpy(np.full(T * nh * hd, np.nan, np.float32))
+        ops.launch_attention_prefill(od, DB.from_numpy(Q), DB.from_numpy(kc), DB.from_numpy(vc), T, start, nh, nkv, hd, max_seq, scale)
+        got = od.numpy()
+        assert np.isfinite(got).all(), (case, T, start, nh, nkv)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max())), (case, T, start, nh, nkv, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize("pos", [0, 1, 15, 16, 63, 300, 2047])
 @pytest.mark.parametrize("nh,nkv,hd,table", [(32, 8, 128, True), (32, 8, 128, False), (4, 2, 64, True), (64, 8, 128, True), (6, 3, 80, False)])
 def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd, table):
