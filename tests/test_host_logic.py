@@ -48,6 +48,22 @@ def test_experiments_are_a_separate_library():
     assert not [n for n in names if not hasattr(X, n)]
 
 
+def test_prompt_gemm_workspace_covers_its_layout():
+    """ntk_gemm_quant_workspace_bytes (no GPU needed) against the layout csrc/gemm_f16.hip describes: per 64-token chunk (16 of them) the
+    FP16 planes of in/32 + 1 steps (8 KB each) and the step sums in WHOLE units of 8 steps up to step in/32 + 7 (2 KB each: the
+    pre-pass writes a full unit of zeros behind the last step -- a 128-column remainder used to overrun the area), then the tokens'
+    scales (2 x 1024 floats) and the partial sums of K splits (32 chunk x split products for matrices of <= 8192 rows, 16 above)."""
+    L = _lib.lib()
+    L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+    for in_f in (128, 256, 384, 640, 4096, 14336, 28672):
+        for out_f in (16, 4096, 8192, 8208, 28672):
+            steps = in_f // 32
+            chunk = (steps + 1) * 8192 + ((steps + 8 + 7) // 8) * 2048
+            need = 16 * chunk + 2 * 1024 * 4 + (32 if out_f <= 8192 else 16) * 64 * out_f * 4
+            got = L.ntk_gemm_quant_workspace_bytes(C.c_int(in_f), C.c_int(out_f))
+            assert need <= got <= need + 16 * 256 + 4096, (in_f, out_f, need, got)
+
+
 def test_abi_basics_without_gpu():
     L = _lib.lib()
     assert L.ntk_abi_version() == 1
