@@ -402,12 +402,15 @@ def test_gemv_fused_norm_qkv(qname, in_f, rows):
 
 
 @pytest.mark.parametrize("qname", ["Q4_K", "Q6_K"])
+@pytest.mark.parametrize("outliers", [False, True])
 @pytest.mark.parametrize("out_f,in_f,norm,resid,silu", [(64, 256, False, False, False), (300, 4096, True, False, False), (257, 4096, False, True, False),
                                                        (1024, 8192, True, False, True), (96, 2048, False, False, True), (40, 8192, False, True, False)])
-def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu):
+def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu, outliers):
     """The integer-activation form of the Q4_K / Q6_K GEMV (activations as three int8 digit planes per 32-column sub-block, products on
     v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 48 MiB -- forced for every eligible launch and
-    compared with the oracle at the GEMV's tolerance: plain, RMSNorm prologue, residual epilogue, gate|up + SiLU."""
+    compared with the oracle at the GEMV's tolerance: plain, RMSNorm prologue, residual epilogue, gate|up + SiLU.  `outliers`: a few
+    channels 1000 x the rest, the shape real Llama activations have and the synthetic ones lack (no checkpoint exists offline): the
+    31 neighbours of an outlier in its sub-block keep 2^-23 of the OUTLIER as their error, which is what the form trades."""
     from ntransformer_amd import _lib
     L = _lib.lib()
     L.ntk_gemv_tune_xi_min_bytes.argtypes = [C.c_size_t]
@@ -416,6 +419,7 @@ def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu):
     dt = G.GGML_TO_DT[gt]
     r = rng(out_f + in_f + 3 * norm + 5 * resid + 7 * silu + gt)
     x = (r.standard_normal(in_f) * np.exp(r.uniform(-3, 3, in_f))).astype(np.float32)   # wide dynamic range inside every sub-block
+    if outliers: x[r.choice(in_f, 4, replace=False)] *= 1000.0
     nw = (1.0 + 0.1 * r.standard_normal(in_f)).astype(np.float32)
     xin = O.rmsnorm(x[None, :], nw, 1e-5)[0] if norm else x
     W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
