@@ -3,6 +3,8 @@ against the golden logits produced by the reference's own host code + CPU kernel
 teacher-forced on the golden token stream.  North-star tolerance: |dlogit| <= 1e-3."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -225,11 +227,14 @@ def _scratch_dir():
     return "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
 
 
-def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
+def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=None, rel_bar=False):
+    """patch(path): edits the written GGUF in place before anybody loads it; rel_bar: the 1e-3 scales with the logits' RMS (models whose
+    activations were made larger on purpose)."""
     import time
     spec = E.synth_spec(preset, mix, layers=layers)
     path = os.path.join(_scratch_dir(), "_parity_%s.gguf" % tag)
     E.synth_write_gguf(path, spec)
+    if patch is not None: patch(path)
     try:
         threads = _oracle_threads()
         m = O.OracleModel(path, ctx)
@@ -245,7 +250,7 @@ def _parity_at_config(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
         t_oracle = time.perf_counter() - t0
         want = np.stack(want)
         assert np.isfinite(want).all()
-        bar = TOL
+        bar = TOL * (max(1.0, float(np.sqrt((want ** 2).mean()))) if rel_bar else 1.0)
         observed = {}
         # reference: the reference's exact launch sequence (per-token prompt loop, 15 launches per layer, --no-fuse);
         # launchers: batched MFMA prompt + 1:1 decode; fused / graph: batched prompt + fused decode (eager / hipGraph replay)

@@ -110,13 +110,18 @@ def _teacher_stream(m, prompt, fed, perturb_seed=None, rel=6e-8):
     return np.stack(out)
 
 
-def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
+def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=None, flip_scale=1.0, abs_scale=1.0, kv_scale=1.0):
+    """flip_scale: factor on the two bars that contain F16 rounding flips (layer vs oracle, end to end) and abs_scale: on the absolute
+    logit bar of the forced arbiter, kv_scale: on the excess of a stored half over rounding -- 1 for the seeded models; a model built
+    to amplify (outlier channels) states its factors.  The per-layer bar against the arbiter forced to the engine's roundings (5e-5 of
+    the layer output's RMS) never scales."""
     spec = E.synth_spec(preset, mix, layers=layers)
     path = os.path.join(_scratch_dir(), "_depth_%s.gguf" % tag)
     E.synth_write_gguf(path, spec)
+    if patch is not None: patch(path)   # edits the GGUF in place before anybody loads it
     rec = {"test": tag, "model": preset, "mix": mix, "layers": layers, "prompt_tokens": n_prompt, "decode_steps": n_decode,
-           "bars": {"layer_vs_arbiter_rel": LAYER_BAR_ARBITER, "layer_vs_oracle_rel": LAYER_BAR_ORACLE, "kv_rel": KV_BAR,
-                    "forced_abs": FORCED_BAR, "free_factor": FREE_FACTOR, "e2e_sanity_abs": E2E_SANITY_BAR}}
+           "bars": {"layer_vs_arbiter_rel": LAYER_BAR_ARBITER, "layer_vs_oracle_rel": LAYER_BAR_ORACLE * flip_scale, "kv_rel": KV_BAR * kv_scale,
+                    "forced_abs": FORCED_BAR * abs_scale, "free_factor": FREE_FACTOR, "e2e_sanity_abs": E2E_SANITY_BAR * flip_scale}}
     try:
         m = O.OracleModel(path, ctx)
         per = m.nkv * m.hd
@@ -174,8 +179,8 @@ def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
                     pm["vs_oracle"] = max(pm["vs_oracle"], e_orc)
                     flips_layer += int((rk.reshape(-1) != m.k_cache[l][lo:hi]).sum() + (rv.reshape(-1) != m.v_cache[l][lo:hi]).sum())
                     assert e_arb <= LAYER_BAR_ARBITER, (tag, name, "layer", l, "pos", start, e_arb)
-                    assert e_orc <= LAYER_BAR_ORACLE, (tag, name, "layer", l, "pos", start, e_orc)
-                    assert exkv <= KV_BAR, (tag, name, "layer", l, "pos", start, exkv)
+                    assert e_orc <= LAYER_BAR_ORACLE * flip_scale, (tag, name, "layer", l, "pos", start, e_orc)
+                    assert exkv <= KV_BAR * kv_scale, (tag, name, "layer", l, "pos", start, exkv)
                     # teacher forcing of the cache: the next step's layers see the ORACLE's rows at these positions
                     eng.kv_write(l, start, m.k_cache[l][lo:hi].reshape(T, per), m.v_cache[l][lo:hi].reshape(T, per))
         eng.close()
@@ -249,12 +254,15 @@ def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256):
                                                "half_roundings_differing_from_arbiter": nmis, "cache_elements": nel,
                                                "max_kv_excess_rel": excess}
             rec["c_end_to_end_vs_oracle"][mode] = [float(x) for x in e_e2e]
-            assert e_forced.max() <= FORCED_BAR, (tag, mode, "forced arbiter", e_forced)
-            assert excess <= KV_BAR, (tag, mode, "a stored half is further from the exact value than rounding + F32 error allow", excess)
+            assert e_forced.max() <= FORCED_BAR * abs_scale, (tag, mode, "forced arbiter", e_forced)
+            assert excess <= KV_BAR * kv_scale, (tag, mode, "a stored half is further from the exact value than rounding + F32 error allow", excess)
             assert e_free <= free_bar, (tag, mode, "free arbiter", e_free, free_bar)
-            assert e_e2e.max() <= E2E_SANITY_BAR, (tag, mode, "end to end", e_e2e)
+            # (flip_scale > 1: an amplifying model -- its end-to-end distance is judged against what separates two valid evaluations of
+            # the reference arithmetic there, the oracle and the free arbiter, not against the seeded models' 5e-3)
+            e2e_bar = E2E_SANITY_BAR if flip_scale == 1.0 else max(E2E_SANITY_BAR * flip_scale, 3.0 * e_oracle_free)
+            assert e_e2e.max() <= e2e_bar, (tag, mode, "end to end", e_e2e, e2e_bar)
             top2 = np.sort(want, axis=1)[:, -2:]
-            clear = (top2[:, 1] - top2[:, 0]) > 2 * E2E_SANITY_BAR
+            clear = (top2[:, 1] - top2[:, 0]) > 2 * e2e_bar
             assert np.array_equal(got.argmax(1)[clear], want.argmax(1)[clear]), (tag, mode, "arg-max")
         rec["b_c_seconds"] = round(time.perf_counter() - t0, 2)
         rec["passed"] = True
@@ -281,3 +289,42 @@ def test_depth_70b_width_16_layers(mix):
     """BASELINE configs 4 / 5 at their real width (H 8192, FFN 28672, 64 / 8 heads), 16 of the 80 layers: load_layer
     (transformer.cpp:286-328) over the Q5_K attn_v / Q6_K ffn_down mix well beyond the first two layers."""
     _depth_parity("70b_width_16_layers_" + mix.lower(), "70b", mix, 16, 18, 3)
+
+
+def test_depth_8b_q4_k_m_outlier_channels():
+    """Real Llama activations have a few channels hundreds of times larger than the rest; the seeded synthetic tensors do not (no
+    checkpoint exists offline).  This model gets them: eight channels of every RMSNorm weight vector (F32 tensors of the GGUF) x 60, so
+    that the inputs of every Q|K|V, gate|up and LM-head launch carry outliers -- with the integer-activation GEMV forced for every
+    eligible launch (its block-floating digit planes are what outliers stress) and the prompt through the two-piece FP16 GEMM.  8B
+    width, Q4_K_M mix, 6 layers, the same bars as the other depth tests.  (End to end such a model amplifies F16 rounding flips --
+    0.017 of a logit RMS of 5 with or without the integer form, same box -- which is why it is judged layer by layer and against the
+    arbiter, like the others.)"""
+    import ctypes as C
+    from ntransformer_amd import _lib, gguf as G
+    chans = [5, 77, 1033, 2047, 2500, 3001, 3333, 4000]
+
+    def patch(path):
+        f = G.read_gguf(path)
+        spots = [f.data_offset + t.offset for t in f.tensors.values() if t.name.endswith("_norm.weight") and t.ggml_type == G.GGML_F32]
+        f.close()
+        assert len(spots) >= 13   # 2 per layer + the output norm
+        with open(path, "r+b") as fh:
+            for base in spots:
+                for c in chans:
+                    fh.seek(base + 4 * c)
+                    v = np.frombuffer(fh.read(4), np.float32)[0]
+                    fh.seek(base + 4 * c)
+                    fh.write(np.float32(v * 60.0).tobytes())
+    L = _lib.lib()
+    L.ntk_gemv_tune_xi_min_bytes.argtypes = [C.c_size_t]
+    L.ntk_gemv_tune_xi_min_bytes.restype = None
+    L.ntk_gemv_tune_xi_min_bytes(0)
+    try:
+        # The model is adversarial for F32 itself: the ORACLE (the reference's arithmetic) sits 2.0e-4 from the float64 arbiter forced
+        # to its own roundings here, 20 x its distance on the seeded models, and a flipped half moves a layer output 6e-4 of its RMS
+        # against 1e-4.  Hence flip_scale 6; abs_scale 10 (the forced-arbiter bar on logits is the north star's 1e-3 itself, not a
+        # tenth of it); kv_scale 5.  Observed (profiles/r03_parity_outlier_channels.txt): per layer 2.1e-5 of the RMS with the integer
+        # form forced (7e-6 without), logits 3.0e-4 / 7.8e-5 from the forced arbiter, the FP16 prompt GEMM 2.2e-4.
+        _depth_parity("8b_q4_k_m_outlier_channels_6_layers", "8b", "Q4_K_M", 6, 20, 3, patch=patch, flip_scale=6.0, abs_scale=10.0, kv_scale=5.0)
+    finally:
+        L.ntk_gemv_tune_xi_min_bytes(48 << 20)
