@@ -160,6 +160,28 @@ typedef struct ntk_gemv_seg {
 int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w,
                    float eps, const float* resid, int silu_pair, void* stream);
 
+/* Engine-owned load-time repack of a K-quant matrix and the decode GEMV on the int8 matrix cores that reads it (csrc/gemv_rp.hip; SURVEY
+ * 7.1 step 7 / 8(b) "Ownership": repack buffers belong to the engine object, the 1:1 ntk_gemv above keeps taking raw GGUF).  Q4_K, Q5_K,
+ * Q6_K; in_features % 256 == 0 and <= 32768; rows padded to tiles of 16 inside the buffer.  Same integers, same scales (ntk_rp_dequant gives
+ * the GGUF dequantisation bit for bit), 1.028 x / 1.023 x / 1.000 x the GGUF bytes.  Arithmetic: x -> per 256-column super-block three
+ * signed base-256 digit planes of rint(x 2^(22-e)) (e = exponent of the block's largest |x|: <= 2^-23 of it per term), exact integer dot
+ * products per sub-block on v_mfma_i32_16x16x64_i8, the reference's factorisation (gemm.cu:190-244, 297-354, 421-459) around them.
+ *   ntk_rp_bytes        size of the repacked form (0: unsupported dtype / shape)
+ *   ntk_rp_pack         raw GGUF [rows][in] -> dst (16-byte aligned, ntk_rp_bytes); stream ordered
+ *   ntk_rp_dequant      parity instrumentation: the weights as F32 [rows][in] from the repacked form
+ *   ntk_gemv_rp(_fused) = ntk_gemv / ntk_gemv_fused with segs[i].W pointing at REPACKED tensors (same epilogues; one or two formats) */
+size_t ntk_rp_bytes(int dtype, int rows, int in_features);
+int ntk_rp_pack(void* dst, const void* raw, int rows, int in_features, int dtype, void* stream);
+int ntk_rp_dequant(float* out, const void* rp, int rows, int in_features, int dtype, void* stream);
+int ntk_gemv_rp(float* y, const void* rp, const float* x, int out_features, int in_features, int weight_dtype, void* stream);
+int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                      const float* resid, int silu_pair, void* stream);
+/* parity instrumentation of the above: the LDS image its prologue builds from x (4 in + 68 in/256 bytes: three digit planes, a zero plane,
+ * 64 bytes of sub-block-sum digits and one 2^(e-22) per super-block; nsub = 8: 32-column sub-blocks (Q4_K / Q5_K), 16: Q6_K), and
+ * D[16][16] = A[16][64] . B[64][16] on the matrix instruction under the lane maps the kernel assumes */
+int ntk_debug_rp_prologue(uint8_t* out, const float* x, const float* norm_w, float eps, int in_features, int nsub, int nwaves, void* stream);
+int ntk_debug_mfma_i8_probe(int* D, const int8_t* A, const int8_t* B, void* stream);
+
 /* RoPE(q,k at *d_pos) + KV store + GQA decode attention over keys 0..*d_pos, one launch
  * (launch_rope + launch_copy_to_kv_cache + launch_attention_decode; attention.cpp:165-190).
  * q [nh*hd], k,v [nkv*hd] are the raw projections (left untouched); d_pos is a DEVICE int.

@@ -85,6 +85,13 @@ def lib() -> C.CDLL:
         "ntk_copy": (i, [vp, vp, i, vp]),
         "ntk_cosine_similarity": (i, [vp, vp, vp, i, vp]),
         "ntk_gemv_fused": (i, [C.POINTER(GemvSeg), i, vp, i, vp, f, vp, i, vp]),
+        "ntk_rp_bytes": (sz, [i, i, i]),
+        "ntk_rp_pack": (i, [vp, vp, i, i, i, vp]),
+        "ntk_rp_dequant": (i, [vp, vp, i, i, i, vp]),
+        "ntk_gemv_rp": (i, [vp, vp, vp, i, i, i, vp]),
+        "ntk_gemv_rp_fused": (i, [C.POINTER(GemvSeg), i, vp, i, vp, f, vp, i, vp]),
+        "ntk_debug_rp_prologue": (i, [vp, vp, vp, f, i, i, i, vp]),
+        "ntk_debug_mfma_i8_probe": (i, [vp, vp, vp, vp]),
         "ntk_gemm_quant": (i, [vp, vp, vp, i, i, i, i, vp, vp]),
         "ntk_attention_decode_split": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, f, i, vp, vp]),
         "ntk_attention_split_scratch_bytes": (C.c_size_t, [i, i, i]),

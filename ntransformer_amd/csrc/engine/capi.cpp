@@ -55,6 +55,7 @@ int nt_engine_set_option(nt_engine_t e, const char* key, const char* value) {
     else if (k == "device_sampling") E(e)->options().device_sampling = on;
     else if (k == "f16_prefill" || k == "bf16_prefill") E(e)->model().set_bf16_prefill(on);   // (the round-2 name stays accepted)
     else if (k == "fuse_attention") E(e)->model().set_fuse_attention(on);
+    else if (k == "repack") E(e)->model().set_repack(on);
     else if (k == "persistent") { E(e)->options().persistent = on; E(e)->model().set_persistent(on); }
     else if (k == "synth_threads") E(e)->options().synth_threads = atoi(value);
     else return NTK_E_SHAPE;

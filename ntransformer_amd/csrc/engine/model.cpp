@@ -66,6 +66,7 @@ void Model::free_all() {
     // a second load() on the same object starts from a clean slate
     token_embd_ = output_norm_ = output_ = DevTensor();
     weight_bytes_ = 0;
+    repack_bytes_ = 0;
     output_tied_ = false;
     host_pos_ = 0;
     attn_regime_ = 0;
@@ -304,11 +305,48 @@ int Model::finish_load(int /*max_context*/) {
     }
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
+    if (repack_) NT_TRY(repack_all());
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
-    fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights)\nFree VRAM: %.1f GB\n",
-            weight_bytes_ / 1073741824.0, fr / 1073741824.0);
+    fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights%s)\nFree VRAM: %.1f GB\n",
+            weight_bytes_ / 1073741824.0, repack_bytes_ ? (" + " + std::to_string(repack_bytes_ / 1073741824.0).substr(0, 5) + " GB repacked for decode").c_str() : "",
+            fr / 1073741824.0);
     return NTK_OK;
+}
+
+// ---- engine-owned repack of the K-quant projections (csrc/gemv_rp.hip): made once, on the device, from the uploaded GGUF bytes, which
+//      stay resident for the 1:1 launchers and the prompt GEMM ----
+int Model::repack_one(DevTensor& t) {
+    if (t.rp || !t.ptr) return NTK_OK;
+    if (t.out_f <= 0 || t.out_f > 0x7FFFFFFF || t.in_f <= 0 || t.in_f > 32768) return NTK_OK;
+    const size_t n = ntk_rp_bytes(t.dtype, (int)t.out_f, (int)t.in_f);
+    if (n == 0 || n > 0xFFFFFFF0ull) return NTK_OK;   // formats / shapes the matrix-core GEMV does not take keep the raw path
+    void* d = nt_hip_malloc(n + 256);
+    if (!d) { err_ = "out of device memory (decode repack)"; return NTK_E_NOMEM; }
+    allocs_.push_back(d);
+    const int st = ntk_rp_pack(d, t.ptr, (int)t.out_f, (int)t.in_f, t.dtype, stream_);
+    if (st != NTK_OK) { err_ = std::string("decode repack failed: ") + ntk_status_string(st); return st; }
+    t.rp = d;
+    t.rp_bytes = n;
+    repack_bytes_ += n;
+    return NTK_OK;
+}
+
+int Model::repack_all() {
+    for (auto& L : layers_) {
+        NT_TRY(repack_one(L.wq)); NT_TRY(repack_one(L.wk)); NT_TRY(repack_one(L.wv)); NT_TRY(repack_one(L.wo));
+        NT_TRY(repack_one(L.w_gate)); NT_TRY(repack_one(L.w_up)); NT_TRY(repack_one(L.w_down));
+    }
+    NT_TRY(repack_one(output_));
+    return ntk_stream_synchronize(stream_);
+}
+
+void Model::set_repack(bool on) {
+    if (on == repack_ && (!on || layers_.empty() || repack_bytes_ > 0)) { repack_ = on; return; }
+    repack_ = on;
+    if (layers_.empty()) return;   // before the load: finish_load() decides
+    for (auto& row : graphs_) for (auto& gx : row) { if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx)); gx = nullptr; }
+    if (on && repack_all() != NTK_OK) repack_ = false;
 }
 
 int Model::alloc_buffers() {   // transformer.cpp:330-391
@@ -619,7 +657,13 @@ int Model::enqueue_token(bool greedy) {
         if (is_quant(w.dtype)) {
             ntk_gemv_seg seg = {w.ptr, logits_, (int)w.out_f, w.dtype};
             prof_mark(0, true);
-            NT_TRY(ntk_gemv_fused(&seg, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s));
+            int st = NTK_E_DTYPE;
+            if (repack_ && w.rp) {
+                ntk_gemv_seg rs = {w.rp, logits_, (int)w.out_f, w.dtype};
+                st = ntk_gemv_rp_fused(&rs, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s);
+                if (st != NTK_OK && st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) return st;
+            }
+            if (st != NTK_OK) NT_TRY(ntk_gemv_fused(&seg, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s));
             prof_mark(0, false);
         } else {
             NT_TRY(ntk_rmsnorm(residual_ + H, hidden_, (const float*)output_norm_.ptr, 1, (int)w.in_f, cfg_.norm_eps, s));
@@ -681,6 +725,19 @@ int Model::enqueue_layers(int first, int last_layer) {
                        const float* resid) -> int {
         const float* nw = norm ? (const float*)norm->ptr : nullptr;
         bool done[3] = {false, false, false};
+        if (repack_) {   // every matrix has its repacked form: one launch of the matrix-core GEMV, whatever the mix of K-quant formats
+            bool all = true;
+            for (int a = 0; a < n; ++a) all = all && ws[a]->rp != nullptr && ws[a]->in_f == ws[0]->in_f;
+            if (all) {
+                ntk_gemv_seg segs[3];
+                for (int a = 0; a < n; ++a) segs[a] = {ws[a]->rp, ys[a], (int)ws[a]->out_f, ws[a]->dtype};
+                mark(0, true);
+                const int st = ntk_gemv_rp_fused(segs, n, x, (int)ws[0]->in_f, nw, cfg_.norm_eps, resid, 0, s);
+                mark(0, false);
+                if (st == NTK_OK) return NTK_OK;
+                if (st != NTK_E_DTYPE && st != NTK_E_ALIGN && st != NTK_E_SHAPE) return st;   // (those: the raw-GGUF launches below take over)
+            }
+        }
         if (n > 1 && !resid) {   // matrices in two K-quant formats (Q4_K_M's attn_v): still one launch when the library has the pair
             bool all_quant = true, mixed = false;
             for (int a = 0; a < n; ++a) { all_quant = all_quant && is_quant(ws[a]->dtype); mixed = mixed || ws[a]->dtype != ws[0]->dtype; }
@@ -773,7 +830,13 @@ int Model::enqueue_layers(int first, int last_layer) {
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
             ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
             mark(0, true);
-            NT_TRY(ntk_gemv_fused(segs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s));
+            int st = NTK_E_DTYPE;
+            if (repack_ && L.w_gate.rp && L.w_up.rp) {
+                ntk_gemv_seg rs[2] = {{L.w_gate.rp, gate_buf, I, L.w_gate.dtype}, {L.w_up.rp, up_buf, I, L.w_up.dtype}};
+                st = ntk_gemv_rp_fused(rs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s);
+                if (st != NTK_OK && st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) return st;
+            }
+            if (st != NTK_OK) NT_TRY(ntk_gemv_fused(segs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s));
             mark(0, false);
         } else {
             const DevTensor* ws[2] = {&L.w_gate, &L.w_up};

@@ -20,6 +20,8 @@ struct DevTensor {
     int dtype = 0;
     int64_t in_f = 0, out_f = 0;
     size_t nbytes = 0;
+    void* rp = nullptr;    // engine-owned repack for the matrix-core decode GEMV (csrc/gemv_rp.hip); nullptr: none
+    size_t rp_bytes = 0;
 };
 
 struct LayerWeights {
@@ -83,6 +85,11 @@ public:
     // longer ones keep the launch path.  Turned off for good if the kernel ever reports a bounded wait that gave up.
     void set_persistent(bool on);   // EXPERIMENTS=1 builds only; otherwise stays off
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
+    // Decode GEMVs of the K-quant matrices from the load-time repack (ntk_gemv_rp_fused) instead of the raw GGUF blocks (ntk_gemv_fused).
+    // The repack is made at load unless the option was switched off BEFORE the load; the switch itself works at any time.
+    void set_repack(bool on);
+    bool repack() const { return repack_; }
+    uint64_t repack_bytes() const { return repack_bytes_; }
     void set_bf16_prefill(bool on) { bf16_prefill_ = on; }   // batched prompt: FP16-MFMA (gemm_f16.hip; the option keeps its round-2 name) or the F32-MFMA form (16)
     bool persistent_available() const { return persistent_plan_ != nullptr; }
     void* persistent_plan() const { return persistent_plan_; }
@@ -121,6 +128,8 @@ private:
     enum Shard { WHOLE, ROWS, COLS };
     // upload this rank's part of a full host tensor [out_f][in_f]: everything, rows [rank * out/world ...), or the column slice
     int upload_shard(DevTensor& dst, const void* host_full, int dtype, int64_t in_f, int64_t out_f, size_t nbytes_full, Shard how);
+    int repack_all();                 // the repacked form of every K-quant projection (after the upload)
+    int repack_one(DevTensor& t);
     int tp_check_shapes();            // the head / FFN / block divisibility the slices need
     int tp_allreduce(float* hidden, int n);   // hidden += sum over ranks of the partial vectors in the current slot
     float* tp_slot() const;           // where the next partial vector goes
@@ -177,6 +186,8 @@ private:
     size_t gemm_ws_bytes_ = 0;
     bool bf16_prefill_ = true;
     unsigned* attn_sync_ = nullptr;  // 3 words for ntk_attention_gemv_fused (attention producers inside the Wo launch)
+    bool repack_ = true;             // decode GEMVs read the repacked K-quant tensors
+    uint64_t repack_bytes_ = 0;
     bool fuse_attention_ = false;    // attention + Wo projection as one launch: measured SLOWER than two launches (profiles/r02_*): opt-in
     int tp_rank_ = 0, tp_world_ = 1;
     void* tp_comm_ = nullptr;        // this rank's communication buffer (flags + two slots of max_seq x H floats)

@@ -1,0 +1,762 @@
+// gemv_rp.hip -- K-quant decode GEMV on the int8 matrix cores, from an ENGINE-OWNED load-time repack of the GGUF blocks
+// (SURVEY 7.1 step 7 / 8(b) "Ownership": repack buffers belong to the engine; the 1:1 ntk_gemv keeps taking raw GGUF).
+//
+// Replaces, for the engine's fused decode path, gemv_q4_k / q5_k / q6_k_kernel of the reference (src/cuda/gemm.cu:158-470):
+// the same weights (bit-identical integers and scales, checked by ntk_rp_dequant), the same factorisation
+//      y[r] = sum_sb  d * ( sum_j sc_j * sum_{k in j} q_k x_k )  -  dmin * sum_j m_j * sum_{k in j} x_k          (Q4_K / Q5_K)
+//      y[r] = sum_sb  d * ( sum_j sc_j * sum_{k in j} q_k x_k )  -  32 d * sum_j sc_j * sum_{k in j} x_k          (Q6_K)
+// with the inner sums as EXACT integer dot products: x is converted once per workgroup into three signed base-256 digit planes
+// X_k = rint(x_k 2^(22-e)) (e = exponent of the largest |x| of the 256-column super-block; error per term <= 2^-23 of that maximum,
+// the level of the F32 rounding it replaces), and v_mfma_i32_16x16x64_i8 multiplies 16 weight rows x 64 columns by the digit
+// planes of the two (four) sub-blocks the 64 columns span.  Why: the VALU decoders of gemv.hip issue ~250 vector instructions per
+// 4096 weights and are bound by that (84 % VALU issue, 0.51-0.67 of HBM on the long launches, profiles/r03_gemv_microbench.txt);
+// here the unpack is 3 instructions per 8 weights, the per-(row, sub-block) scale work 4 per 1024 weights, and nothing is staged
+// through LDS: a wave's 1 KiB load IS the B operand of two MFMAs.
+//
+// Repacked layout ("rp", one allocation per tensor; tile = 16 rows, item = tile x 256-column super-block):
+//   P1 [tile][sb][step 0..1][S1 bytes]   step = 128 columns.  Bytes 16 l .. 16 l + 15 belong to lane l = 16 kg + i (row i of the tile):
+//        byte b: low nibble  = low 4 bits of the quant of column 128 s + 16 kg + b        (operand of the MFMA of half 0)
+//                high nibble = ...                          column 128 s + 64 + 16 kg + b   (half 1)
+//        Q5_K: + 256 bytes, dword l: bit 8 y + 4 h + v = bit 4 of the quant of column 128 s + 64 h + 16 kg + 4 v + y
+//        Q6_K: + 512 bytes, dwords 2 l + h: bits 8 y + 2 v (+1) = bits 4..5 of the quant of that column
+//   P2 [tile][sb][S2 bytes]   16 rows x 16 bytes: Q4_K / Q5_K {sc[8], m[8]} (the 6-bit values as bytes), Q6_K sc[16] (int8);
+//        then 16 x {d, dmin} (FP16 pairs; Q6_K: 16 x d).
+//   Bytes: Q4_K 2368 per item (GGUF 2304: 1.028 x), Q5_K 2880 (2816: 1.023 x), Q6_K 3360 (3360: 1.000 x).
+//   Rows are padded to whole tiles with zero weights.
+//
+// MFMA roles: first operand (M = 16) = digit planes of x from LDS, entry m = 4 jj + p (sub-block jj of the 64 columns, digit p; p = 3
+// unused), zero outside its own sub-block; second operand (N = 16) = the 16 weight rows.  Accumulator lane (row i = lane & 15,
+// mg = lane >> 4) register r = digit r of sub-block mg: a lane scales ITS row by ITS sub-block's scale (v_bfe + 3 v_mad_i32_i24),
+// sums the super-block in integers, and converts once per super-block.  The minimum / offset term is one more MFMA per super-block:
+// the row's m[8] (sc[16]) against the digits of the sub-block sums of X.
+#include "common.hip.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace ntk {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+
+template <int DT> struct Rp;
+template <> struct Rp<NTK_DT_Q4_K> { static constexpr int S1 = 1024, S2 = 320, BB = 144, NSUB = 8; };
+template <> struct Rp<NTK_DT_Q5_K> { static constexpr int S1 = 1280, S2 = 320, BB = 176, NSUB = 8; };
+template <> struct Rp<NTK_DT_Q6_K> { static constexpr int S1 = 1536, S2 = 288, BB = 210, NSUB = 16; };
+
+static bool rp_supported(int dt) { return dt == NTK_DT_Q4_K || dt == NTK_DT_Q5_K || dt == NTK_DT_Q6_K; }
+static size_t rp_s1(int dt) { return dt == NTK_DT_Q4_K ? 1024 : dt == NTK_DT_Q5_K ? 1280 : 1536; }
+static size_t rp_s2(int dt) { return dt == NTK_DT_Q6_K ? 288 : 320; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// raw GGUF accessors (reference src/core/types.h:112-137): the quant integer of column cc of a super-block
+// ------------------------------------------------------------------------------------------------------------------
+template <int DT> __device__ __forceinline__ int raw_q(const uint8_t* blk, int cc) {
+    if constexpr (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K) {
+        const int chunk = cc >> 6, l = cc & 31, hi = (cc >> 5) & 1;
+        const uint8_t* qs = blk + (DT == NTK_DT_Q4_K ? 16 : 48);
+        const int by = qs[32 * chunk + l];
+        int q = hi ? (by >> 4) : (by & 15);
+        if constexpr (DT == NTK_DT_Q5_K) q |= ((blk[16 + l] >> (2 * chunk + hi)) & 1) << 4;
+        return q;
+    } else {
+        const int n = cc >> 7, quarter = (cc >> 5) & 3, l = cc & 31;
+        const int by = blk[64 * n + l + ((quarter & 1) ? 32 : 0)];
+        const int nib = (quarter >= 2) ? (by >> 4) : (by & 15);
+        const int hi2 = (blk[128 + 32 * n + l] >> (2 * quarter)) & 3;
+        return nib | (hi2 << 4);
+    }
+}
+
+// P1 + P2 of one item (tile, sb): 128 threads build the two step records, 16 the row records
+template <int DT>
+__global__ __launch_bounds__(128) void rp_pack_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ raw, int rows, int nsb, size_t p2_off) {
+    using F = Rp<DT>;
+    const int item = blockIdx.x, tile = item / nsb, sb = item - tile * nsb;
+    const int t = threadIdx.x, s = t >> 6, l = t & 63, i = l & 15, kg = l >> 4;
+    const int row = 16 * tile + i;
+    const bool live = row < rows;
+    const size_t row_bytes = (size_t)nsb * F::BB;
+    const uint8_t* blk = raw + (size_t)(live ? row : 0) * row_bytes + (size_t)sb * F::BB;
+    uint8_t* p1 = dst + (size_t)item * (2 * F::S1) + (size_t)s * F::S1;
+    uint32_t w[4] = {0u, 0u, 0u, 0u}, hb = 0u, hh[2] = {0u, 0u};
+    if (live) {
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const int c0 = 128 * s + 16 * kg + b;
+            const int q0 = raw_q<DT>(blk, c0), q1 = raw_q<DT>(blk, c0 + 64);
+            w[b >> 2] |= (uint32_t)((q0 & 15) | ((q1 & 15) << 4)) << (8 * (b & 3));
+            const int v = b >> 2, y = b & 3;
+            if constexpr (DT == NTK_DT_Q5_K) hb |= (uint32_t)((q0 >> 4) & 1) << (8 * y + v) | (uint32_t)((q1 >> 4) & 1) << (8 * y + 4 + v);
+            if constexpr (DT == NTK_DT_Q6_K) { hh[0] |= (uint32_t)((q0 >> 4) & 3) << (8 * y + 2 * v); hh[1] |= (uint32_t)((q1 >> 4) & 3) << (8 * y + 2 * v); }
+        }
+    }
+    *reinterpret_cast<u4*>(p1 + 16 * l) = u4{w[0], w[1], w[2], w[3]};
+    if constexpr (DT == NTK_DT_Q5_K) *reinterpret_cast<uint32_t*>(p1 + 1024 + 4 * l) = hb;
+    if constexpr (DT == NTK_DT_Q6_K) *reinterpret_cast<u2*>(p1 + 1024 + 8 * l) = u2{hh[0], hh[1]};
+    if (t < 16) {   // row record of row t
+        const int r = 16 * tile + t;
+        const bool lv = r < rows;
+        const uint8_t* b2 = raw + (size_t)(lv ? r : 0) * row_bytes + (size_t)sb * F::BB;
+        uint8_t* p2 = dst + p2_off + (size_t)item * F::S2;
+        uint8_t rec[16];
+        uint16_t d = 0, dmin = 0;
+        for (int k = 0; k < 16; ++k) rec[k] = 0;
+        if (lv) {
+            if constexpr (DT == NTK_DT_Q6_K) {
+                for (int k = 0; k < 16; ++k) rec[k] = b2[192 + k];
+                d = (uint16_t)(b2[208] | (b2[209] << 8));
+            } else {
+                uint32_t s0, s1, s2;
+                __builtin_memcpy(&s0, b2 + 4, 4); __builtin_memcpy(&s1, b2 + 8, 4); __builtin_memcpy(&s2, b2 + 12, 4);
+                for (int j = 0; j < 8; ++j) {
+                    float sc, mn;
+                    kq_scale_min(s0, s1, s2, j, sc, mn);
+                    rec[j] = (uint8_t)(int)sc; rec[8 + j] = (uint8_t)(int)mn;
+                }
+                d = (uint16_t)(b2[0] | (b2[1] << 8)); dmin = (uint16_t)(b2[2] | (b2[3] << 8));
+            }
+        }
+        for (int k = 0; k < 16; ++k) p2[16 * t + k] = rec[k];
+        if constexpr (DT == NTK_DT_Q6_K) *reinterpret_cast<uint16_t*>(p2 + 256 + 2 * t) = d;
+        else *reinterpret_cast<uint32_t*>(p2 + 256 + 4 * t) = (uint32_t)d | ((uint32_t)dmin << 16);
+    }
+}
+
+// the weights back as floats from the repacked form, with the block formulas of SURVEY Appendix A evaluated product by product
+// (no contraction): w = (d sc) q - (dmin m)   /   w = (d sc) (q - 32).  out [rows][in].  Test / parity instrumentation.
+template <int DT>
+__global__ __launch_bounds__(256) void rp_dequant_kernel(float* __restrict__ out, const uint8_t* __restrict__ rp, int rows, int in, int nsb, size_t p2_off) {
+    using F = Rp<DT>;
+    const int row = blockIdx.x;
+    const int tile = row >> 4, i = row & 15;
+    for (int col = threadIdx.x; col < in; col += blockDim.x) {
+        const int sb = col >> 8, c = col & 255, s = c >> 7, h = (c >> 6) & 1, kg = (c >> 4) & 3, b = c & 15, l = 16 * kg + i;
+        const size_t item = (size_t)tile * nsb + sb;
+        const uint8_t* p1 = rp + item * (2 * F::S1) + (size_t)s * F::S1;
+        const uint8_t* p2 = rp + p2_off + item * F::S2;
+        const int by = p1[16 * l + b];
+        int q = h ? (by >> 4) : (by & 15);
+        const int v = b >> 2, y = b & 3;
+        if constexpr (DT == NTK_DT_Q5_K) q |= (int)((*reinterpret_cast<const uint32_t*>(p1 + 1024 + 4 * l) >> (8 * y + 4 * h + v)) & 1u) << 4;
+        if constexpr (DT == NTK_DT_Q6_K) q |= (int)((*reinterpret_cast<const uint32_t*>(p1 + 1024 + 8 * l + 4 * h) >> (8 * y + 2 * v)) & 3u) << 4;
+        float w;
+        if constexpr (DT == NTK_DT_Q6_K) {
+            const float d = h2f(*reinterpret_cast<const uint16_t*>(p2 + 256 + 2 * i));
+            const float sc = (float)(int)(int8_t)p2[16 * i + (c >> 4)];
+            w = __fmul_rn(__fmul_rn(d, sc), (float)(q - 32));
+        } else {
+            const uint32_t dd = *reinterpret_cast<const uint32_t*>(p2 + 256 + 4 * i);
+            const float d = h2f((uint16_t)(dd & 0xFFFFu)), dmin = h2f((uint16_t)(dd >> 16));
+            const int j = c >> 5;
+            const float sc = (float)p2[16 * i + j], mn = (float)p2[16 * i + 8 + j];
+            w = __fsub_rn(__fmul_rn(__fmul_rn(d, sc), (float)q), __fmul_rn(dmin, mn));
+        }
+        out[(size_t)row * in + col] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the GEMV
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RP_MAXQ = 8;     // super-blocks of x one wave converts in the prologue (register quads)
+constexpr int RP_DEPTH = 2;    // items in flight per wave beside the one being decoded
+
+struct RpSeg {
+    const uint8_t* rp;   // repacked tensor (P1, then P2 at p2_off)
+    float* y;
+    size_t p2_off;
+    int rows, tiles;
+    int wg0, nwg;        // workgroups [wg0, wg0 + nwg) of the grid work on this segment
+    int kb, krem;        // workgroup wl owns kb + (wl < krem) tiles (pairs of tiles in the SiLU form) from wl * kb + min(wl, krem)
+    int per[2], remw[2]; // its N items over the NW waves: wave w owns per + (w < remw) from w * per + min(w, remw); [0]: kb + 1 tiles, [1]: kb
+};
+struct RpParams {
+    RpSeg seg[3];
+    int nseg, nseg_a;    // segments [0, nseg_a) have the kernel's format A, the rest format B
+    const float* x;
+    int in, nsb;         // columns, super-blocks per row
+    const float* norm_w;
+    float eps;
+    const float* resid;
+    int silu_pair;       // seg[0] = gate, seg[1] = up (same shape, same format); their workgroups are seg[0]'s
+    int kmax;            // row-sum slots per wave (tiles a wave's item range can touch)
+};
+
+// LDS: [0, 4 in) digit planes 0..2 + a plane of zeros | sub-block-sum digits, 64 B per super-block | 2^(e-22) per super-block |
+//      32 floats scratch | 64 ints (wave item bounds, first tiles) | row sums [waves][kmax][16]
+__host__ __device__ inline size_t rp_lds_bytes(int in, int nsb, int nwaves, int kmax) {
+    return (size_t)4 * in + (size_t)68 * nsb + 128 + 256 + (size_t)nwaves * kmax * 64 + 64;
+}
+
+__device__ __forceinline__ int dpp_add_i(int v, int src) { return v + src; }
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+
+// one super-block of x (the wave's 256 columns, 4 per lane) -> digit planes, sub-block-sum digits, 2^(e-22)
+template <int NSUB>
+__device__ __forceinline__ void rp_convert_quad(uint8_t* smem, const int in, const int nsb, const int sb, const int lane, const float v0, const float v1,
+                                                const float v2, const float v3) {
+    float am = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+    am = wave_max(am);
+    int e = am > 0.0f ? __builtin_amdgcn_frexp_expf(am) : 0;   // am = m 2^e, 0.5 <= m < 1
+    e = max(e, -100);                                            // (keeps 2^(22-e) finite for vanishing activations)
+    const float up = __builtin_ldexpf(1.0f, 22 - e), inv = __builtin_ldexpf(1.0f, e - 22);
+    // rint through the magic constant 1.5 * 2^23: the low mantissa bits ARE the two's-complement integer, |X| <= 2^22
+    const int x0 = (int)(__float_as_uint(fmaf(v0, up, 12582912.0f)) - 0x4B400000u), x1 = (int)(__float_as_uint(fmaf(v1, up, 12582912.0f)) - 0x4B400000u),
+              x2 = (int)(__float_as_uint(fmaf(v2, up, 12582912.0f)) - 0x4B400000u), x3 = (int)(__float_as_uint(fmaf(v3, up, 12582912.0f)) - 0x4B400000u);
+    // signed base-256 digits: X + 0x808080 has the digits d_p + 128 as its (unsigned) bytes; xor 0x80 makes them the int8 d_p
+    const uint32_t y0 = ((uint32_t)x0 + 0x808080u) ^ 0x808080u, y1 = ((uint32_t)x1 + 0x808080u) ^ 0x808080u,
+                   y2 = ((uint32_t)x2 + 0x808080u) ^ 0x808080u, y3 = ((uint32_t)x3 + 0x808080u) ^ 0x808080u;
+    // 4 x 3 byte transpose: plane p of the four columns
+    const uint32_t ta = __builtin_amdgcn_perm(y1, y0, 0x05010400u);    // y0.b0 y1.b0 y0.b1 y1.b1
+    const uint32_t tb = __builtin_amdgcn_perm(y1, y0, 0x07030602u);    // y0.b2 y1.b2 y0.b3 y1.b3
+    const uint32_t tc = __builtin_amdgcn_perm(y3, y2, 0x05010400u);
+    const uint32_t td = __builtin_amdgcn_perm(y3, y2, 0x07030602u);
+    const uint32_t p0 = __builtin_amdgcn_perm(tc, ta, 0x05040100u);    // digit 0 of columns 0..3
+    const uint32_t p1 = __builtin_amdgcn_perm(tc, ta, 0x07060302u);    // digit 1
+    const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u);    // digit 2
+    const int col = 256 * sb + 4 * lane;
+    *reinterpret_cast<uint32_t*>(smem + col) = p0;
+    *reinterpret_cast<uint32_t*>(smem + in + col) = p1;
+    *reinterpret_cast<uint32_t*>(smem + 2 * in + col) = p2;
+    *reinterpret_cast<uint32_t*>(smem + 3 * in + col) = 0u;
+    // sums of X over the 16-column (Q6_K) / 32-column (Q4_K, Q5_K) sub-blocks: 4 / 8 consecutive lanes
+    int sm = (x0 + x1) + (x2 + x3);
+    sm += dpp_i<DPP_QUAD_1032>(sm);
+    sm += dpp_i<DPP_QUAD_2301>(sm);
+    if constexpr (NSUB == 8) sm += dpp_i<DPP_ROW_HALF_MIRROR>(sm);
+    uint32_t ys = ((uint32_t)sm + 0x80808080u) ^ 0x80808080u;   // four signed digits (|sum| <= 2^27)
+    int pos;
+    if constexpr (NSUB == 8) { pos = (lane & 4) ? 8 + (lane >> 3) : (lane >> 3); if (lane & 4) ys = 0u; }   // bytes 8..15 of an entry stay zero
+    else pos = lane >> 2;
+    if ((lane & 3) == 0) {
+        uint8_t* e0 = smem + 4 * (size_t)in + 64 * sb + pos;
+        e0[0] = (uint8_t)ys; e0[16] = (uint8_t)(ys >> 8); e0[32] = (uint8_t)(ys >> 16); e0[48] = (uint8_t)(ys >> 24);
+    }
+    if (lane == 0) reinterpret_cast<float*>(smem + 4 * (size_t)in + 64 * (size_t)nsb)[sb] = inv;
+}
+
+template <int DT> struct RpItem {
+    u4 n0, n1;      // the two step records' nibble chunks
+    u4 rec;         // the row record
+    uint32_t dd;    // d | dmin << 16  (Q6_K: d)
+    uint32_t hb0, hb1;   // Q5_K
+    u2 hh0, hh1;         // Q6_K
+};
+
+template <int DT, bool NORM>
+__device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, const int seg_hi, uint8_t* smem) {
+    using F = Rp<DT>;
+    constexpr int NSUB = F::NSUB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = (int)(blockDim.x >> 6);
+    const int in = p.in, nsb = p.nsb;
+    const int bid = (int)blockIdx.x;
+
+    // ---- x (and the norm weights) first: everything below runs under their latency ----
+    float4 xq[RP_MAXQ], wq[RP_MAXQ];
+#pragma unroll
+    for (int q = 0; q < RP_MAXQ; ++q) {
+        xq[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        wq[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int sb = wave + q * NW;
+        if (q * NW < nsb) {   // uniform
+            const int col = min(sb, nsb - 1) * 256 + 4 * lane;
+            xq[q] = *reinterpret_cast<const float4*>(p.x + col);
+            if constexpr (NORM) wq[q] = *reinterpret_cast<const float4*>(p.norm_w + col);
+        }
+    }
+
+    // ---- this workgroup's segment, tiles and items (no divisions: the host precomputed the splits) ----
+    RpSeg sg = p.seg[seg_lo];
+    for (int k = seg_lo + 1; k < seg_hi; ++k)
+        if (!p.silu_pair && bid >= p.seg[k].wg0) sg = p.seg[k];
+    const bool silu = p.silu_pair != 0;
+    const uint8_t* rp_alt = silu ? p.seg[1].rp : sg.rp;   // the up matrix (odd virtual tiles)
+    const int mult = silu ? 2 : 1;
+    const int wl = bid - sg.wg0;
+    const int big = wl < sg.krem ? 1 : 0;
+    const int u0 = wl * sg.kb + min(wl, sg.krem), u1 = u0 + sg.kb + big;   // tiles (pairs) of this workgroup
+    const int N = (u1 - u0) * mult * nsb;                                   // items
+    const int per = sg.per[1 - big], remw = sg.remw[1 - big];
+    const int ia = wave * per + min(wave, remw), ib = ia + per + (wave < remw ? 1 : 0);   // this wave's items
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int v0 = (int)((unsigned)ia / (unsigned)nsb);   // first virtual tile of the wave (the one division)
+
+    // load cursor: matrix (SiLU form: 0 gate / 1 up), item offset inside the matrix, super-block index
+    int l_mat = silu ? (v0 & 1) : 0;
+    unsigned l_off = (unsigned)(u0 + (silu ? (v0 >> 1) : v0)) * (unsigned)nsb + (unsigned)(ia - v0 * nsb);
+    int l_sb = ia - v0 * nsb;
+    auto load_item = [&](RpItem<DT>& it) {   // the item under the load cursor
+        const uint8_t* base = l_mat ? rp_alt : sg.rp;
+        const uint8_t* p1 = base + (size_t)l_off * (2 * F::S1);
+        const uint8_t* p2 = base + sg.p2_off + (size_t)l_off * F::S2;
+        it.n0 = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p1 + 16 * lane));
+        it.n1 = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p1 + F::S1 + 16 * lane));
+        if constexpr (DT == NTK_DT_Q5_K) {
+            it.hb0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p1 + 1024 + 4 * lane));
+            it.hb1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p1 + F::S1 + 1024 + 4 * lane));
+        }
+        if constexpr (DT == NTK_DT_Q6_K) {
+            it.hh0 = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p1 + 1024 + 8 * lane));
+            it.hh1 = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p1 + F::S1 + 1024 + 8 * lane));
+        }
+        it.rec = *reinterpret_cast<const u4*>(p2 + 16 * i16);
+        if constexpr (DT == NTK_DT_Q6_K) it.dd = *reinterpret_cast<const uint16_t*>(p2 + 256 + 2 * i16);
+        else it.dd = *reinterpret_cast<const uint32_t*>(p2 + 256 + 4 * i16);
+    };
+    auto load_advance = [&]() {
+        if (++l_sb < nsb) { ++l_off; return; }
+        l_sb = 0;
+        if (silu) {
+            if (l_mat == 0) { l_mat = 1; l_off -= (unsigned)(nsb - 1); } else { l_mat = 0; ++l_off; }
+        } else ++l_off;
+    };
+
+    // x has landed before the first weights are requested (a CU returns its loads in request order: gemv.hip, prologue)
+#pragma unroll
+    for (int q = 0; q < RP_MAXQ; ++q) asm volatile("" : "+v"(xq[q].x), "+v"(xq[q].y), "+v"(xq[q].z), "+v"(xq[q].w));
+    // RP_DEPTH items on their way, UNCONDITIONALLY (the s_waitcnt of the steady-state loop is exact only if its entry state is): a
+    // wave with fewer items re-reads its workgroup's last item (or the next wave's: an L2 hit either way)
+    RpItem<DT> ring[RP_DEPTH];
+#pragma unroll
+    for (int u = 0; u < RP_DEPTH; ++u) {
+        load_item(ring[u]);
+        if (ia + u + 1 < N) load_advance();
+    }
+
+    // ---- prologue: RMSNorm (reference rmsnorm.cu:16-70), digit planes ----
+    float* red = reinterpret_cast<float*>(smem + 4 * (size_t)in + 68 * (size_t)nsb);
+    int* bnd = reinterpret_cast<int*>(red + 32);   // [0, 17): first item of wave w; [32, 48): first virtual tile of wave w
+    float* part = red + 32 + 64;
+    if (lane == 0) { bnd[wave] = ia; bnd[32 + wave] = v0; if (wave == NW - 1) bnd[NW] = ib; }
+    if constexpr (NORM) {
+        float ssq = 0.0f;
+#pragma unroll
+        for (int q = 0; q < RP_MAXQ; ++q) {
+            const float m = (wave + q * NW < nsb) ? 1.0f : 0.0f;
+            ssq = fmaf(xq[q].x * m, xq[q].x, ssq); ssq = fmaf(xq[q].y * m, xq[q].y, ssq);
+            ssq = fmaf(xq[q].z * m, xq[q].z, ssq); ssq = fmaf(xq[q].w * m, xq[q].w, ssq);
+        }
+        ssq = wave_sum(ssq);
+        if (lane == 0) red[wave] = ssq;
+        __syncthreads();
+        float tot = 0.0f;
+        for (int w = 0; w < NW; ++w) tot += red[w];
+        const float rms_inv = 1.0f / sqrtf(tot / (float)in + p.eps);   // rsqrtf(mean + eps), rmsnorm.cu:60-61
+#pragma unroll
+        for (int q = 0; q < RP_MAXQ; ++q) {   // x * rms_inv * w, the reference's association (rmsnorm.cu:68)
+            xq[q].x = xq[q].x * rms_inv * wq[q].x; xq[q].y = xq[q].y * rms_inv * wq[q].y;
+            xq[q].z = xq[q].z * rms_inv * wq[q].z; xq[q].w = xq[q].w * rms_inv * wq[q].w;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RP_MAXQ; ++q) {
+        const int sb = wave + q * NW;
+        if (sb < nsb) rp_convert_quad<NSUB>(smem, in, nsb, sb, lane, xq[q].x, xq[q].y, xq[q].z, xq[q].w);   // uniform
+    }
+    __syncthreads();
+
+    // ---- lane constants of the A operands (digit planes) ----
+    const int m16 = lane & 15;            // entry m = 4 jj + p of the first MFMA operand
+    const int jjm = m16 >> 2, pp = m16 & 3;
+    const bool a_ok = pp < 3 && (NSUB == 8 ? (jjm == (kg >> 1)) : (jjm == kg));
+    const uint32_t xbase = (uint32_t)(a_ok ? pp * in : 3 * in) + 16u * (uint32_t)kg;
+    const bool c_ok = m16 < 4 && kg == 0;   // correction: entry m = digit m of the sub-block sums, k-slots of kg 0 only
+    const uint32_t cbase = c_ok ? (uint32_t)(4 * in + 16 * m16) : (uint32_t)(3 * in);
+    const float* invt = reinterpret_cast<const float*>(smem + 4 * (size_t)in + 64 * (size_t)nsb);
+    const uint32_t o0 = 8u * (uint32_t)kg, o1 = o0 + 16u;   // bit offsets of this lane's scale byte in a dword of the row record
+
+    float racc = 0.0f;
+    int slot = 0;                          // row-sum slot of the tile being accumulated
+    int p_sb = ia - v0 * nsb;              // process cursor: super-block of the next item
+    auto flush = [&]() {
+        float t = racc + __shfl_xor(racc, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        if (lane < 16) part[(wave * p.kmax + slot) * 16 + lane] = t;
+        racc = 0.0f;
+        ++slot;
+    };
+
+    const v4i z4 = {0, 0, 0, 0};
+    auto process = [&](const RpItem<DT>& it) {
+        const int sbk = p_sb;
+        const uint8_t* xa = smem + xbase + 256u * (uint32_t)sbk;
+        v4i b[4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u4 raw = s ? it.n1 : it.n0;
+            v4i& b0 = b[2 * s];
+            v4i& b1 = b[2 * s + 1];
+            if constexpr (DT == NTK_DT_Q4_K) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { b0[k] = (int)(raw[k] & 0x0F0F0F0Fu); b1[k] = (int)((raw[k] >> 4) & 0x0F0F0F0Fu); }
+            } else if constexpr (DT == NTK_DT_Q5_K) {
+                const uint32_t hb = s ? it.hb1 : it.hb0;   // byte y, bit 4 h + v
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    b0[k] = (int)(((hb << (4 - k)) & 0x10101010u) | (raw[k] & 0x0F0F0F0Fu));
+                    b1[k] = (int)(((hb >> k) & 0x10101010u) | ((raw[k] >> 4) & 0x0F0F0F0Fu));
+                }
+            } else {
+                const u2 hh = s ? it.hh1 : it.hh0;         // byte y, bits 2 v .. 2 v + 1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t h0 = k < 2 ? (hh[0] << (4 - 2 * k)) : (hh[0] >> (2 * k - 4));
+                    const uint32_t h1 = k < 2 ? (hh[1] << (4 - 2 * k)) : (hh[1] >> (2 * k - 4));
+                    b0[k] = (int)((h0 & 0x30303030u) | (raw[k] & 0x0F0F0F0Fu));
+                    b1[k] = (int)((h1 & 0x30303030u) | ((raw[k] >> 4) & 0x0F0F0F0Fu));
+                }
+            }
+        }
+        // minimum (Q4_K / Q5_K: dmin sum_j m_j sum x) / offset (Q6_K: 32 d sum_j sc_j sum x) term: the row's bytes x the digits of the sums
+        v4i bc;
+        if constexpr (NSUB == 8) bc = v4i{kg == 0 ? (int)it.rec[2] : 0, kg == 0 ? (int)it.rec[3] : 0, 0, 0};
+        else bc = v4i{kg == 0 ? (int)it.rec[0] : 0, kg == 0 ? (int)it.rec[1] : 0, kg == 0 ? (int)it.rec[2] : 0, kg == 0 ? (int)it.rec[3] : 0};
+        const v4i a0 = *reinterpret_cast<const v4i*>(xa), a1 = *reinterpret_cast<const v4i*>(xa + 64);
+        const v4i a2 = *reinterpret_cast<const v4i*>(xa + 128), a3 = *reinterpret_cast<const v4i*>(xa + 192);
+        const v4i ac = *reinterpret_cast<const v4i*>(smem + cbase + 64u * (uint32_t)sbk);
+        const float inv = invt[sbk];
+        // the five matrix instructions back to back; their results are consumed below, after the last has been issued
+        const v4i c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b[0], z4, 0, 0, 0);
+        const v4i c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b[1], z4, 0, 0, 0);
+        const v4i c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b[2], z4, 0, 0, 0);
+        const v4i c3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b[3], z4, 0, 0, 0);
+        const v4i cc = __builtin_amdgcn_mfma_i32_16x16x64_i8(ac, bc, z4, 0, 0, 0);
+        int s0, s1, s2, s3;   // the scale of (row, sub-block of this lane) in each of the four MFMAs
+        if constexpr (NSUB == 8) {   // sub-block 4 s + 2 h + mg: byte 2 h + mg of dword s of the record
+            s0 = (int)__builtin_amdgcn_ubfe(it.rec[0], o0, 8u); s1 = (int)__builtin_amdgcn_ubfe(it.rec[0], o1, 8u);
+            s2 = (int)__builtin_amdgcn_ubfe(it.rec[1], o0, 8u); s3 = (int)__builtin_amdgcn_ubfe(it.rec[1], o1, 8u);
+        } else {                     // sub-block 8 s + 4 h + mg: byte mg of dword 2 s + h
+            s0 = __builtin_amdgcn_sbfe((int)it.rec[0], o0, 8u); s1 = __builtin_amdgcn_sbfe((int)it.rec[1], o0, 8u);
+            s2 = __builtin_amdgcn_sbfe((int)it.rec[2], o0, 8u); s3 = __builtin_amdgcn_sbfe((int)it.rec[3], o0, 8u);
+        }
+        const int i0 = __mul24(c0[0], s0) + __mul24(c1[0], s1) + __mul24(c2[0], s2) + __mul24(c3[0], s3);
+        const int i1 = __mul24(c0[1], s0) + __mul24(c1[1], s1) + __mul24(c2[1], s2) + __mul24(c3[1], s3);
+        const int i2 = __mul24(c0[2], s0) + __mul24(c1[2], s1) + __mul24(c2[2], s2) + __mul24(c3[2], s3);
+        const float d = h2f((uint16_t)(it.dd & 0xFFFFu));
+        const float S = fmaf(fmaf((float)i2, 256.0f, (float)i1), 256.0f, (float)i0);
+        racc = fmaf(S, d * inv, racc);
+        const float corr = fmaf(fmaf(fmaf((float)cc[3], 256.0f, (float)cc[2]), 256.0f, (float)cc[1]), 256.0f, (float)cc[0]);
+        float fneg;
+        if constexpr (NSUB == 8) fneg = -h2f((uint16_t)(it.dd >> 16)) * inv; else fneg = -32.0f * d * inv;
+        racc = fmaf(corr, fneg, racc);
+        if (++p_sb == nsb) { p_sb = 0; flush(); }   // the wave's share of this tile is complete (uniform)
+    };
+
+    // ---- the wave's items: RP_DEPTH in flight; the steady-state loop issues unconditionally (exact s_waitcnt), the tail does not ----
+    int g = ia;
+    while (g + 2 * RP_DEPTH <= ib) {
+#pragma unroll
+        for (int u = 0; u < RP_DEPTH; ++u) { process(ring[u]); load_item(ring[u]); load_advance(); }
+        g += RP_DEPTH;
+    }
+#pragma unroll
+    for (int u = 0; u < RP_DEPTH; ++u)
+        if (g + u < ib) { process(ring[u]); if (g + u + RP_DEPTH < ib) { load_item(ring[u]); load_advance(); } }
+    g += RP_DEPTH;
+#pragma unroll
+    for (int u = 0; u < RP_DEPTH; ++u)
+        if (g + u < ib) process(ring[u]);
+    if (ib > ia && p_sb != 0) flush();
+    __syncthreads();
+
+    // ---- row sums of the workgroup's tiles: the waves' pieces in wave order, epilogue, store ----
+    const int ntl = (u1 - u0) * mult;   // virtual tiles
+    auto tile_sum = [&](const int tl, const int r) {
+        float t = 0.0f;
+        const int lo = tl * nsb, hi = lo + nsb;
+        for (int w = 0; w < NW; ++w) {
+            const int aw = bnd[w], bw = bnd[w + 1];
+            if (bw > aw && aw < hi && bw > lo) t += part[(w * p.kmax + (tl - bnd[32 + w])) * 16 + r];
+        }
+        return t;
+    };
+    if (silu) {
+        for (int e = tid; e < (u1 - u0) * 16; e += (int)blockDim.x) {
+            const int pl = e >> 4, r = e & 15, row = (u0 + pl) * 16 + r;
+            if (row < sg.rows) {
+                const float gv = tile_sum(2 * pl, r), uv = tile_sum(2 * pl + 1, r);
+                sg.y[row] = gv / (1.0f + expf(-gv)) * uv;   // reference gemm.cu:719-724
+            }
+        }
+    } else {
+        const bool res = p.resid != nullptr && sg.wg0 == p.seg[0].wg0;   // the residual belongs to segment 0
+        for (int e = tid; e < ntl * 16; e += (int)blockDim.x) {
+            const int tl = e >> 4, r = e & 15, row = (u0 + tl) * 16 + r;
+            if (row < sg.rows) {
+                float v = tile_sum(tl, r);
+                if (res) v = p.resid[row] + v;   // reference elementwise.cu:23-32
+                sg.y[row] = v;
+            }
+        }
+    }
+}
+
+template <int DTA, int DTB, bool NORM>
+__global__ __launch_bounds__(1024) void rp_gemv_kernel(const RpParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rp_smem[];
+    if constexpr (DTA == DTB) {
+        rp_body<DTA, NORM>(p, 0, p.nseg, rp_smem);
+    } else {
+        if ((int)blockIdx.x < p.seg[p.nseg_a].wg0) rp_body<DTA, NORM>(p, 0, p.nseg_a, rp_smem);
+        else rp_body<DTB, NORM>(p, p.nseg_a, p.nseg, rp_smem);
+    }
+}
+
+// prologue only: the LDS image of x (4 in + 68 nsb bytes) to global memory.  Parity instrumentation.
+template <int NSUB, bool NORM>
+__global__ __launch_bounds__(1024) void rp_prologue_dump_kernel(uint8_t* out, const float* x, const float* norm_w, float eps, int in, int nsb) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rp_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    float* red = reinterpret_cast<float*>(rp_smem + 4 * (size_t)in + 68 * (size_t)nsb);
+    float rms_inv = 1.0f;
+    if (NORM) {
+        float ssq = 0.0f;
+        for (int c = tid; c < in; c += blockDim.x) ssq = fmaf(x[c], x[c], ssq);
+        ssq = wave_sum(ssq);
+        if (lane == 0) red[wave] = ssq;
+        __syncthreads();
+        float tot = 0.0f;
+        for (int w = 0; w < NW; ++w) tot += red[w];
+        rms_inv = 1.0f / sqrtf(tot / (float)in + eps);
+    }
+    for (int sb = wave; sb < nsb; sb += NW) {
+        float4 v = *reinterpret_cast<const float4*>(x + 256 * sb + 4 * lane);
+        if (NORM) {
+            const float4 w = *reinterpret_cast<const float4*>(norm_w + 256 * sb + 4 * lane);
+            v.x = v.x * rms_inv * w.x; v.y = v.y * rms_inv * w.y; v.z = v.z * rms_inv * w.z; v.w = v.w * rms_inv * w.w;
+        }
+        rp_convert_quad<NSUB>(rp_smem, in, nsb, sb, lane, v.x, v.y, v.z, v.w);
+    }
+    __syncthreads();
+    const size_t n = 4 * (size_t)in + 68 * (size_t)nsb;
+    for (size_t k = tid; k < n; k += blockDim.x) out[k] = rp_smem[k];
+}
+
+// D = A . B on v_mfma_i32_16x16x64_i8 with the operand / accumulator lane maps the GEMV assumes (A [16][64], B [64][16] -> D [16][16]):
+// first operand lane (i = lane & 15, kg = lane >> 4) = A[i][16 kg .. 16 kg + 15], second = B[16 kg ..][j = lane & 15], result lane
+// (j = lane & 15, mg = lane >> 4) register r = D[4 mg + r][j].  Parity instrumentation (a wrong map fails this before anything else).
+__global__ __launch_bounds__(64) void rp_mfma_probe_kernel(int* D, const int8_t* A, const int8_t* B) {
+    const int lane = threadIdx.x, i = lane & 15, kg = lane >> 4;
+    v4i a, b;
+    int8_t ta[16], tb[16];
+    for (int k = 0; k < 16; ++k) { ta[k] = A[i * 64 + 16 * kg + k]; tb[k] = B[(16 * kg + k) * 16 + i]; }
+    __builtin_memcpy(&a, ta, 16);
+    __builtin_memcpy(&b, tb, 16);
+    const v4i z = {0, 0, 0, 0};
+    const v4i c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, z, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[(4 * kg + r) * 16 + i] = c[r];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+struct RpPlan { int nw, grid, kmax; size_t lds; int nwg[3]; };
+
+// Geometry of one launch.  A workgroup owns whole tiles (pairs of tiles for the SiLU form) of ONE segment; its waves split the
+// workgroup's items (tile x super-block) evenly and meet in LDS.  Chosen: waves per workgroup and workgroups per segment so that (i)
+// every workgroup is resident at once (16 waves and 160 KB of LDS per CU), (ii) items per wave are as even as possible.
+static bool rp_plan(const int* tiles, const int* dts, int nseg, int nsb, int in, int silu_pair, int force_nw, RpPlan& best) {
+    static const int kNW[] = {16, 14, 12, 10, 8, 7, 6, 5, 4};
+    double best_score = -1.0;
+    const int mult = silu_pair ? 2 : 1;
+    const int nsegw = silu_pair ? 1 : nseg;   // segments that own workgroups
+    for (int nw : kNW) {
+        if (force_nw > 0 && nw != force_nw) continue;
+        if ((nsb + nw - 1) / nw > RP_MAXQ) continue;
+        // workgroups per CU: waves, then LDS (kmax is not known yet: bound it by 4 slots here, checked below)
+        const size_t lds0 = rp_lds_bytes(in, nsb, nw, 4);
+        int per_cu = std::min(16 / nw, (int)((size_t)(160 * 1024) / lds0));
+        if (per_cu < 1) continue;
+        const int gmax = 256 * per_cu;
+        double wsum = 0.0;
+        for (int i = 0; i < nsegw; ++i) wsum += (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+        int nwg[3] = {0, 0, 0}, grid = 0, max_items = 0;
+        double work = 0.0, cap = 0.0;
+        for (int i = 0; i < nsegw; ++i) {
+            const double wi = (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+            int gi = std::max(1, (int)(gmax * wi / wsum));
+            gi = std::min(gi, tiles[i]);
+            const int k = (tiles[i] + gi - 1) / gi;           // tiles (pairs) per workgroup, at most
+            gi = (tiles[i] + k - 1) / k;
+            nwg[i] = gi;
+            grid += gi;
+            const int n_items = k * mult * nsb;
+            const int per_wave = (n_items + nw - 1) / nw;
+            max_items = std::max(max_items, per_wave);
+            const double bytes = (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+            work += (double)tiles[i] * mult * nsb * bytes;
+            cap += (double)gi * nw * per_wave * bytes;
+        }
+        if (grid > gmax) continue;
+        const double eff = work / cap;
+        const double waves = (double)grid * nw;
+        const double score = eff * (0.7 + 0.3 * std::min(1.0, waves / 4096.0)) + 1e-4 * nw;
+        const int kmax = (max_items - 1) / nsb + 2;
+        const size_t lds = rp_lds_bytes(in, nsb, nw, kmax);
+        if (lds > 160 * 1024 || (size_t)per_cu * lds > 160 * 1024) continue;
+        if (score > best_score) {
+            best_score = score;
+            best.nw = nw; best.grid = grid; best.kmax = kmax; best.lds = lds;
+            for (int i = 0; i < 3; ++i) best.nwg[i] = nwg[i];
+        }
+    }
+    return best_score > 0.0;
+}
+
+static int g_rp_force_nw = 0;   // tuning builds: ntk_tune_rp_waves()
+
+using RpFn = void (*)(const RpParams);
+template <int DTA, int DTB> static RpFn rp_fn(bool norm) {
+    static const RpFn t[2] = {rp_gemv_kernel<DTA, DTB, false>, rp_gemv_kernel<DTA, DTB, true>};
+    static const bool ok = hipFuncSetAttribute((const void*)t[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                           hipFuncSetAttribute((const void*)t[1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    return ok ? t[norm ? 1 : 0] : nullptr;
+}
+
+}  // namespace ntk
+
+extern "C" {
+
+size_t ntk_rp_bytes(int dtype, int rows, int in_features) {
+    if (!ntk::rp_supported(dtype) || rows <= 0 || in_features <= 0 || in_features % 256 != 0) return 0;
+    const size_t tiles = ((size_t)rows + 15) / 16, nsb = (size_t)in_features / 256;
+    return tiles * nsb * (2 * ntk::rp_s1(dtype) + ntk::rp_s2(dtype));
+}
+
+int ntk_rp_pack(void* dst, const void* raw, int rows, int in_features, int dtype, void* stream) {
+    if (!dst || !raw) return NTK_E_NULL;
+    if (!ntk::rp_supported(dtype)) return NTK_E_DTYPE;
+    if (rows <= 0 || in_features <= 0 || in_features % 256 != 0) return NTK_E_SHAPE;
+    if (reinterpret_cast<uintptr_t>(dst) & 15) return NTK_E_ALIGN;
+    const int tiles = (rows + 15) / 16, nsb = in_features / 256;
+    if ((long)tiles * nsb > 0x7FFFFFFFl) return NTK_E_SHAPE;
+    const size_t p2 = (size_t)tiles * nsb * 2 * ntk::rp_s1(dtype);
+    hipStream_t st = ntk::resolve_stream(stream);
+    const dim3 g((unsigned)(tiles * nsb)), b(128);
+    uint8_t* d = static_cast<uint8_t*>(dst);
+    const uint8_t* r = static_cast<const uint8_t*>(raw);
+    if (dtype == NTK_DT_Q4_K) hipLaunchKernelGGL(ntk::rp_pack_kernel<NTK_DT_Q4_K>, g, b, 0, st, d, r, rows, nsb, p2);
+    else if (dtype == NTK_DT_Q5_K) hipLaunchKernelGGL(ntk::rp_pack_kernel<NTK_DT_Q5_K>, g, b, 0, st, d, r, rows, nsb, p2);
+    else hipLaunchKernelGGL(ntk::rp_pack_kernel<NTK_DT_Q6_K>, g, b, 0, st, d, r, rows, nsb, p2);
+    return ntk::last_launch_status();
+}
+
+int ntk_rp_dequant(float* out, const void* rp, int rows, int in_features, int dtype, void* stream) {
+    if (!out || !rp) return NTK_E_NULL;
+    if (!ntk::rp_supported(dtype)) return NTK_E_DTYPE;
+    if (rows <= 0 || in_features <= 0 || in_features % 256 != 0) return NTK_E_SHAPE;
+    const int tiles = (rows + 15) / 16, nsb = in_features / 256;
+    const size_t p2 = (size_t)tiles * nsb * 2 * ntk::rp_s1(dtype);
+    hipStream_t st = ntk::resolve_stream(stream);
+    const dim3 g((unsigned)rows), b(256);
+    const uint8_t* r = static_cast<const uint8_t*>(rp);
+    if (dtype == NTK_DT_Q4_K) hipLaunchKernelGGL(ntk::rp_dequant_kernel<NTK_DT_Q4_K>, g, b, 0, st, out, r, rows, in_features, nsb, p2);
+    else if (dtype == NTK_DT_Q5_K) hipLaunchKernelGGL(ntk::rp_dequant_kernel<NTK_DT_Q5_K>, g, b, 0, st, out, r, rows, in_features, nsb, p2);
+    else hipLaunchKernelGGL(ntk::rp_dequant_kernel<NTK_DT_Q6_K>, g, b, 0, st, out, r, rows, in_features, nsb, p2);
+    return ntk::last_launch_status();
+}
+
+int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                      const float* resid, int silu_pair, void* stream) {
+    using namespace ntk;
+    if (!segs || !x) return NTK_E_NULL;
+    if (nseg < 1 || nseg > 3) return NTK_E_SHAPE;
+    if (in_features <= 0 || in_features % 256 != 0 || in_features > 32768) return NTK_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (norm_w && (reinterpret_cast<uintptr_t>(norm_w) & 15))) return NTK_E_ALIGN;
+    if (silu_pair && (nseg != 2 || segs[0].rows != segs[1].rows || segs[0].dtype != segs[1].dtype || resid)) return NTK_E_SHAPE;
+    // order: format A first (the first segment's), then the rest (one other format at most)
+    ntk_gemv_seg ord[3];
+    int na = 0, nb = 0, dtb = -1;
+    for (int i = 0; i < nseg; ++i) {
+        if (!rp_supported(segs[i].dtype)) return NTK_E_DTYPE;
+        if (segs[i].rows <= 0) return NTK_E_SHAPE;
+        if (!segs[i].W || !segs[i].y) return NTK_E_NULL;
+        if (reinterpret_cast<uintptr_t>(segs[i].W) & 15) return NTK_E_ALIGN;
+    }
+    for (int i = 0; i < nseg; ++i) if (segs[i].dtype == segs[0].dtype) ord[na++] = segs[i];
+    for (int i = 0; i < nseg; ++i) if (segs[i].dtype != segs[0].dtype) {
+        if (dtb < 0) dtb = segs[i].dtype; else if (segs[i].dtype != dtb) return NTK_E_DTYPE;
+        ord[na + nb++] = segs[i];
+    }
+    if (resid && ord[0].W != segs[0].W) return NTK_E_SHAPE;   // (the residual belongs to segment 0, which is of format A by construction)
+    const int dta = segs[0].dtype;
+    if (dtb < 0) dtb = dta;
+    RpParams p;
+    memset(&p, 0, sizeof p);
+    const int nsb = in_features / 256;
+    int tiles[3] = {0, 0, 0}, dts[3] = {0, 0, 0};
+    for (int i = 0; i < nseg; ++i) { tiles[i] = (ord[i].rows + 15) / 16; dts[i] = ord[i].dtype; }
+    RpPlan plan;
+    if (!rp_plan(tiles, dts, nseg, nsb, in_features, silu_pair, g_rp_force_nw, plan)) return NTK_E_SHAPE;
+    int wg = 0;
+    const int mult = silu_pair ? 2 : 1;
+    for (int i = 0; i < nseg; ++i) {
+        RpSeg& s = p.seg[i];
+        s.rp = static_cast<const uint8_t*>(ord[i].W);
+        s.y = ord[i].y;
+        s.rows = ord[i].rows;
+        s.tiles = tiles[i];
+        s.p2_off = (size_t)tiles[i] * nsb * 2 * rp_s1(dts[i]);
+        if (s.p2_off + (size_t)tiles[i] * nsb * rp_s2(dts[i]) > 0xFFFFFFF0ull) return NTK_E_SHAPE;   // (32-bit item offsets)
+        if (silu_pair && i == 1) { const RpSeg& g0 = p.seg[0]; s.wg0 = g0.wg0; s.nwg = g0.nwg; s.kb = g0.kb; s.krem = g0.krem;
+                                   for (int c = 0; c < 2; ++c) { s.per[c] = g0.per[c]; s.remw[c] = g0.remw[c]; } continue; }
+        s.wg0 = wg; s.nwg = plan.nwg[i];
+        s.kb = tiles[i] / s.nwg; s.krem = tiles[i] % s.nwg;
+        for (int c = 0; c < 2; ++c) {   // [0]: workgroups with kb + 1 tiles, [1]: with kb
+            const int n_items = (s.kb + 1 - c) * mult * nsb;
+            s.per[c] = n_items / plan.nw; s.remw[c] = n_items % plan.nw;
+        }
+        wg += plan.nwg[i];
+    }
+    p.nseg = nseg; p.nseg_a = na;
+    p.x = x; p.in = in_features; p.nsb = nsb;
+    p.norm_w = norm_w; p.eps = eps; p.resid = resid; p.silu_pair = silu_pair; p.kmax = plan.kmax;
+    RpFn fn = nullptr;
+    const bool nm = norm_w != nullptr;
+    if (dta == dtb) {
+        fn = dta == NTK_DT_Q4_K ? rp_fn<NTK_DT_Q4_K, NTK_DT_Q4_K>(nm) : dta == NTK_DT_Q5_K ? rp_fn<NTK_DT_Q5_K, NTK_DT_Q5_K>(nm) : rp_fn<NTK_DT_Q6_K, NTK_DT_Q6_K>(nm);
+    } else if (dta == NTK_DT_Q4_K && dtb == NTK_DT_Q6_K) fn = rp_fn<NTK_DT_Q4_K, NTK_DT_Q6_K>(nm);
+    else if (dta == NTK_DT_Q4_K && dtb == NTK_DT_Q5_K) fn = rp_fn<NTK_DT_Q4_K, NTK_DT_Q5_K>(nm);
+    else if (dta == NTK_DT_Q6_K && dtb == NTK_DT_Q4_K) fn = rp_fn<NTK_DT_Q6_K, NTK_DT_Q4_K>(nm);
+    else if (dta == NTK_DT_Q5_K && dtb == NTK_DT_Q4_K) fn = rp_fn<NTK_DT_Q5_K, NTK_DT_Q4_K>(nm);
+    else return NTK_E_DTYPE;
+    if (!fn) return NTK_E_LAUNCH;
+    hipLaunchKernelGGL(fn, dim3((unsigned)plan.grid), dim3((unsigned)(64 * plan.nw)), plan.lds, resolve_stream(stream), p);
+    return last_launch_status();
+}
+
+int ntk_gemv_rp(float* y, const void* rp, const float* x, int out_features, int in_features, int weight_dtype, void* stream) {
+    ntk_gemv_seg seg{rp, y, out_features, weight_dtype};
+    return ntk_gemv_rp_fused(&seg, 1, x, in_features, nullptr, 0.0f, nullptr, 0, stream);
+}
+
+#ifdef NTK_TUNE
+void ntk_tune_rp_waves(int nw) { ntk::g_rp_force_nw = nw; }   // tuning builds (make tune): waves per workgroup of every rp launch, 0 = the planner's choice
+#endif
+
+int ntk_debug_rp_prologue(uint8_t* out, const float* x, const float* norm_w, float eps, int in_features, int nsub, int nwaves, void* stream) {
+    if (!out || !x) return NTK_E_NULL;
+    if (in_features <= 0 || in_features % 256 != 0 || (nsub != 8 && nsub != 16) || nwaves < 1 || nwaves > 16) return NTK_E_SHAPE;
+    const int nsb = in_features / 256;
+    const size_t lds = ntk::rp_lds_bytes(in_features, nsb, nwaves, 1);
+    if (lds > 160 * 1024) return NTK_E_SHAPE;
+    using Fn = void (*)(uint8_t*, const float*, const float*, float, int, int);
+    Fn fn = nsub == 8 ? (norm_w ? ntk::rp_prologue_dump_kernel<8, true> : ntk::rp_prologue_dump_kernel<8, false>)
+                      : (norm_w ? ntk::rp_prologue_dump_kernel<16, true> : ntk::rp_prologue_dump_kernel<16, false>);
+    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return NTK_E_LAUNCH;
+    hipLaunchKernelGGL(fn, dim3(1), dim3((unsigned)(64 * nwaves)), lds, ntk::resolve_stream(stream), out, x, norm_w, eps, in_features, nsb);
+    return ntk::last_launch_status();
+}
+
+int ntk_debug_mfma_i8_probe(int* D, const int8_t* A, const int8_t* B, void* stream) {
+    if (!D || !A || !B) return NTK_E_NULL;
+    hipLaunchKernelGGL(ntk::rp_mfma_probe_kernel, dim3(1), dim3(64), 0, ntk::resolve_stream(stream), D, A, B);
+    return ntk::last_launch_status();
+}
+
+}  // extern "C"

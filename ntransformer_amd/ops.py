@@ -166,6 +166,30 @@ def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resi
                                     stream), "gemv_fused")
 
 
+def rp_bytes(dtype, rows, in_features) -> int:
+    return int(_lib.lib().ntk_rp_bytes(int(dtype), rows, in_features))
+
+
+def rp_pack(raw, rows, in_features, dtype, stream=None) -> "DeviceBuffer":
+    """ntk_rp_pack: the engine-owned repack of a raw GGUF K-quant matrix (device buffer in, new device buffer out)."""
+    n = rp_bytes(dtype, rows, in_features)
+    if n == 0:
+        raise _lib.NtkError(-1, "rp_pack: dtype / shape without a repacked form")
+    dst = DeviceBuffer(n + 256)
+    check(_lib.lib().ntk_rp_pack(_p(dst), _p(raw), rows, in_features, int(dtype), stream), "rp_pack")
+    synchronize(stream)   # `raw` may be released by the caller
+    return dst
+
+
+def gemv_rp_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resid=None, silu_pair=False, stream=None):
+    """ntk_gemv_rp_fused: gemv_fused over REPACKED tensors: segs = [(rp, y, rows, dtype), ...] (<= 3; one or two K-quant formats)."""
+    arr = (GemvSeg * len(segs))()
+    for i, (W, y, rows, dt) in enumerate(segs):
+        arr[i].W, arr[i].y, arr[i].rows, arr[i].dtype = _p(W), _p(y), rows, int(dt)
+    check(_lib.lib().ntk_gemv_rp_fused(arr, len(segs), _p(x), in_features, _p(norm_w), eps, _p(resid), int(silu_pair),
+                                       stream), "gemv_rp_fused")
+
+
 def gemm_quant_ws_multi(segs, X, n_tokens, in_features, stream=None):
     """ntk_gemm_quant_ws_multi: segs = [(W, Y, rows, dtype), ...] of one format sharing X, one launch (workspace allocated here)."""
     L = _lib.lib()

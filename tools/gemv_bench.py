@@ -31,11 +31,15 @@ def main():
     ap.add_argument("--shapes", default=",".join(SHAPES))
     ap.add_argument("--pool-mb", type=int, default=1536)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--rp", action="store_true", help="the matrix-core GEMV over repacked tensors (ntk_gemv_rp_fused); GB/s still counts GGUF bytes")
+    ap.add_argument("--nw", type=int, default=0, help="--rp with a tuning build (make tune, NTK_LIB_PATH): waves per workgroup, 0 = planner")
     a = ap.parse_args()
     ops.init(0)
     L = _lib.lib()
     global HIP
     HIP = C.CDLL("libamdhip64.so")
+    if a.nw:
+        L.ntk_tune_rp_waves(a.nw)
     pool_bytes = a.pool_mb << 20
     rng = np.random.default_rng(0)
     # valid-looking blocks are irrelevant for timing; small-magnitude bytes keep fp16 scales finite
@@ -52,6 +56,12 @@ def main():
             rb = G.row_bytes(gt, in_f)
             per_launch = rb * (sum(rlist) if kind != "silu" else 2 * rlist[0])
             per_launch_al = (per_launch + 4095) // 4096 * 4096
+            if a.rp:
+                if gt not in (G.GGML_Q4_K, G.GGML_Q5_K, G.GGML_Q6_K):
+                    continue
+                rpb = [ops.rp_bytes(dt, r, in_f) for r in (rlist if kind != "silu" else [rlist[0], rlist[0]])]
+                rpb = [(b + 255) // 256 * 256 for b in rpb]
+                per_launch_al = (sum(rpb) + 4095) // 4096 * 4096
             nslots = max(2, pool_bytes // per_launch_al)
             x = DB.from_numpy(rng.standard_normal(in_f).astype(np.float32))
             nw = DB.from_numpy(np.ones(in_f, np.float32))
@@ -59,6 +69,14 @@ def main():
 
             def launch(slot):
                 base = pool.ptr + slot * per_launch_al
+                if a.rp:
+                    segs, off = [], 0
+                    for i, b in enumerate(rpb):
+                        segs.append((base + off, ys[i], rlist[0] if kind == "silu" else rlist[i], dt))
+                        off += b
+                    ops.gemv_rp_fused(segs, x, in_f, norm_w=nw if kind in ("qkv", "silu") else None, eps=1e-5,
+                                      resid=ys[0] if kind == "resid" else None, silu_pair=kind == "silu")
+                    return
                 if kind == "plain":
                     ops.launch_gemv(ys[0], base, x, rlist[0], in_f, dt)
                 elif kind == "resid":
@@ -97,9 +115,9 @@ def main():
             HIP.hipGraphDestroy(graph)
             us = ms.value * 1e3 / n
             gbs = per_launch / (us * 1e-6) / 1e9
-            results.append({"dtype": dname, "shape": sname, "bytes": per_launch, "us": round(us, 2), "GBs": round(gbs, 1),
+            results.append({"dtype": dname + (".rp" if a.rp else ""), "shape": sname, "bytes": per_launch, "us": round(us, 2), "GBs": round(gbs, 1),
                             "frac_8TBs": round(gbs / 8000, 4)})
-            print("%-5s %-18s %9.2f MB %8.2f us %8.1f GB/s  %5.1f%% of 8 TB/s" % (dname, sname, per_launch / 1e6, us, gbs, gbs / 80), flush=True)
+            print("%-8s %-18s %9.2f MB %8.2f us %8.1f GB/s  %5.1f%% of 8 TB/s" % (dname + (".rp" if a.rp else ""), sname, per_launch / 1e6, us, gbs, gbs / 80), flush=True)
     if a.json:
         json.dump(results, open(a.json, "w"), indent=1)
 
