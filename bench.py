@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-fuse", action="store_true", help="the reference's 15-launch/layer sequence")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--persistent", action="store_true", help="the persistent one-launch-per-token kernel instead of fused launches")
+    ap.add_argument("--no-repack", action="store_true", help="K-quant decode GEMVs from the raw GGUF blocks (csrc/gemv.hip) instead of the engine's load-time repack (csrc/gemv_rp.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=128, help="-n of the reference CLI run that is the CPU baseline (BASELINE config 1: 128)")
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (8B Q4_K_M, 70B Q4_K_M, 70B Q6_K, 3.9K-context 8B Q8_0)")
@@ -173,6 +174,8 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     eng.set_option("graph", not args.no_graph)
     if args.persistent:
         eng.set_option("persistent", 1)
+    if args.no_repack:
+        eng.set_option("repack", 0)
     t_load = time.perf_counter()
     eng.load_synthetic(spec, args.ctx)
     t_load = time.perf_counter() - t_load

@@ -634,6 +634,16 @@ void Model::prof_mark(int cls, bool begin) {
     if (begin) prof_->push_back({cls, e, nullptr, 1, false}); else prof_->back().b = e;
 }
 
+// which launch kinds read the repacked tensors: 1 Q|K|V, 2 Wo, 4 gate|up, 8 down, 16 LM head (tuning builds: NTK_RP_MASK)
+static int rp_mask() {
+#ifdef NTK_TUNE
+    static const int m = [] { const char* e = getenv("NTK_RP_MASK"); return e ? atoi(e) : 31; }();
+    return m;
+#else
+    return 31;
+#endif
+}
+
 int Model::enqueue_token(bool greedy) {
     const int H = cfg_.hidden_size;
     void* s = stream_;
@@ -658,7 +668,7 @@ int Model::enqueue_token(bool greedy) {
             ntk_gemv_seg seg = {w.ptr, logits_, (int)w.out_f, w.dtype};
             prof_mark(0, true);
             int st = NTK_E_DTYPE;
-            if (repack_ && w.rp) {
+            if (repack_ && w.rp && (rp_mask() & 16)) {
                 ntk_gemv_seg rs = {w.rp, logits_, (int)w.out_f, w.dtype};
                 st = ntk_gemv_rp_fused(&rs, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s);
                 if (st != NTK_OK && st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) return st;
@@ -722,10 +732,10 @@ int Model::enqueue_layers(int first, int last_layer) {
     // launch (RMSNorm prologue when `norm`, residual epilogue when `resid`, n == 1); dense F16/F32 tensors take
     // the 1:1 launchers.  Scratch: residual_[0,H) = dense output before the residual add, residual_[H,2H) = norm(x).
     auto project = [&](const DevTensor* const* ws, float* const* ys, int n, const float* x, const DevTensor* norm,
-                       const float* resid) -> int {
+                       const float* resid, int kind) -> int {
         const float* nw = norm ? (const float*)norm->ptr : nullptr;
         bool done[3] = {false, false, false};
-        if (repack_) {   // every matrix has its repacked form: one launch of the matrix-core GEMV, whatever the mix of K-quant formats
+        if (repack_ && (rp_mask() & kind)) {   // every matrix has its repacked form: one launch of the matrix-core GEMV, whatever the mix of K-quant formats
             bool all = true;
             for (int a = 0; a < n; ++a) all = all && ws[a]->rp != nullptr && ws[a]->in_f == ws[0]->in_f;
             if (all) {
@@ -781,10 +791,10 @@ int Model::enqueue_layers(int first, int last_layer) {
         }
         return NTK_OK;
     };
-    auto project1 = [&](const DevTensor& w, float* y, const float* x, const DevTensor* norm, const float* resid) -> int {
+    auto project1 = [&](const DevTensor& w, float* y, const float* x, const DevTensor* norm, const float* resid, int kind) -> int {
         const DevTensor* ws[1] = {&w};
         float* ys[1] = {y};
-        return project(ws, ys, 1, x, norm, resid);
+        return project(ws, ys, 1, x, norm, resid, kind);
     };
 
     for (int i = first; i < last_layer; ++i) {
@@ -794,7 +804,7 @@ int Model::enqueue_layers(int first, int last_layer) {
         {
             const DevTensor* ws[3] = {&L.wq, &L.wk, &L.wv};
             float* ys[3] = {q_buf, k_buf, v_buf};
-            NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr));
+            NT_TRY(project(ws, ys, 3, hidden_, &L.attn_norm, nullptr, 1));
         }
 #ifdef NTK_EXPERIMENTS
         if (attn_regime_ == 0 && fuse_attention_ && attn_sync_ && is_quant(L.wo.dtype) && tp_world_ == 1) {
@@ -819,10 +829,10 @@ int Model::enqueue_layers(int first, int last_layer) {
                                               attn_regime_ == 1 ? 8 : 16, attn_scratch_, s));
         mark(1, false);
         if (tp_world_ > 1) {   // partial sum over this rank's heads -> exchange slot -> hidden += sum over ranks
-            NT_TRY(project1(L.wo, tp_slot(), attn_out, nullptr, nullptr));
+            NT_TRY(project1(L.wo, tp_slot(), attn_out, nullptr, nullptr, 2));
             NT_TRY(tp_allreduce(hidden_, H));
         } else {
-            NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_));
+            NT_TRY(project1(L.wo, hidden_, attn_out, nullptr, hidden_, 2));
         }
 #ifdef NTK_EXPERIMENTS
     ffn:
@@ -831,7 +841,7 @@ int Model::enqueue_layers(int first, int last_layer) {
             ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
             mark(0, true);
             int st = NTK_E_DTYPE;
-            if (repack_ && L.w_gate.rp && L.w_up.rp) {
+            if (repack_ && L.w_gate.rp && L.w_up.rp && (rp_mask() & 4)) {
                 ntk_gemv_seg rs[2] = {{L.w_gate.rp, gate_buf, I, L.w_gate.dtype}, {L.w_up.rp, up_buf, I, L.w_up.dtype}};
                 st = ntk_gemv_rp_fused(rs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s);
                 if (st != NTK_OK && st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) return st;
@@ -841,14 +851,14 @@ int Model::enqueue_layers(int first, int last_layer) {
         } else {
             const DevTensor* ws[2] = {&L.w_gate, &L.w_up};
             float* ys[2] = {gate_buf, up_buf};
-            NT_TRY(project(ws, ys, 2, hidden_, &L.ffn_norm, nullptr));
+            NT_TRY(project(ws, ys, 2, hidden_, &L.ffn_norm, nullptr, 4));
             NT_TRY(ntk_silu_mul(gate_buf, gate_buf, up_buf, I, s));
         }
         if (tp_world_ > 1) {
-            NT_TRY(project1(L.w_down, tp_slot(), gate_buf, nullptr, nullptr));
+            NT_TRY(project1(L.w_down, tp_slot(), gate_buf, nullptr, nullptr, 8));
             NT_TRY(tp_allreduce(hidden_, H));
         } else {
-            NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_));
+            NT_TRY(project1(L.w_down, hidden_, gate_buf, nullptr, hidden_, 8));
         }
     }
     return NTK_OK;

@@ -171,7 +171,6 @@ struct RpSeg {
     int rows, tiles;
     int wg0, nwg;        // workgroups [wg0, wg0 + nwg) of the grid work on this segment
     int kb, krem;        // workgroup wl owns kb + (wl < krem) tiles (pairs of tiles in the SiLU form) from wl * kb + min(wl, krem)
-    int per[2], remw[2]; // its N items over the NW waves: wave w owns per + (w < remw) from w * per + min(w, remw); [0]: kb + 1 tiles, [1]: kb
 };
 struct RpParams {
     RpSeg seg[3];
@@ -182,13 +181,12 @@ struct RpParams {
     float eps;
     const float* resid;
     int silu_pair;       // seg[0] = gate, seg[1] = up (same shape, same format); their workgroups are seg[0]'s
-    int kmax;            // row-sum slots per wave (tiles a wave's item range can touch)
 };
 
 // LDS: [0, 4 in) digit planes 0..2 + a plane of zeros | sub-block-sum digits, 64 B per super-block | 2^(e-22) per super-block |
-//      32 floats scratch | 64 ints (wave item bounds, first tiles) | row sums [waves][kmax][16]
-__host__ __device__ inline size_t rp_lds_bytes(int in, int nsb, int nwaves, int kmax) {
-    return (size_t)4 * in + (size_t)68 * nsb + 128 + 256 + (size_t)nwaves * kmax * 64 + 64;
+//      32 floats scratch | row sums [tiles of the workgroup][waves][64 lanes]
+__host__ __device__ inline size_t rp_lds_bytes(int in, int nsb, int nwaves, int ntl) {
+    return (size_t)4 * in + (size_t)68 * nsb + 128 + (size_t)ntl * nwaves * 256 + 64;
 }
 
 __device__ __forceinline__ int dpp_add_i(int v, int src) { return v + src; }
@@ -270,7 +268,10 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
         }
     }
 
-    // ---- this workgroup's segment, tiles and items (no divisions: the host precomputed the splits) ----
+    // ---- this workgroup's segment and tiles; the workgroup's items (tile x super-block, in memory order) go round the waves: at any
+    //      moment the waves of a workgroup read ONE contiguous run of items (a wave that owned a contiguous range of its own would put
+    //      every wave of the chip on the same offset of a power-of-two stride: measured, the 2 KiB-item Q4_K ran at 69 % of HBM where
+    //      the 3 KiB-item Q6_K reached 81 %) ----
     RpSeg sg = p.seg[seg_lo];
     for (int k = seg_lo + 1; k < seg_hi; ++k)
         if (!p.silu_pair && bid >= p.seg[k].wg0) sg = p.seg[k];
@@ -278,22 +279,21 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     const uint8_t* rp_alt = silu ? p.seg[1].rp : sg.rp;   // the up matrix (odd virtual tiles)
     const int mult = silu ? 2 : 1;
     const int wl = bid - sg.wg0;
-    const int big = wl < sg.krem ? 1 : 0;
-    const int u0 = wl * sg.kb + min(wl, sg.krem), u1 = u0 + sg.kb + big;   // tiles (pairs) of this workgroup
-    const int N = (u1 - u0) * mult * nsb;                                   // items
-    const int per = sg.per[1 - big], remw = sg.remw[1 - big];
-    const int ia = wave * per + min(wave, remw), ib = ia + per + (wave < remw ? 1 : 0);   // this wave's items
+    const int u0 = wl * sg.kb + min(wl, sg.krem), u1 = u0 + sg.kb + (wl < sg.krem ? 1 : 0);   // tiles (pairs) of this workgroup
+    const int ntl = (u1 - u0) * mult;                 // virtual tiles (SiLU form: gate tile, up tile, gate tile ...)
+    const int N = ntl * nsb;                          // items; wave w owns items w, w + NW, w + 2 NW ...
     const int i16 = lane & 15, kg = lane >> 4;
-    const int v0 = (int)((unsigned)ia / (unsigned)nsb);   // first virtual tile of the wave (the one division)
 
-    // load cursor: matrix (SiLU form: 0 gate / 1 up), item offset inside the matrix, super-block index
-    int l_mat = silu ? (v0 & 1) : 0;
-    unsigned l_off = (unsigned)(u0 + (silu ? (v0 >> 1) : v0)) * (unsigned)nsb + (unsigned)(ia - v0 * nsb);
-    int l_sb = ia - v0 * nsb;
-    auto load_item = [&](RpItem<DT>& it) {   // the item under the load cursor
-        const uint8_t* base = l_mat ? rp_alt : sg.rp;
-        const uint8_t* p1 = base + (size_t)l_off * (2 * F::S1);
-        const uint8_t* p2 = base + sg.p2_off + (size_t)l_off * F::S2;
+    // load cursor: item index and its virtual tile
+    int l_idx = wave, l_v = 0;
+    auto load_item = [&](RpItem<DT>& it) {   // the item under the load cursor (beyond the end: the workgroup's last item again -- an L2 hit)
+        while (l_idx >= (l_v + 1) * nsb && l_v + 1 < ntl) ++l_v;   // uniform, at most a few steps
+        const int li = min(l_idx, N - 1);
+        const int tile = u0 + (silu ? (l_v >> 1) : l_v);
+        const uint8_t* base = (silu && (l_v & 1)) ? rp_alt : sg.rp;
+        const unsigned off = (unsigned)tile * (unsigned)nsb + (unsigned)(li - l_v * nsb);
+        const uint8_t* p1 = base + (size_t)off * (2 * F::S1);
+        const uint8_t* p2 = base + sg.p2_off + (size_t)off * F::S2;
         it.n0 = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p1 + 16 * lane));
         it.n1 = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p1 + F::S1 + 16 * lane));
         if constexpr (DT == NTK_DT_Q5_K) {
@@ -304,35 +304,24 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
             it.hh0 = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p1 + 1024 + 8 * lane));
             it.hh1 = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p1 + F::S1 + 1024 + 8 * lane));
         }
-        it.rec = *reinterpret_cast<const u4*>(p2 + 16 * i16);
-        if constexpr (DT == NTK_DT_Q6_K) it.dd = *reinterpret_cast<const uint16_t*>(p2 + 256 + 2 * i16);
-        else it.dd = *reinterpret_cast<const uint32_t*>(p2 + 256 + 4 * i16);
-    };
-    auto load_advance = [&]() {
-        if (++l_sb < nsb) { ++l_off; return; }
-        l_sb = 0;
-        if (silu) {
-            if (l_mat == 0) { l_mat = 1; l_off -= (unsigned)(nsb - 1); } else { l_mat = 0; ++l_off; }
-        } else ++l_off;
+        // (non-temporal like the rest of the weight stream: 12 % of the bytes must not push the KV cache and the activations out of L2)
+        it.rec = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p2 + 16 * i16));
+        if constexpr (DT == NTK_DT_Q6_K) it.dd = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p2 + 256 + 2 * i16));
+        else it.dd = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p2 + 256 + 4 * i16));
+        l_idx += NW;
     };
 
     // x has landed before the first weights are requested (a CU returns its loads in request order: gemv.hip, prologue)
 #pragma unroll
     for (int q = 0; q < RP_MAXQ; ++q) asm volatile("" : "+v"(xq[q].x), "+v"(xq[q].y), "+v"(xq[q].z), "+v"(xq[q].w));
-    // RP_DEPTH items on their way, UNCONDITIONALLY (the s_waitcnt of the steady-state loop is exact only if its entry state is): a
-    // wave with fewer items re-reads its workgroup's last item (or the next wave's: an L2 hit either way)
+    // RP_DEPTH items on their way, UNCONDITIONALLY (the s_waitcnt of the steady-state loop is exact only if its entry state is)
     RpItem<DT> ring[RP_DEPTH];
 #pragma unroll
-    for (int u = 0; u < RP_DEPTH; ++u) {
-        load_item(ring[u]);
-        if (ia + u + 1 < N) load_advance();
-    }
+    for (int u = 0; u < RP_DEPTH; ++u) load_item(ring[u]);
 
     // ---- prologue: RMSNorm (reference rmsnorm.cu:16-70), digit planes ----
     float* red = reinterpret_cast<float*>(smem + 4 * (size_t)in + 68 * (size_t)nsb);
-    int* bnd = reinterpret_cast<int*>(red + 32);   // [0, 17): first item of wave w; [32, 48): first virtual tile of wave w
-    float* part = red + 32 + 64;
-    if (lane == 0) { bnd[wave] = ia; bnd[32 + wave] = v0; if (wave == NW - 1) bnd[NW] = ib; }
+    float* part = red + 32;
     if constexpr (NORM) {
         float ssq = 0.0f;
 #pragma unroll
@@ -371,19 +360,18 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     const uint32_t o0 = 8u * (uint32_t)kg, o1 = o0 + 16u;   // bit offsets of this lane's scale byte in a dword of the row record
 
     float racc = 0.0f;
-    int slot = 0;                          // row-sum slot of the tile being accumulated
-    int p_sb = ia - v0 * nsb;              // process cursor: super-block of the next item
-    auto flush = [&]() {
-        float t = racc + __shfl_xor(racc, 16, 64);
-        t += __shfl_xor(t, 32, 64);
-        if (lane < 16) part[(wave * p.kmax + slot) * 16 + lane] = t;
+    int p_idx = wave, p_tl = 0;            // process cursor: item index, virtual tile being accumulated
+    auto flush = [&]() {                   // this wave's share of tile p_tl (zero if it had no item there): 64 lane sums, added up in the epilogue
+        part[(p_tl * NW + wave) * 64 + lane] = racc;
         racc = 0.0f;
-        ++slot;
+        ++p_tl;
     };
 
     const v4i z4 = {0, 0, 0, 0};
     auto process = [&](const RpItem<DT>& it) {
-        const int sbk = p_sb;
+        while (p_idx >= (p_tl + 1) * nsb) flush();   // uniform
+        const int sbk = p_idx - p_tl * nsb;
+        p_idx += NW;
         const uint8_t* xa = smem + xbase + 256u * (uint32_t)sbk;
         v4i b[4];
 #pragma unroll
@@ -444,35 +432,28 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
         float fneg;
         if constexpr (NSUB == 8) fneg = -h2f((uint16_t)(it.dd >> 16)) * inv; else fneg = -32.0f * d * inv;
         racc = fmaf(corr, fneg, racc);
-        if (++p_sb == nsb) { p_sb = 0; flush(); }   // the wave's share of this tile is complete (uniform)
     };
 
     // ---- the wave's items: RP_DEPTH in flight; the steady-state loop issues unconditionally (exact s_waitcnt), the tail does not ----
-    int g = ia;
-    while (g + 2 * RP_DEPTH <= ib) {
+    // (p_idx: next item to process; items p_idx, p_idx + NW ... p_idx + (RP_DEPTH - 1) NW are in the ring)
+    while (p_idx + (2 * RP_DEPTH - 1) * NW < N) {   // the prefetches of this trip (items + RP_DEPTH ... + 2 RP_DEPTH - 1) all exist
 #pragma unroll
-        for (int u = 0; u < RP_DEPTH; ++u) { process(ring[u]); load_item(ring[u]); load_advance(); }
-        g += RP_DEPTH;
+        for (int u = 0; u < RP_DEPTH; ++u) { process(ring[u]); load_item(ring[u]); }
     }
 #pragma unroll
     for (int u = 0; u < RP_DEPTH; ++u)
-        if (g + u < ib) { process(ring[u]); if (g + u + RP_DEPTH < ib) { load_item(ring[u]); load_advance(); } }
-    g += RP_DEPTH;
+        if (p_idx < N) { process(ring[u]); if (p_idx + (RP_DEPTH - 1) * NW < N) load_item(ring[u]); }
 #pragma unroll
     for (int u = 0; u < RP_DEPTH; ++u)
-        if (g + u < ib) process(ring[u]);
-    if (ib > ia && p_sb != 0) flush();
+        if (p_idx < N) process(ring[u]);
+    while (p_tl < ntl) flush();
     __syncthreads();
 
-    // ---- row sums of the workgroup's tiles: the waves' pieces in wave order, epilogue, store ----
-    const int ntl = (u1 - u0) * mult;   // virtual tiles
+    // ---- row sums of the workgroup's tiles: the waves' shares in wave order (and the four sub-block lanes of a row), epilogue, store ----
     auto tile_sum = [&](const int tl, const int r) {
+        const float* q = part + (size_t)tl * NW * 64 + r;
         float t = 0.0f;
-        const int lo = tl * nsb, hi = lo + nsb;
-        for (int w = 0; w < NW; ++w) {
-            const int aw = bnd[w], bw = bnd[w + 1];
-            if (bw > aw && aw < hi && bw > lo) t += part[(w * p.kmax + (tl - bnd[32 + w])) * 16 + r];
-        }
+        for (int w = 0; w < NW; ++w) t += (q[w * 64] + q[w * 64 + 16]) + (q[w * 64 + 32] + q[w * 64 + 48]);
         return t;
     };
     if (silu) {
@@ -555,11 +536,11 @@ __global__ __launch_bounds__(64) void rp_mfma_probe_kernel(int* D, const int8_t*
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-struct RpPlan { int nw, grid, kmax; size_t lds; int nwg[3]; };
+struct RpPlan { int nw, grid; size_t lds; int nwg[3]; };
 
-// Geometry of one launch.  A workgroup owns whole tiles (pairs of tiles for the SiLU form) of ONE segment; its waves split the
-// workgroup's items (tile x super-block) evenly and meet in LDS.  Chosen: waves per workgroup and workgroups per segment so that (i)
-// every workgroup is resident at once (16 waves and 160 KB of LDS per CU), (ii) items per wave are as even as possible.
+// Geometry of one launch.  A workgroup owns whole tiles (pairs of tiles for the SiLU form) of ONE segment; its items (tile x super-block)
+// go round its waves, which meet in LDS.  Chosen: waves per workgroup and workgroups per segment so that (i) every workgroup is resident
+// at once (16 waves and 160 KB of LDS per CU), (ii) every CU has work, (iii) items per wave are as even as possible.
 static bool rp_plan(const int* tiles, const int* dts, int nseg, int nsb, int in, int silu_pair, int force_nw, RpPlan& best) {
     static const int kNW[] = {16, 14, 12, 10, 8, 7, 6, 5, 4};
     double best_score = -1.0;
@@ -568,41 +549,39 @@ static bool rp_plan(const int* tiles, const int* dts, int nseg, int nsb, int in,
     for (int nw : kNW) {
         if (force_nw > 0 && nw != force_nw) continue;
         if ((nsb + nw - 1) / nw > RP_MAXQ) continue;
-        // workgroups per CU: waves, then LDS (kmax is not known yet: bound it by 4 slots here, checked below)
-        const size_t lds0 = rp_lds_bytes(in, nsb, nw, 4);
-        int per_cu = std::min(16 / nw, (int)((size_t)(160 * 1024) / lds0));
-        if (per_cu < 1) continue;
-        const int gmax = 256 * per_cu;
-        double wsum = 0.0;
-        for (int i = 0; i < nsegw; ++i) wsum += (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
-        int nwg[3] = {0, 0, 0}, grid = 0, max_items = 0;
-        double work = 0.0, cap = 0.0;
-        for (int i = 0; i < nsegw; ++i) {
-            const double wi = (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
-            int gi = std::max(1, (int)(gmax * wi / wsum));
-            gi = std::min(gi, tiles[i]);
-            const int k = (tiles[i] + gi - 1) / gi;           // tiles (pairs) per workgroup, at most
-            gi = (tiles[i] + k - 1) / k;
-            nwg[i] = gi;
-            grid += gi;
-            const int n_items = k * mult * nsb;
-            const int per_wave = (n_items + nw - 1) / nw;
-            max_items = std::max(max_items, per_wave);
-            const double bytes = (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
-            work += (double)tiles[i] * mult * nsb * bytes;
-            cap += (double)gi * nw * per_wave * bytes;
-        }
-        if (grid > gmax) continue;
-        const double eff = work / cap;
-        const double waves = (double)grid * nw;
-        const double score = eff * (0.7 + 0.3 * std::min(1.0, waves / 4096.0)) + 1e-4 * nw;
-        const int kmax = (max_items - 1) / nsb + 2;
-        const size_t lds = rp_lds_bytes(in, nsb, nw, kmax);
-        if (lds > 160 * 1024 || (size_t)per_cu * lds > 160 * 1024) continue;
-        if (score > best_score) {
-            best_score = score;
-            best.nw = nw; best.grid = grid; best.kmax = kmax; best.lds = lds;
-            for (int i = 0; i < 3; ++i) best.nwg[i] = nwg[i];
+        for (int per_cu = std::min(4, 16 / nw); per_cu >= 1; --per_cu) {
+            const int gmax = 256 * per_cu;
+            double wsum = 0.0;
+            for (int i = 0; i < nsegw; ++i) wsum += (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+            int nwg[3] = {0, 0, 0}, grid = 0, max_ntl = 0;
+            double work = 0.0, cap = 0.0;
+            for (int i = 0; i < nsegw; ++i) {
+                const double wi = (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+                int gi = std::max(1, (int)(gmax * wi / wsum));
+                gi = std::min(gi, tiles[i]);
+                const int k = (tiles[i] + gi - 1) / gi;           // tiles (pairs) per workgroup, at most
+                gi = (tiles[i] + k - 1) / k;
+                nwg[i] = gi;
+                grid += gi;
+                const int n_items = k * mult * nsb;
+                const int per_wave = (n_items + nw - 1) / nw;
+                max_ntl = std::max(max_ntl, k * mult);
+                const double bytes = (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+                work += (double)tiles[i] * mult * nsb * bytes;
+                cap += (double)gi * nw * per_wave * bytes;
+            }
+            if (grid > gmax) continue;
+            const size_t lds = rp_lds_bytes(in, nsb, nw, max_ntl);
+            if (lds > 160 * 1024 || (size_t)per_cu * lds > 160 * 1024) continue;
+            const double eff = work / cap;
+            const double waves = (double)grid * nw;
+            const double cus = std::min(1.0, (double)grid / 256.0);
+            const double score = eff * cus * (0.7 + 0.3 * std::min(1.0, waves / 4096.0)) + 1e-4 * nw;
+            if (score > best_score) {
+                best_score = score;
+                best.nw = nw; best.grid = grid; best.lds = lds;
+                for (int i = 0; i < 3; ++i) best.nwg[i] = nwg[i];
+            }
         }
     }
     return best_score > 0.0;
@@ -694,7 +673,6 @@ int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in
     RpPlan plan;
     if (!rp_plan(tiles, dts, nseg, nsb, in_features, silu_pair, g_rp_force_nw, plan)) return NTK_E_SHAPE;
     int wg = 0;
-    const int mult = silu_pair ? 2 : 1;
     for (int i = 0; i < nseg; ++i) {
         RpSeg& s = p.seg[i];
         s.rp = static_cast<const uint8_t*>(ord[i].W);
@@ -703,19 +681,14 @@ int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in
         s.tiles = tiles[i];
         s.p2_off = (size_t)tiles[i] * nsb * 2 * rp_s1(dts[i]);
         if (s.p2_off + (size_t)tiles[i] * nsb * rp_s2(dts[i]) > 0xFFFFFFF0ull) return NTK_E_SHAPE;   // (32-bit item offsets)
-        if (silu_pair && i == 1) { const RpSeg& g0 = p.seg[0]; s.wg0 = g0.wg0; s.nwg = g0.nwg; s.kb = g0.kb; s.krem = g0.krem;
-                                   for (int c = 0; c < 2; ++c) { s.per[c] = g0.per[c]; s.remw[c] = g0.remw[c]; } continue; }
+        if (silu_pair && i == 1) { const RpSeg& g0 = p.seg[0]; s.wg0 = g0.wg0; s.nwg = g0.nwg; s.kb = g0.kb; s.krem = g0.krem; continue; }
         s.wg0 = wg; s.nwg = plan.nwg[i];
         s.kb = tiles[i] / s.nwg; s.krem = tiles[i] % s.nwg;
-        for (int c = 0; c < 2; ++c) {   // [0]: workgroups with kb + 1 tiles, [1]: with kb
-            const int n_items = (s.kb + 1 - c) * mult * nsb;
-            s.per[c] = n_items / plan.nw; s.remw[c] = n_items % plan.nw;
-        }
         wg += plan.nwg[i];
     }
     p.nseg = nseg; p.nseg_a = na;
     p.x = x; p.in = in_features; p.nsb = nsb;
-    p.norm_w = norm_w; p.eps = eps; p.resid = resid; p.silu_pair = silu_pair; p.kmax = plan.kmax;
+    p.norm_w = norm_w; p.eps = eps; p.resid = resid; p.silu_pair = silu_pair;
     RpFn fn = nullptr;
     const bool nm = norm_w != nullptr;
     if (dta == dtb) {

@@ -37,23 +37,24 @@ def main():
     print("%-48s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "share"))
     for k, (c, t, shapes) in sorted(stats.items(), key=lambda kv: -kv[1][1]):
         print("%-48s %8d %12.1f %10.2f %6.1f%%" % (k, c, t, t / c, 100 * t / busy))
-    g = [v for k, v in stats.items() if "gemv_quant_" in k]   # every form: plain, integer-activation (xi), two-format (pair)
+    is_gemv = lambda k: "gemv_quant_" in k or "rp_gemv_kernel" in k   # every form: plain, integer-activation (xi), two-format (pair), matrix-core (rp)
+    g = [v for k, v in stats.items() if is_gemv(k)]
     if g and n_tokens:
         c, t = sum(v[0] for v in g), sum(v[1] for v in g)
         per_launch = a.gemv_bytes_per_token * n_tokens / c
-        print("\ngemv_quant_* pooled: %.1f launches/token, avg %.2f us, algorithmic %.1f MB/launch -> %.1f GB/s = %.1f%% of 8 TB/s"
+        print("\ngemv launches (gemv_quant_* + rp_gemv_kernel) pooled: %.1f launches/token, avg %.2f us, algorithmic %.1f MB/launch -> %.1f GB/s = %.1f%% of 8 TB/s"
               % (c / n_tokens, t / c, per_launch / 1e6, per_launch / (t / c * 1e-6) / 1e9, per_launch / (t / c * 1e-6) / 8e12 * 100))
         print("kernel time per token: %.1f us all kernels, %.1f us GEMV launches" % (busy / n_tokens, t / n_tokens))
     # per launch geometry of the GEMV (grid in workgroups, block, vgprs, lds): one line per distinct shape
     byshape = collections.defaultdict(lambda: [0, 0.0])
     for name, s, e, gx, wx, vg, lds in dec:
-        if "gemv_quant_" in name:
-            k = (gx // max(wx, 1), wx, vg, lds)
+        if is_gemv(name):
+            k = (name.split("(")[0].replace("void ", "").replace("ntk::", "")[:34], gx // max(wx, 1), wx, vg, lds)
             byshape[k][0] += 1
             byshape[k][1] += (e - s) / 1e3
     print("\ngemv launches by geometry (workgroups, threads, vgprs, lds bytes): calls, avg us")
     for k, (c, t) in sorted(byshape.items(), key=lambda kv: -kv[1][1]):
-        print("  %-28s %6d %9.2f" % (k, c, t / c))
+        print("  %-70s %6d %9.2f" % (k, c, t / c))
 
 
 if __name__ == "__main__":
