@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void rp_dequant_kernel(float* __restrict__ out
 // the GEMV
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int RP_MAXQ = 8;     // super-blocks of x one wave converts in the prologue (register quads)
-constexpr int RP_DEPTH = 2;    // items in flight per wave beside the one being decoded
+#ifndef NTK_RP_DEPTH
+#define NTK_RP_DEPTH 2
+#endif
+constexpr int RP_DEPTH = NTK_RP_DEPTH;    // items in flight per wave (tuning builds: -DNTK_RP_DEPTH=n)
 
 struct RpSeg {
     const uint8_t* rp;   // repacked tensor (P1, then P2 at p2_off)
@@ -539,55 +542,65 @@ __global__ __launch_bounds__(64) void rp_mfma_probe_kernel(int* D, const int8_t*
 struct RpPlan { int nw, grid; size_t lds; int nwg[3]; };
 
 // Geometry of one launch.  A workgroup owns whole tiles (pairs of tiles for the SiLU form) of ONE segment; its items (tile x super-block)
-// go round its waves, which meet in LDS.  Chosen: waves per workgroup and workgroups per segment so that (i) every workgroup is resident
-// at once (16 waves and 160 KB of LDS per CU), (ii) every CU has work, (iii) items per wave are as even as possible.
-static bool rp_plan(const int* tiles, const int* dts, int nseg, int nsb, int in, int silu_pair, int force_nw, RpPlan& best) {
-    static const int kNW[] = {16, 14, 12, 10, 8, 7, 6, 5, 4};
-    double best_score = -1.0;
-    const int mult = silu_pair ? 2 : 1;
-    const int nsegw = silu_pair ? 1 : nseg;   // segments that own workgroups
-    for (int nw : kNW) {
-        if (force_nw > 0 && nw != force_nw) continue;
-        if ((nsb + nw - 1) / nw > RP_MAXQ) continue;
-        for (int per_cu = std::min(4, 16 / nw); per_cu >= 1; --per_cu) {
-            const int gmax = 256 * per_cu;
-            double wsum = 0.0;
-            for (int i = 0; i < nsegw; ++i) wsum += (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
-            int nwg[3] = {0, 0, 0}, grid = 0, max_ntl = 0;
-            double work = 0.0, cap = 0.0;
-            for (int i = 0; i < nsegw; ++i) {
-                const double wi = (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
-                int gi = std::max(1, (int)(gmax * wi / wsum));
-                gi = std::min(gi, tiles[i]);
-                const int k = (tiles[i] + gi - 1) / gi;           // tiles (pairs) per workgroup, at most
-                gi = (tiles[i] + k - 1) / k;
-                nwg[i] = gi;
-                grid += gi;
-                const int n_items = k * mult * nsb;
-                const int per_wave = (n_items + nw - 1) / nw;
-                max_ntl = std::max(max_ntl, k * mult);
-                const double bytes = (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
-                work += (double)tiles[i] * mult * nsb * bytes;
-                cap += (double)gi * nw * per_wave * bytes;
-            }
-            if (grid > gmax) continue;
-            const size_t lds = rp_lds_bytes(in, nsb, nw, max_ntl);
-            if (lds > 160 * 1024 || (size_t)per_cu * lds > 160 * 1024) continue;
-            const double eff = work / cap;
-            const double waves = (double)grid * nw;
-            const double cus = std::min(1.0, (double)grid / 256.0);
-            const double score = eff * cus * (0.7 + 0.3 * std::min(1.0, waves / 4096.0)) + 1e-4 * nw;
-            if (score > best_score) {
-                best_score = score;
-                best.nw = nw; best.grid = grid; best.lds = lds;
-                for (int i = 0; i < 3; ++i) best.nwg[i] = nwg[i];
-            }
-        }
+// go round its waves, which meet in LDS.  Workgroups land on CUs round-robin, so what a launch costs is (the most loaded CU's bytes) +
+// (a prologue per workgroup).  Rules, from sweeps of every (waves per workgroup, workgroups per CU) at the 8B / 70B shapes
+// (tools/gemv_bench.py --rp --sweep, profiles/r04_gemv_rp_plan_sweep.txt):
+//   * 8 waves per workgroup; 16 when x has more than 32 super-blocks (the down projections: 4 register quads of x per wave at most);
+//   * one workgroup per CU, k = ceil(units / 256) units each -- unless two workgroups of ceil(units / 512) units load the fullest CU no
+//     more AND that grid would leave a sixth of the CUs of a long launch (>= 48 MB) idle (the 8B gate|up: 224 workgroups of 4 pairs).
+static bool rp_plan_try(const int* tiles, const int* dts, int nsegw, int mult, int nsb, int in, int nw, int per_cu, RpPlan& out, int* max_cu_units) {
+    if ((nsb + nw - 1) / nw > RP_MAXQ || per_cu < 1 || per_cu * nw > 16) return false;
+    const int gmax = 256 * per_cu;
+    double wsum = 0.0;
+    for (int i = 0; i < nsegw; ++i) wsum += (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+    int grid = 0, max_ntl = 0, kmax = 0;
+    for (int i = 0; i < nsegw; ++i) {
+        const double wi = (double)tiles[i] * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+        int gi = std::max(1, (int)(gmax * wi / wsum));
+        gi = std::min(gi, tiles[i]);
+        const int k = (tiles[i] + gi - 1) / gi;           // tiles (pairs) per workgroup, at most
+        gi = (tiles[i] + k - 1) / k;
+        out.nwg[i] = gi;
+        grid += gi;
+        kmax = std::max(kmax, k);
+        max_ntl = std::max(max_ntl, k * mult);
     }
-    return best_score > 0.0;
+    if (grid > gmax) return false;
+    const size_t lds = rp_lds_bytes(in, nsb, nw, max_ntl);
+    if (lds > 160 * 1024 || (size_t)per_cu * lds > 160 * 1024) return false;
+    out.nw = nw; out.grid = grid; out.lds = lds;
+    *max_cu_units = kmax * ((grid + 255) / 256);   // CU 0 hosts ceil(grid / 256) workgroups
+    return true;
 }
 
-static int g_rp_force_nw = 0;   // tuning builds: ntk_tune_rp_waves()
+static bool rp_plan(const int* tiles, const int* dts, int nseg, int nsb, int in, int silu_pair, int force_nw, int force_per_cu, RpPlan& best) {
+    const int mult = silu_pair ? 2 : 1;
+    const int nsegw = silu_pair ? 1 : nseg;   // segments that own workgroups
+    double bytes = 0.0;
+    for (int i = 0; i < nsegw; ++i) bytes += (double)tiles[i] * mult * nsb * (double)(2 * rp_s1(dts[i]) + rp_s2(dts[i]));
+    int m = 0;
+    if (force_nw > 0 || force_per_cu > 0) {   // tuning builds
+        for (int nw : {16, 14, 12, 10, 8, 7, 6, 5, 4}) for (int pc = 4; pc >= 1; --pc) {
+            if ((force_nw > 0 && nw != force_nw) || (force_per_cu > 0 && pc != force_per_cu)) continue;
+            if (rp_plan_try(tiles, dts, nsegw, mult, nsb, in, nw, pc, best, &m)) return true;
+        }
+        return false;
+    }
+    const int nw = nsb > 32 ? 16 : 8;
+    RpPlan one, two;
+    int m1 = 0, m2 = 0;
+    const bool ok1 = rp_plan_try(tiles, dts, nsegw, mult, nsb, in, nw, 1, one, &m1);
+    const bool ok2 = nw == 8 && rp_plan_try(tiles, dts, nsegw, mult, nsb, in, nw, 2, two, &m2);
+    if (ok1 && ok2) { best = (m2 <= m1 && one.grid < 240 && bytes >= 48e6) ? two : one; return true; }
+    if (ok1) { best = one; return true; }
+    if (ok2) { best = two; return true; }
+    for (int w : {16, 14, 12, 10, 8, 7, 6, 5, 4}) for (int pc = 1; pc <= 4; ++pc)   // whatever fits (shapes outside the target models)
+        if (rp_plan_try(tiles, dts, nsegw, mult, nsb, in, w, pc, best, &m)) return true;
+    return false;
+}
+
+static int g_rp_force_nw = 0, g_rp_force_per_cu = 0;   // tuning builds: ntk_tune_rp_plan()
+static int g_rp_last_nw = 0, g_rp_last_grid = 0, g_rp_last_lds = 0;
 
 using RpFn = void (*)(const RpParams);
 template <int DTA, int DTB> static RpFn rp_fn(bool norm) {
@@ -671,7 +684,7 @@ int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in
     int tiles[3] = {0, 0, 0}, dts[3] = {0, 0, 0};
     for (int i = 0; i < nseg; ++i) { tiles[i] = (ord[i].rows + 15) / 16; dts[i] = ord[i].dtype; }
     RpPlan plan;
-    if (!rp_plan(tiles, dts, nseg, nsb, in_features, silu_pair, g_rp_force_nw, plan)) return NTK_E_SHAPE;
+    if (!rp_plan(tiles, dts, nseg, nsb, in_features, silu_pair, g_rp_force_nw, g_rp_force_per_cu, plan)) return NTK_E_SHAPE;
     int wg = 0;
     for (int i = 0; i < nseg; ++i) {
         RpSeg& s = p.seg[i];
@@ -699,6 +712,9 @@ int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in
     else if (dta == NTK_DT_Q5_K && dtb == NTK_DT_Q4_K) fn = rp_fn<NTK_DT_Q5_K, NTK_DT_Q4_K>(nm);
     else return NTK_E_DTYPE;
     if (!fn) return NTK_E_LAUNCH;
+#ifdef NTK_TUNE
+    g_rp_last_nw = plan.nw; g_rp_last_grid = plan.grid; g_rp_last_lds = (int)plan.lds;
+#endif
     hipLaunchKernelGGL(fn, dim3((unsigned)plan.grid), dim3((unsigned)(64 * plan.nw)), plan.lds, resolve_stream(stream), p);
     return last_launch_status();
 }
@@ -709,7 +725,10 @@ int ntk_gemv_rp(float* y, const void* rp, const float* x, int out_features, int 
 }
 
 #ifdef NTK_TUNE
-void ntk_tune_rp_waves(int nw) { ntk::g_rp_force_nw = nw; }   // tuning builds (make tune): waves per workgroup of every rp launch, 0 = the planner's choice
+// tuning builds (make tune): waves per workgroup / workgroups per CU of every rp launch, 0 = the planner's choice
+void ntk_tune_rp_plan(int nw, int per_cu) { ntk::g_rp_force_nw = nw; ntk::g_rp_force_per_cu = per_cu; }
+void ntk_tune_rp_waves(int nw) { ntk_tune_rp_plan(nw, 0); }
+void ntk_tune_rp_last_plan(int* out3) { out3[0] = ntk::g_rp_last_nw; out3[1] = ntk::g_rp_last_grid; out3[2] = ntk::g_rp_last_lds; }
 #endif
 
 int ntk_debug_rp_prologue(uint8_t* out, const float* x, const float* norm_w, float eps, int in_features, int nsub, int nwaves, void* stream) {

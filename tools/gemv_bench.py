@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--rp", action="store_true", help="the matrix-core GEMV over repacked tensors (ntk_gemv_rp_fused); GB/s still counts GGUF bytes")
     ap.add_argument("--nw", type=int, default=0, help="--rp with a tuning build (make tune, NTK_LIB_PATH): waves per workgroup, 0 = planner")
+    ap.add_argument("--sweep", action="store_true", help="--rp with a tuning build: every (waves per workgroup, workgroups per CU) the planner could take, per shape")
     a = ap.parse_args()
     ops.init(0)
     L = _lib.lib()
@@ -90,30 +91,52 @@ def main():
                 else:
                     ops.gemv_fused([(base, ys[0], rlist[0], dt), (base + rlist[0] * rb, ys[1], rlist[0], dt)], x, in_f,
                                    norm_w=nw, eps=1e-5, silu_pair=True)
-            for s in range(min(nslots, 4)):
-                launch(s)
-            ops.synchronize()
-            n = max(nslots, 200 if per_launch < (64 << 20) else 20)
-            # capture the n launches into one hipGraph: back-to-back on the device like a decode token, no host
-            # launch cost in the measurement (eager launches from Python are host-bound below ~10 us per kernel)
-            stream = L.ntk_stream(0)
-            graph, gexec = C.c_void_p(), C.c_void_p()
-            assert HIP.hipStreamBeginCapture(C.c_void_p(stream), 1) == 0
-            for i in range(n):
-                launch(i % nslots)
-            assert HIP.hipStreamEndCapture(C.c_void_p(stream), C.byref(graph)) == 0
-            assert HIP.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
-            HIP.hipGraphLaunch(gexec, C.c_void_p(stream))
-            ops.synchronize()
-            L.ntk_event_record(ev0, None)
-            HIP.hipGraphLaunch(gexec, C.c_void_p(stream))
-            L.ntk_event_record(ev1, None)
-            L.ntk_event_synchronize(ev1)
-            ms = C.c_float()
-            L.ntk_event_elapsed_ms(ev0, ev1, C.byref(ms))
-            HIP.hipGraphExecDestroy(gexec)
-            HIP.hipGraphDestroy(graph)
-            us = ms.value * 1e3 / n
+            def measure():
+                for s in range(min(nslots, 4)):
+                    launch(s)
+                ops.synchronize()
+                n = max(nslots, 200 if per_launch < (64 << 20) else 20)
+                # capture the n launches into one hipGraph: back-to-back on the device like a decode token, no host
+                # launch cost in the measurement (eager launches from Python are host-bound below ~10 us per kernel)
+                stream = L.ntk_stream(0)
+                graph, gexec = C.c_void_p(), C.c_void_p()
+                assert HIP.hipStreamBeginCapture(C.c_void_p(stream), 1) == 0
+                for i in range(n):
+                    launch(i % nslots)
+                assert HIP.hipStreamEndCapture(C.c_void_p(stream), C.byref(graph)) == 0
+                assert HIP.hipGraphInstantiate(C.byref(gexec), graph, None, None, 0) == 0
+                HIP.hipGraphLaunch(gexec, C.c_void_p(stream))
+                ops.synchronize()
+                L.ntk_event_record(ev0, None)
+                HIP.hipGraphLaunch(gexec, C.c_void_p(stream))
+                L.ntk_event_record(ev1, None)
+                L.ntk_event_synchronize(ev1)
+                ms = C.c_float()
+                L.ntk_event_elapsed_ms(ev0, ev1, C.byref(ms))
+                HIP.hipGraphExecDestroy(gexec)
+                HIP.hipGraphDestroy(graph)
+                return ms.value * 1e3 / n
+            if a.rp and a.sweep:   # every geometry the planner could take for this launch (tuning build)
+                rows_out = []
+                for nwv in (16, 14, 12, 10, 8, 7, 6, 5, 4):
+                    for pc in (1, 2, 3, 4):
+                        L.ntk_tune_rp_plan(nwv, pc)
+                        try:
+                            us = measure()
+                        except _lib.NtkError:
+                            continue
+                        plan = (C.c_int * 3)()
+                        L.ntk_tune_rp_last_plan(plan)
+                        rows_out.append((us, nwv, pc, plan[1], plan[2]))
+                L.ntk_tune_rp_plan(0, 0)
+                us0 = measure()
+                plan = (C.c_int * 3)()
+                L.ntk_tune_rp_last_plan(plan)
+                rows_out.sort()
+                print("%-8s %-18s planner: nw %d grid %d lds %d -> %.2f us; best: %s" % (dname + ".rp", sname, plan[0], plan[1], plan[2], us0,
+                      "  ".join("nw%d/cu%d g%d %.2f" % (r[1], r[2], r[3], r[0]) for r in rows_out[:6])), flush=True)
+                continue
+            us = measure()
             gbs = per_launch / (us * 1e-6) / 1e9
             results.append({"dtype": dname + (".rp" if a.rp else ""), "shape": sname, "bytes": per_launch, "us": round(us, 2), "GBs": round(gbs, 1),
                             "frac_8TBs": round(gbs / 8000, 4)})
