@@ -162,6 +162,9 @@ __global__ __launch_bounds__(256) void rp_dequant_kernel(float* __restrict__ out
 // the GEMV
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int RP_MAXQ = 8;     // super-blocks of x one wave converts in the prologue (register quads)
+#ifndef NTK_RP_LAZY_MIN
+#define NTK_RP_LAZY_MIN 3   // quads of x per wave from which they are converted on the way (tuning builds: -DNTK_RP_LAZY_MIN=n)
+#endif
 #ifndef NTK_RP_DEPTH
 #define NTK_RP_DEPTH 2
 #endif
@@ -204,31 +207,30 @@ __device__ __forceinline__ void rp_convert_quad(uint8_t* smem, const int in, con
     int e = am > 0.0f ? __builtin_amdgcn_frexp_expf(am) : 0;   // am = m 2^e, 0.5 <= m < 1
     e = max(e, -100);                                            // (keeps 2^(22-e) finite for vanishing activations)
     const float up = __builtin_ldexpf(1.0f, 22 - e), inv = __builtin_ldexpf(1.0f, e - 22);
-    // rint through the magic constant 1.5 * 2^23: the low mantissa bits ARE the two's-complement integer, |X| <= 2^22
-    const int x0 = (int)(__float_as_uint(fmaf(v0, up, 12582912.0f)) - 0x4B400000u), x1 = (int)(__float_as_uint(fmaf(v1, up, 12582912.0f)) - 0x4B400000u),
-              x2 = (int)(__float_as_uint(fmaf(v2, up, 12582912.0f)) - 0x4B400000u), x3 = (int)(__float_as_uint(fmaf(v3, up, 12582912.0f)) - 0x4B400000u);
-    // signed base-256 digits: X + 0x808080 has the digits d_p + 128 as its (unsigned) bytes; xor 0x80 makes them the int8 d_p
-    const uint32_t y0 = ((uint32_t)x0 + 0x808080u) ^ 0x808080u, y1 = ((uint32_t)x1 + 0x808080u) ^ 0x808080u,
-                   y2 = ((uint32_t)x2 + 0x808080u) ^ 0x808080u, y3 = ((uint32_t)x3 + 0x808080u) ^ 0x808080u;
+    // rint through the magic constant 1.5 * 2^23: the low mantissa bits ARE the two's-complement integer X, |X| <= 2^22.  Signed base-256
+    // digits: X + 0x808080 has the digits d_p + 128 as its (unsigned) bytes -- one subtraction takes the magic constant off and puts the
+    // bias on -- and an xor with 0x80 per byte (after the transpose, a dword at a time) makes them the int8 d_p
+    const uint32_t y0 = __float_as_uint(fmaf(v0, up, 12582912.0f)) - (0x4B400000u - 0x808080u), y1 = __float_as_uint(fmaf(v1, up, 12582912.0f)) - (0x4B400000u - 0x808080u),
+                   y2 = __float_as_uint(fmaf(v2, up, 12582912.0f)) - (0x4B400000u - 0x808080u), y3 = __float_as_uint(fmaf(v3, up, 12582912.0f)) - (0x4B400000u - 0x808080u);
     // 4 x 3 byte transpose: plane p of the four columns
     const uint32_t ta = __builtin_amdgcn_perm(y1, y0, 0x05010400u);    // y0.b0 y1.b0 y0.b1 y1.b1
     const uint32_t tb = __builtin_amdgcn_perm(y1, y0, 0x07030602u);    // y0.b2 y1.b2 y0.b3 y1.b3
     const uint32_t tc = __builtin_amdgcn_perm(y3, y2, 0x05010400u);
     const uint32_t td = __builtin_amdgcn_perm(y3, y2, 0x07030602u);
-    const uint32_t p0 = __builtin_amdgcn_perm(tc, ta, 0x05040100u);    // digit 0 of columns 0..3
-    const uint32_t p1 = __builtin_amdgcn_perm(tc, ta, 0x07060302u);    // digit 1
-    const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u);    // digit 2
+    const uint32_t p0 = __builtin_amdgcn_perm(tc, ta, 0x05040100u) ^ 0x80808080u;    // digit 0 of columns 0..3
+    const uint32_t p1 = __builtin_amdgcn_perm(tc, ta, 0x07060302u) ^ 0x80808080u;    // digit 1
+    const uint32_t p2 = __builtin_amdgcn_perm(td, tb, 0x05040100u) ^ 0x80808080u;    // digit 2
     const int col = 256 * sb + 4 * lane;
     *reinterpret_cast<uint32_t*>(smem + col) = p0;
     *reinterpret_cast<uint32_t*>(smem + in + col) = p1;
     *reinterpret_cast<uint32_t*>(smem + 2 * in + col) = p2;
     *reinterpret_cast<uint32_t*>(smem + 3 * in + col) = 0u;
     // sums of X over the 16-column (Q6_K) / 32-column (Q4_K, Q5_K) sub-blocks: 4 / 8 consecutive lanes
-    int sm = (x0 + x1) + (x2 + x3);
+    int sm = (int)((y0 + y1) + (y2 + y3));   // (each term carries the bias 0x808080: 16 / 32 of them per sub-block, taken off below)
     sm += dpp_i<DPP_QUAD_1032>(sm);
     sm += dpp_i<DPP_QUAD_2301>(sm);
     if constexpr (NSUB == 8) sm += dpp_i<DPP_ROW_HALF_MIRROR>(sm);
-    uint32_t ys = ((uint32_t)sm + 0x80808080u) ^ 0x80808080u;   // four signed digits (|sum| <= 2^27)
+    uint32_t ys = ((uint32_t)sm + (0x80808080u - (NSUB == 8 ? 32u : 16u) * 0x808080u)) ^ 0x80808080u;   // four signed digits (|sum| <= 2^27)
     int pos;
     if constexpr (NSUB == 8) { pos = (lane & 4) ? 8 + (lane >> 3) : (lane >> 3); if (lane & 4) ys = 0u; }   // bytes 8..15 of an entry stay zero
     else pos = lane >> 2;
@@ -345,12 +347,29 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
             xq[q].z = xq[q].z * rms_inv * wq[q].z; xq[q].w = xq[q].w * rms_inv * wq[q].w;
         }
     }
+    // The digit image.  When the waves divide the super-blocks evenly (or the workgroup has one tile), wave w only ever decodes super-blocks w,
+    // w + NW ...: exactly the ones whose x it holds -- its part of the image is private: no barrier, and each quad is converted right
+    // before the first item that needs it (process(), first tile), so the weight stream keeps flowing under the conversion (~70 VALU
+    // instructions per quad: 4 us of a CU's time for the 28672 columns of the 70B down projection when done up front).  Until then the
+    // quad waits IN PLACE: component c of lane l in the bytes of plane c it will overwrite.  Otherwise: all of it now, barrier.
+    // (measured, tools/gemv_bench.py: with 4 / 7 quads per wave -- the 8192- and 28672-column launches -- on-the-way conversion gains
+    // 0.5 ... 2.3 us per launch; with 2 -- 4096 columns -- the trip through LDS costs 0.25 us more than it hides: those convert at once)
+    const bool priv = nsb % NW == 0 || ntl == 1;     // uniform (one tile: item index = super-block index, whatever the remainder)
+    const int nq = (priv && (nsb + NW - 1) / NW >= NTK_RP_LAZY_MIN) ? (nsb + NW - 1) / NW : 0;   // quads converted on the way
 #pragma unroll
     for (int q = 0; q < RP_MAXQ; ++q) {
         const int sb = wave + q * NW;
-        if (sb < nsb) rp_convert_quad<NSUB>(smem, in, nsb, sb, lane, xq[q].x, xq[q].y, xq[q].z, xq[q].w);   // uniform
+        if (sb < nsb) {   // uniform
+            if (nq > 0 && q > 0) {
+                uint8_t* at = smem + 256 * sb + 4 * lane;
+                *reinterpret_cast<float*>(at) = xq[q].x; *reinterpret_cast<float*>(at + in) = xq[q].y;
+                *reinterpret_cast<float*>(at + 2 * in) = xq[q].z; *reinterpret_cast<float*>(at + 3 * in) = xq[q].w;
+            } else {
+                rp_convert_quad<NSUB>(smem, in, nsb, sb, lane, xq[q].x, xq[q].y, xq[q].z, xq[q].w);
+            }
+        }
     }
-    __syncthreads();
+    if (!priv) __syncthreads();
 
     // ---- lane constants of the A operands (digit planes) ----
     const int m16 = lane & 15;            // entry m = 4 jj + p of the first MFMA operand
@@ -359,6 +378,7 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     const uint32_t xbase = (uint32_t)(a_ok ? pp * in : 3 * in) + 16u * (uint32_t)kg;
     const bool c_ok = m16 < 4 && kg == 0;   // correction: entry m = digit m of the sub-block sums, k-slots of kg 0 only
     const uint32_t cbase = c_ok ? (uint32_t)(4 * in + 16 * m16) : (uint32_t)(3 * in);
+    const uint32_t cstride = c_ok ? 64u : 256u;   // (the other lanes read zeros of THEIR item's super-block: written by this wave)
     const float* invt = reinterpret_cast<const float*>(smem + 4 * (size_t)in + 64 * (size_t)nsb);
     const uint32_t o0 = 8u * (uint32_t)kg, o1 = o0 + 16u;   // bit offsets of this lane's scale byte in a dword of the row record
 
@@ -375,6 +395,12 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
         while (p_idx >= (p_tl + 1) * nsb) flush();   // uniform
         const int sbk = p_idx - p_tl * nsb;
         p_idx += NW;
+        if (nq > 0 && p_tl == 0 && sbk >= NW) {   // first use of this super-block's x (uniform): floats in place -> digit planes (LDS and VALU only)
+            const uint8_t* at = smem + 256 * sbk + 4 * lane;
+            const float v0 = *reinterpret_cast<const float*>(at), v1 = *reinterpret_cast<const float*>(at + in);
+            const float v2 = *reinterpret_cast<const float*>(at + 2 * in), v3 = *reinterpret_cast<const float*>(at + 3 * in);
+            rp_convert_quad<NSUB>(smem, in, nsb, sbk, lane, v0, v1, v2, v3);
+        }
         const uint8_t* xa = smem + xbase + 256u * (uint32_t)sbk;
         v4i b[4];
 #pragma unroll
@@ -409,7 +435,7 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
         else bc = v4i{kg == 0 ? (int)it.rec[0] : 0, kg == 0 ? (int)it.rec[1] : 0, kg == 0 ? (int)it.rec[2] : 0, kg == 0 ? (int)it.rec[3] : 0};
         const v4i a0 = *reinterpret_cast<const v4i*>(xa), a1 = *reinterpret_cast<const v4i*>(xa + 64);
         const v4i a2 = *reinterpret_cast<const v4i*>(xa + 128), a3 = *reinterpret_cast<const v4i*>(xa + 192);
-        const v4i ac = *reinterpret_cast<const v4i*>(smem + cbase + 64u * (uint32_t)sbk);
+        const v4i ac = *reinterpret_cast<const v4i*>(smem + cbase + cstride * (uint32_t)sbk);
         const float inv = invt[sbk];
         // the five matrix instructions back to back; their results are consumed below, after the last has been issued
         const v4i c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b[0], z4, 0, 0, 0);
@@ -545,7 +571,8 @@ struct RpPlan { int nw, grid; size_t lds; int nwg[3]; };
 // go round its waves, which meet in LDS.  Workgroups land on CUs round-robin, so what a launch costs is (the most loaded CU's bytes) +
 // (a prologue per workgroup).  Rules, from sweeps of every (waves per workgroup, workgroups per CU) at the 8B / 70B shapes
 // (tools/gemv_bench.py --rp --sweep, profiles/r04_gemv_rp_plan_sweep.txt):
-//   * 8 waves per workgroup; 16 when x has more than 32 super-blocks (the down projections: 4 register quads of x per wave at most);
+//   * 8 waves per workgroup; 16 when x has more than 32 super-blocks (the down projections).  (14 waves for the 56 super-blocks of the
+//     8B down projection, which would keep every wave's part of the digit image private, measured slower than 16 with a barrier.)
 //   * one workgroup per CU, k = ceil(units / 256) units each -- unless two workgroups of ceil(units / 512) units load the fullest CU no
 //     more AND that grid would leave a sixth of the CUs of a long launch (>= 48 MB) idle (the 8B gate|up: 224 workgroups of 4 pairs).
 static bool rp_plan_try(const int* tiles, const int* dts, int nsegw, int mult, int nsb, int in, int nw, int per_cu, RpPlan& out, int* max_cu_units) {
