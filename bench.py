@@ -17,9 +17,11 @@ Besides the contract fields the line carries
   cpu_baseline -- the reference's own CLI + host loop (oracle/_ref/ntransformer_cpu: reference src/main.cpp, engine.cpp,
                   transformer.cpp ... compiled unmodified, linked with the CPU restatement of its CUDA kernels) run on the
                   SAME full-size 8B Q8_0 GGUF on this host's cores; its own `Decode: ... tok/s` line is the value
-  config.also  -- (N=1) the other BASELINE configurations timed in the same process the same way: 8B Q4_K_M (config 3), 70B Q4_K_M
-                  -n 64 (config 4), 70B Q6_K -n 64 (config 5, one replica) and the headline model decoding behind a 3900-token prompt
-                  (the long-context attention regime)
+  config.also  -- the other BASELINE configurations timed in the same process the same way, one compact entry each {k, value, ms,
+                  frac (end to end, of 8 TB/s), gemv_frac (GEMV launches, live HIP events), prompt_tok_s}: at N = 1 8B Q4_K_M (config 3),
+                  70B Q4_K_M -n 64 (config 4), 70B Q6_K -n 64 (config 5, one replica) and the headline model decoding behind a 3900-token
+                  prompt (the split-KV attention regime); at N > 1 the 70B Q6_K replicas of config 5 (whole-job value over the N GPUs).
+                  The line stays under 5 KB so that a log window of the driver cannot cut an entry off
   vs_baseline  -- whole-job value / the published single-GPU number of BASELINE.md (48.9 tok/s, RTX 3090): with N independent replicas
                   (scaling = weak) that is N x the per-GPU speed-up, which `vs_baseline_per_gpu` states on its own
 """
@@ -122,12 +124,10 @@ def cpu_baseline_reference_cli(args, spec):
             raise RuntimeError("reference CLI failed (rc %d): %s" % (r.returncode, txt[-400:]))
         n_dec, ms_dec = int(m.group(1)), float(m.group(2))
         return {"value": round(n_dec / (ms_dec * 1e-3), 4), "unit": "tokens/s", "cores": threads, "kind": "port",
-                "sample": "reference CLI (oracle/_ref/ntransformer_cpu: reference main.cpp + Engine + Transformer host code, "
-                          "unmodified; kernels = the CPU restatement, OpenMP over output rows) on the FULL %s %s GGUF "
-                          "(%.1f GB in %s), -p %s -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Stats line, %d decode tokens in "
-                          "%.0f ms (prompt %s tokens %s ms); whole run %.1f s + %.1f s writing the file"
-                          % (args.model, args.mix, os.path.getsize(path) / 1e9, os.path.dirname(path), cpu_prompt, args.cpu_tokens, args.ctx,
-                             n_dec, ms_dec, mp.group(1) if mp else "?", mp.group(2) if mp else "?", wall, t_write),
+                "sample": "reference CLI (oracle/_ref/ntransformer_cpu: the reference's unmodified host code over the CPU restatement of its "
+                          "kernels) on the full %s %s GGUF (%.1f GB), -p <%d tokens> -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Decode: line, "
+                          "%d tokens in %.0f ms; run %.0f s + %.0f s writing the file"
+                          % (args.model, args.mix, os.path.getsize(path) / 1e9, len(cpu_prompt) + 1, args.cpu_tokens, args.ctx, n_dec, ms_dec, wall, t_write),
                 "host": _cpu_model(), "host_cpus": info}
     finally:
         try:
@@ -156,11 +156,16 @@ def _gemv_bytes_per_token(spec, mix):
     return total
 
 
-def activation_form(mix):
-    """what the GEMV launches multiply the integer weights with (csrc/gemv_core.hip.h): F32 activations everywhere, except that Q4_K /
-    Q6_K launches of >= 48 MiB with rows of <= 2 column slices take 22-bit block-floating integer activations (exact integer dot
-    products per 32-column sub-block; error per term 2^-23 of the sub-block's largest |x|, the level of the F32 rounding it replaces)"""
-    return "f32" if mix in ("Q8_0", "Q4_0", "F16", "F32", "Q5_K") else "f32; int24-block for Q4_K / Q6_K launches >= 48 MiB"
+ACTIVATION_FORMS = {
+    "f32": "F32 activations x integer weights, F32 accumulate (csrc/gemv.hip)",
+    "int24-block": "K-quant launches of the fused decode path: x as three int8 digit planes of rint(x 2^(22-e)), e per 256-column super-block "
+                   "(<= 2^-23 of the block's largest |x| per term), exact integer dot products on v_mfma_i32_16x16x64_i8 over the engine's "
+                   "load-time repack (csrc/gemv_rp.hip); scales, minima and summation in F32",
+}
+
+
+def activation_form(mix, repack=True):
+    return "f32" if (mix in ("Q8_0", "Q4_0", "F16", "F32") or not repack) else "int24-block"
 
 
 def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
@@ -191,7 +196,12 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     pos += warmup
     elapsed, _, out = timed(lambda k: eng.decode_greedy_steps(tok, pos, k), steps)
     pos_end = pos + steps
-    res = {"spec": spec, "elapsed": elapsed, "pos": pos, "pos_end": pos_end, "t_load": t_load,
+    try:   # the shader clock right behind the timed region (DVFS moves in milliseconds): lets a profiled pass be compared with an un-profiled one
+        from ntransformer_amd import ops as _ops
+        sclk = round(_ops.sclk_mhz(), 1)
+    except Exception:
+        sclk = None
+    res = {"spec": spec, "elapsed": elapsed, "pos": pos, "pos_end": pos_end, "t_load": t_load, "sclk_mhz": sclk,
            "b_tok": eng.bytes_per_token(pos + steps // 2), "path": eng.decode_path() if hasattr(eng, "decode_path") else None}
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the compute stream over a few eagerly
@@ -219,8 +229,7 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
             t0 = time.perf_counter()
             eng.forward(long_prompt, 0)
             dt = time.perf_counter() - t0
-            res["prompt"] = {"tokens": args.prompt_bench, "ms": round(dt * 1e3, 2), "tokens_per_s": round(args.prompt_bench / dt, 1),
-                             "activation_form": "two FP16 pieces per F32 activation, per-token power-of-two scale (|error| <= 2^-23 |x|: csrc/gemm_f16.hip)"}
+            res["prompt"] = {"tokens": args.prompt_bench, "ms": round(dt * 1e3, 2), "tokens_per_s": round(args.prompt_bench / dt, 1)}
         except Exception as e:   # never at the expense of the decode number
             res["prompt"] = {"tokens": args.prompt_bench, "error": repr(e)}
     eng.close()
@@ -232,7 +241,8 @@ def roofline_block(args, model, mix, r):
     avg_launch_ms = r["ms"][0] / max(r["calls"][0], 1)
     achieved = (r["gemv_bytes_tok"] / max(launches_tok, 1)) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     traffic, traffic_src = _pmc_traffic(model, mix)
-    return {"bound": "hbm", "kernel": "gemv_quant_kernel<%s> (all projection launches of a token pooled)" % mix,
+    kern = "gemv_quant_kernel" if activation_form(mix, not args.no_repack) == "f32" else "rp_gemv_kernel"
+    return {"bound": "hbm", "kernel": "ntk::%s, %s (all projection launches of a token pooled)" % (kern, mix),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": int(r["gemv_bytes_tok"] / max(launches_tok, 1)), "launches_per_token": launches_tok,
@@ -277,19 +287,26 @@ def main():
         return replica.timed_steps(fn, k, sync, None, None)
 
     r = run_workload(args, args.model, args.mix, args.steps, args.warmup, timed_all_ranks, sync)
+    headline = (args.model, args.mix) == ("8b", "Q8_0")
+    if rank != 0 and world > 1 and headline and not args.no_also:   # (rank 0 runs it below, inside the collective timing: same order on every rank)
+        try:
+            keep_pb, args.prompt_bench = args.prompt_bench, 0
+            run_workload(args, "70b", "Q6_K", 64, min(args.warmup, 8), timed_all_ranks, sync)
+            args.prompt_bench = keep_pb
+        except Exception as e:
+            print("bench.py: rank %d: 70B Q6_K replica failed: %r" % (rank, e), file=sys.stderr)
 
     if rank == 0:
         elapsed = r["elapsed"]
         tok_s = world * args.steps / elapsed
-        headline = (args.model, args.mix) == ("8b", "Q8_0")
         line = {
             "metric": "decode tokens/sec (Llama-3.1-8B Q8_0 class, resident weights, greedy, batch 1)" if headline
                       else "decode tokens/sec (%s %s, resident weights, greedy, batch 1)" % (args.model, args.mix),
             "value": round(tok_s, 3), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "sclk_mhz": r["sclk_mhz"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(tok_s / REF_3090_TOK_S, 3) if headline else None,   # whole-job value / the published single-GPU number
             "vs_baseline_per_gpu": round(tok_s / world / REF_3090_TOK_S, 3) if headline else None,
-            "dtype": "f32", "activation_form": activation_form(args.mix), "data": "synthetic",
+            "dtype": "f32", "activation_form": activation_form(args.mix, not args.no_repack), "activation_forms": ACTIVATION_FORMS, "data": "synthetic",
             "config": {"workload": "Llama-3.1-%s-shaped %s GGUF tensors (seed 20260925), resident in HBM, %d-token prompt, greedy decode"
                                    % (args.model.upper(), args.mix, args.prompt_len),
                        "ctx": args.ctx, "decode_positions": [r["pos"], r["pos_end"]], "replicas": world,
@@ -300,30 +317,34 @@ def main():
             "hbm_fraction_of_8TBs_end_to_end": round(r["b_tok"] * tok_s / world / (HBM_PEAK_GBS * 1e9), 4),
             "roofline": roofline_block(args, args.model, args.mix, r),
         }
-        # ---- the other BASELINE configurations under the same clock (N = 1 only: they are single-GPU configurations) ----
-        if world == 1 and headline and not args.no_also:
+        # ---- the other BASELINE configurations under the same clock: compact entries (the whole line stays under 5 KB) ----
+        def also_entry(key, model, mix, steps, a, nrep):
+            a_tok_s = nrep * steps / a["elapsed"]
+            rb = roofline_block(args, model, mix, a)
+            e = {"k": key, "value": round(a_tok_s, 2), "ms": round(1e3 * a["elapsed"] / steps, 4), "steps": steps,
+                 "frac": round(a["b_tok"] * a_tok_s / nrep / (HBM_PEAK_GBS * 1e9), 4), "gemv_frac": rb["frac"], "gemv_us": rb["avg_launch_us"],
+                 "pos": [a["pos"], a["pos_end"]], "form": activation_form(mix, not args.no_repack), "sclk_mhz": a["sclk_mhz"]}
+            if a.get("prompt") and "tokens_per_s" in a["prompt"]:
+                e["prompt_tok_s"] = a["prompt"]["tokens_per_s"]
+            return e
+        line["config"]["also_legend"] = ("k = model_mix[_ctx<prompt tokens>], synthetic, resident, greedy; value tokens/s (whole job); ms per step; frac = "
+                                         "algorithmic bytes/token x tokens/s / 8 TB/s (per GPU); gemv_frac / gemv_us = GEMV launches, live HIP events; "
+                                         "prompt_tok_s = one 1024-token prompt pass")
+        if headline and not args.no_also:
             also = []
-            for model, mix, steps, plen in (("8b", "Q4_K_M", 128, None), ("70b", "Q4_K_M", 64, None), ("70b", "Q6_K", 64, None),
-                                            ("8b", "Q8_0", 64, 3900)):
+            plan = ((("8b", "Q4_K_M", 128, None), ("70b", "Q4_K_M", 64, None), ("70b", "Q6_K", 64, None), ("8b", "Q8_0", 64, 3900))
+                    if world == 1 else (("70b", "Q6_K", 64, None),))   # N > 1: BASELINE config 5, one whole-model replica per GPU
+            for model, mix, steps, plen in plan:
+                key = "%s_%s%s" % (model, mix.lower(), "_ctx%d" % plen if plen else "")
                 try:
                     keep_pb = args.prompt_bench
-                    if plen:
+                    if plen or world > 1:
                         args.prompt_bench = 0
-                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local, sync, prompt_len=plen)
+                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local if world == 1 else timed_all_ranks, sync, prompt_len=plen)
                     args.prompt_bench = keep_pb
-                    a_tok_s = steps / a["elapsed"]
-                    rb = roofline_block(args, model, mix, a)
-                    also.append({"workload": "Llama-3.1-%s-shaped %s, resident, %d-token prompt, greedy decode" % (model.upper(), mix, plen or args.prompt_len),
-                                 "value": round(a_tok_s, 3), "unit": "tokens/s", "steps": steps, "warmup": min(args.warmup, 8),
-                                 "ms_per_step": round(1e3 * a["elapsed"] / steps, 4), "decode_positions": [a["pos"], a["pos_end"]],
-                                 "algorithmic_bytes_per_token": a["b_tok"], "activation_form": activation_form(mix),
-                                 "frac": round(a["b_tok"] * a_tok_s / (HBM_PEAK_GBS * 1e9), 4),
-                                 "gemv_launch_frac": rb["frac"], "gemv_avg_launch_us": rb["avg_launch_us"],
-                                 "gemv_launches_per_token": rb["launches_per_token"],
-                                 "token_ms_by_class_eager": rb["token_ms_by_class_eager"], "path": a["path"], "prompt_pass": a.get("prompt"),
-                                 "load_seconds": round(a["t_load"], 2)})
+                    also.append(also_entry(key, model, mix, steps, a, world))
                 except Exception as e:   # the headline must survive a problem in an extra workload
-                    also.append({"workload": "%s %s" % (model, mix), "value": None, "error": repr(e)})
+                    also.append({"k": key, "value": None, "error": repr(e)[:200]})
             line["config"]["also"] = also
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (the replicas of an N > 1 run would wait on it)
             try:

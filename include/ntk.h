@@ -282,6 +282,10 @@ int ntk_repeat_penalty(float* logits, int n, const int* d_recent, int n_recent, 
 int ntk_argmax_advance(const float* logits, int n, int* d_out_token, int* h_mirror, unsigned long long* h_ring4, int* d_pos,
                        float* scratch, void* stream);
 
+/* measurement instrumentation: the shader clock right now.  d_out2 (DEVICE, 3 x 8 bytes): [0] shader cycles (s_memtime) and [1] 10 ns ticks
+ * (s_memrealtime) over ~50 us of one spinning wave: MHz = 100 * [0] / [1].  bench.py records it right behind the timed region. */
+int ntk_debug_sclk(unsigned long long* d_out2, void* stream);
+
 /* *d_pos += 1 (one thread); keeps positions on the device across graph replays */
 int ntk_advance_pos(int* d_pos, void* stream);
 

@@ -99,6 +99,7 @@ def lib() -> C.CDLL:
         "ntk_embed_rows": (i, [vp, vp, vp, i, i, i, vp]),
         "ntk_argmax": (i, [vp, i, vp, vp, vp, vp]),
         "ntk_advance_pos": (i, [vp, vp]),
+        "ntk_debug_sclk": (i, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = the .so does not export what include/ntk.h declares

@@ -171,6 +171,20 @@ __global__ __launch_bounds__(256) void argmax_stage2(const float* __restrict__ s
 }
 __global__ void advance_pos_kernel(int* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
 
+__global__ __launch_bounds__(64) void sclk_probe_kernel(unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    float acc = (float)threadIdx.x;
+    while (r1 - r0 < 5000ull) {   // 50 us
+#pragma unroll
+        for (int i = 0; i < 64; ++i) acc = fmaf(acc, 1.0000001f, 1e-9f);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (acc == 12345.678f) out[2] = 0;   // (keeps the spin's arithmetic alive; never true)
+}
+
 // stage 2 of the greedy tail of a token (ntk_argmax_advance): final arg-max, the token to the device word and to the pinned host ring
 // -- slot (position & 3), ONE 8-byte store {token, position + 1}: the host can poll it while the next token's launches are already
 // queued, and a token that runs one ahead cannot overwrite what the host has not read yet -- and the position advanced, in one launch
@@ -309,6 +323,14 @@ int ntk_argmax_advance(const float* logits, int n, int* d_out_token, int* h_mirr
     hipStream_t st = resolve_stream(stream);
     hipLaunchKernelGGL(argmax_stage1, dim3(nblk), dim3(256), 0, st, logits, n, sv, si);
     hipLaunchKernelGGL(argmax_advance_stage2, dim3(1), dim3(256), 0, st, (const float*)sv, (const int*)si, nblk, d_out_token, h_mirror, h_ring4, d_pos);
+    return last_launch_status();
+}
+// measurement instrumentation: shader clock right now = s_memtime ticks (shader cycles) per s_memrealtime tick (100 MHz), over ~50 us of
+// one spinning wave.  d_out2[0] = shader cycles, d_out2[1] = 10 ns ticks.  (DVFS moves in milliseconds: launched right behind a workload
+// this reads the clock the workload ran at -- bench.py records it so that a profiled and an un-profiled pass can be compared.)
+int ntk_debug_sclk(unsigned long long* d_out2, void* stream) {
+    if (!d_out2) return NTK_E_NULL;
+    hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, resolve_stream(stream), d_out2);
     return last_launch_status();
 }
 int ntk_advance_pos(int* d_pos, void* stream) {

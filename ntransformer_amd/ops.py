@@ -267,3 +267,13 @@ def argmax(logits, n, d_out_token, scratch, h_mirror=None, stream=None):
 
 def advance_pos(d_pos, stream=None):
     check(_lib.lib().ntk_advance_pos(_p(d_pos), stream), "advance_pos")
+
+
+def sclk_mhz(stream=None) -> float:
+    """ntk_debug_sclk: the shader clock right now, MHz (one wave spinning for ~50 us; blocking)"""
+    import numpy as np
+    b = DeviceBuffer.zeros(24)
+    check(_lib.lib().ntk_debug_sclk(_p(b), stream), "sclk probe")
+    synchronize(stream)
+    v = b.numpy(np.uint64)
+    return 100.0 * float(v[0]) / max(float(v[1]), 1.0)

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: builder-run (NT_RUN_SLOW=1): minutes of CPU oracle on a full-size model")
 
 
 def pytest_sessionstart(session):

@@ -110,11 +110,18 @@ def _teacher_stream(m, prompt, fed, perturb_seed=None, rel=6e-8):
     return np.stack(out)
 
 
-def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=None, flip_scale=1.0, abs_scale=1.0, kv_scale=1.0):
+def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=None, flip_scale=1.0, abs_scale=1.0, kv_scale=1.0,
+                  layerwise_prompt=True, end_to_end=True, engine_cache=False):
     """flip_scale: factor on the two bars that contain F16 rounding flips (layer vs oracle, end to end) and abs_scale: on the absolute
     logit bar of the forced arbiter, kv_scale: on the excess of a stored half over rounding -- 1 for the seeded models; a model built
     to amplify (outlier channels) states its factors.  The per-layer bar against the arbiter forced to the engine's roundings (5e-5 of
-    the layer output's RMS) never scales."""
+    the layer output's RMS) never scales.
+    layerwise_prompt=False: the prompt step is not judged layer by layer (a long prompt: the oracle's cache rows of its positions are
+    written into the engine's cache instead, nt_engine_debug_kv_write) -- the decode steps behind it are.  end_to_end=False: part (a)
+    only (the float64 arbiter end to end costs several oracle passes over the whole stream).  engine_cache=True: a second layer-wise
+    pass over the decode steps in which the cache rows of ALL earlier positions are the ENGINE's own (its batched prompt pass wrote the
+    prompt's, its decode steps the rest) and the arbiter is forced to exactly those rows: the layer arithmetic over a long engine-written
+    cache, not over the oracle's."""
     spec = E.synth_spec(preset, mix, layers=layers)
     path = os.path.join(_scratch_dir(), "_depth_%s.gguf" % tag)
     E.synth_write_gguf(path, spec)
@@ -156,6 +163,10 @@ def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=N
         for toks, start, tr in steps:
             T = len(toks)
             lo, hi = start * per, (start + T) * per
+            if T > 1 and not layerwise_prompt:   # the decode steps see the ORACLE's rows at the prompt's positions
+                for l in range(layers):
+                    eng.kv_write(l, start, m.k_cache[l][lo:hi].reshape(T, per), m.v_cache[l][lo:hi].reshape(T, per))
+                continue
             # (mode of debug_run_layers, batched_prefill): prompt = the reference's per-token loop and the batched GEMM; decode = the
             # reference's 15-launch sequence, the fused launches, the fused launches replayed from a hipGraph
             modes = [("reference", 0, 0), ("launchers", 0, 1)] if T > 1 else [("launchers", 0, 1), ("fused", 1, 1), ("graph", 2, 1)]
@@ -188,7 +199,43 @@ def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=N
                               "within_5e-5_of_oracle": bool(worst["vs_oracle"] <= 5e-5), "max_kv_excess_rel": worst["kv"],
                               "half_roundings_differing_from_oracle": flips_layer, "per_mode": per_mode,
                               "seconds": round(time.perf_counter() - t0, 2)}
-
+        if engine_cache:
+            # ---- (a') the same decode steps over a cache the ENGINE wrote: prompt rows from its own prompt pass, later rows from its own
+            #      decode steps; activations still teacher-forced (the oracle's input to every layer) ----------------------------------
+            t0 = time.perf_counter()
+            worst2, per_mode2 = {"vs_arbiter": 0.0, "kv": 0.0}, {}
+            for name, dbg_mode in (("launchers", 0), ("fused", 1), ("graph", 2)):
+                eng = E.Engine()
+                eng.load(path, ctx)
+                eng.forward(prompt, 0)                                   # the engine's batched prompt pass fills every layer's rows
+                for toks, start, tr in steps[1:]:
+                    lo, hi = start * per, (start + 1) * per
+                    for l in range(layers):
+                        h_in, h_ref = tr["layer_in"][l], tr["layer_out"][l]
+                        rms = float(np.sqrt((h_ref.astype(np.float64) ** 2).mean()))
+                        pk, pv = eng.kv_read(l, 0, start, per)           # what the engine holds at the earlier positions
+                        got = eng.debug_run_layers(h_in, start, l, 1, dbg_mode)
+                        assert np.isfinite(got).all(), (tag, "engine cache", name, l)
+                        rk, rv = eng.kv_read(l, start, 1, per)
+                        past_k, past_v = m.k_cache[l].copy(), m.v_cache[l].copy()
+                        past_k[:lo], past_v[:lo] = pk.reshape(-1), pv.reshape(-1)
+                        a = A.ArbiterModel.__new__(A.ArbiterModel)
+                        a.om, a.kv_report = m, []
+                        a.k_cache, a.v_cache = {l: past_k}, {l: past_v}
+                        arb_out = a.layer(l, h_in.astype(np.float64), start, (rk.reshape(-1), rv.reshape(-1)))
+                        exkv = max(r_["max_excess_over_row_rms"] for r_ in a.kv_report)
+                        e_arb = float(np.abs(got - arb_out).max()) / rms
+                        worst2["vs_arbiter"] = max(worst2["vs_arbiter"], e_arb)
+                        worst2["kv"] = max(worst2["kv"], exkv)
+                        per_mode2[name] = max(per_mode2.get(name, 0.0), e_arb)
+                        assert e_arb <= LAYER_BAR_ARBITER, (tag, "engine cache", name, "layer", l, "pos", start, e_arb)
+                        assert exkv <= KV_BAR * kv_scale, (tag, "engine cache", name, "layer", l, "pos", start, exkv)
+                eng.close()
+            rec["a_layerwise_engine_cache"] = {"max_rel_err_vs_forced_arbiter": worst2["vs_arbiter"], "max_kv_excess_rel": worst2["kv"],
+                                               "per_mode": per_mode2, "seconds": round(time.perf_counter() - t0, 2)}
+        if not end_to_end:
+            rec["passed"] = True
+            return
         # ---- (b) + (c) end to end ----------------------------------------------------------------------------------------------
         t0 = time.perf_counter()
         fedall = fed
@@ -289,6 +336,27 @@ def test_depth_70b_width_16_layers(mix):
     """BASELINE configs 4 / 5 at their real width (H 8192, FFN 28672, 64 / 8 heads), 16 of the 80 layers: load_layer
     (transformer.cpp:286-328) over the Q5_K attn_v / Q6_K ffn_down mix well beyond the first two layers."""
     _depth_parity("70b_width_16_layers_" + mix.lower(), "70b", mix, 16, 18, 3)
+
+
+def test_depth_8b_q8_0_layerwise_behind_a_704_token_prompt():
+    """Layer-wise teacher forcing in the LONG-CONTEXT regime (reference attention.cu:108-202 over hundreds of cache rows): 8B width,
+    8 layers, a 704-token prompt run once by the oracle, its cache rows written into the engine (nt_engine_debug_kv_write), then 4
+    decode steps at positions 704..707 -- beyond the switch to the split-KV attention at 672 (Model::attention_regime) -- each layer,
+    in each launch mode (1:1 launchers, fused, hipGraph), against the arbiter forced to the engine's own roundings of the rows it
+    writes, at the pinned 5e-5 of the layer RMS, and those rows against half an ulp + 2e-5.  Then the same steps once more over a cache
+    the ENGINE wrote itself -- 704 rows per layer from its batched prompt pass, the rest from its own decode steps -- with the arbiter
+    forced to those rows: no engine-level long-context claim rests on a comparison of the engine with itself."""
+    _depth_parity("8b_q8_0_8_layers_pos704", "8b", "Q8_0", 8, 704, 4, ctx=1024, layerwise_prompt=False, end_to_end=False, engine_cache=True)
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get("NT_RUN_SLOW") != "1", reason="builder-run: a 42 GB model, minutes of CPU oracle (NT_RUN_SLOW=1); logged to profiles/r04_parity_depth_70b_80_layers.jsonl")
+def test_depth_70b_q4_k_m_all_80_layers_layerwise():
+    """BASELINE config 4 at its REAL depth: all 80 layers of the 70B Q4_K_M mix -- load_layer (transformer.cpp:286-328) over the whole
+    `use_more_bits` pattern of attn_v (Q6_K / Q5_K) and ffn_down (Q6_K / Q4_K), which a 16-layer model does not reproduce -- layer-wise
+    part (a) only: a 4-token prompt and 2 decode steps, every layer in every launch mode against the forced arbiter (5e-5) and its cache
+    rows (half an ulp + 2e-5)."""
+    _depth_parity("70b_q4_k_m_80_layers", "70b", "Q4_K_M", 80, 4, 2, end_to_end=False)
 
 
 def test_depth_8b_q4_k_m_outlier_channels():
