@@ -22,6 +22,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the library is built with -fvisibility=hidden: exactly what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -200,10 +204,12 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale, int nsplit,
                                float* scratch, void* stream);
 
-/* Tuning knob: Q4_K / Q6_K launches of at least this many weight bytes (default 48 MiB) take the integer-activation form of the GEMV
- * (three int8 digit planes per 32-column sub-block on v_dot4: csrc/gemv_core.hip.h XInt).  0 = every eligible launch (the parity
- * tests), SIZE_MAX = never. */
-void     ntk_gemv_tune_xi_min_bytes(size_t bytes);
+/* Parity instrumentation: ntk_gemv_fused with the activation form of its Q4_K / Q6_K launches chosen by the CALL.  Those launches take,
+ * from 48 MiB of weights on (a constant of the library: below it the conversion costs what the decode saves), the integer-activation
+ * decoders of csrc/gemv_core.hip.h (three int8 digit planes per 32-column sub-block on v_dot4).  integer_activations = 1: whenever the
+ * launch is eligible, 0: never, -1: the size rule -- so that the tests reach both decoders at small sizes.  No global state. */
+int ntk_debug_gemv_fused_form(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                              const float* resid, int silu_pair, int integer_activations, void* stream);
 
 /* Tensor-parallel exchange (csrc/tp.hip): hidden[0..n) += sum over ranks of their partial vectors, in rank
  * order, by one kernel that reads the peers' communication buffers (mapped with ntk_ipc_open or shared in-process) -- no RCCL
@@ -291,5 +297,8 @@ int ntk_advance_pos(int* d_pos, void* stream);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* NTK_H */

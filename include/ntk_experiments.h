@@ -8,6 +8,10 @@
 #ifndef NTK_EXPERIMENTS_H
 #define NTK_EXPERIMENTS_H
 #include "ntk.h"
+/* the library is built with -fvisibility=hidden: exactly what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -66,5 +70,8 @@ int  ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int c
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* NTK_EXPERIMENTS_H */

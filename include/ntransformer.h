@@ -12,6 +12,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the library is built with -fvisibility=hidden: exactly what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -140,5 +144,8 @@ int   nt_sampler_uniforms(uint64_t seed, int n, float* out);
 
 #ifdef __cplusplus
 }
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif
 #endif /* NTRANSFORMER_H */

@@ -85,6 +85,7 @@ def lib() -> C.CDLL:
         "ntk_copy": (i, [vp, vp, i, vp]),
         "ntk_cosine_similarity": (i, [vp, vp, vp, i, vp]),
         "ntk_gemv_fused": (i, [C.POINTER(GemvSeg), i, vp, i, vp, f, vp, i, vp]),
+        "ntk_debug_gemv_fused_form": (i, [C.POINTER(GemvSeg), i, vp, i, vp, f, vp, i, i, vp]),
         "ntk_rp_bytes": (sz, [i, i, i]),
         "ntk_rp_pack": (i, [vp, vp, i, i, i, vp]),
         "ntk_rp_dequant": (i, [vp, vp, i, i, i, vp]),

@@ -640,8 +640,8 @@ static int launch_attention(float* out, const float* Q, const void* kc, const vo
     const bool aligned = (reinterpret_cast<uintptr_t>(kc) & 15) == 0 && (reinterpret_cast<uintptr_t>(vc) & 15) == 0;
     const uint16_t* k16 = static_cast<const uint16_t*>(kc);
     const uint16_t* v16 = static_cast<const uint16_t*>(vc);
-    static const bool tiled_off = [] { const char* e = getenv("NTK_PREFILL_ATTENTION_1TO1"); return e && atoi(e) != 0; }();
-    static const bool mfma_off = [] { const char* e = getenv("NTK_PREFILL_ATTENTION_NO_MFMA"); return e && atoi(e) != 0; }();
+    static const bool tiled_off = NTK_TUNE_ENV_INT("NTK_PREFILL_ATTENTION_1TO1", 0) != 0;      // (tuning builds only: the older prompt kernels)
+    static const bool mfma_off = NTK_TUNE_ENV_INT("NTK_PREFILL_ATTENTION_NO_MFMA", 0) != 0;
     if (causal && T > 1 && aligned && hd == 128 && !tiled_off && !mfma_off) {   // prompt, head_dim 128: F16 matrix cores (attention_mfma.hip)
         const int rc = launch_attention_prefill_mfma(out, Q, k16, v16, T, n_keys_base, nh, nkv, hd, scale, st);
         if (rc != NTK_E_SHAPE && rc != NTK_E_ALIGN) return rc;

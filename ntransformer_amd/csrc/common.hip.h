@@ -12,6 +12,15 @@
         if (e__ != hipSuccess) return NTK_E_LAUNCH;         \
     } while (0)
 
+// Tuning switches exist in tuning builds only (make tune: -DNTK_TUNE -> libntransformer_hip_tune.so, used by tools/*_bench.py and by the
+// tests that force a kernel form); the shipping library has the measured constants and reads no environment variable but NTK_DEVICE.
+#ifdef NTK_TUNE
+#include <cstdlib>
+#define NTK_TUNE_ENV_INT(name, dflt) ([] { const char* e__ = getenv(name); return e__ ? atoi(e__) : (dflt); }())
+#else
+#define NTK_TUNE_ENV_INT(name, dflt) (dflt)
+#endif
+
 namespace ntk {
 
 hipStream_t resolve_stream(void* s);   // runtime.cpp: NULL -> compute stream

@@ -127,8 +127,12 @@ int Engine::run(std::vector<int>& tokens, const GenerateConfig& cfg, std::string
         ++stats_.gen_tokens;
         if (!emit(next)) break;
     }
-    if (opt_.fused) { const int sr = model_.sync(); if (rc == NTK_OK) rc = sr; }   // (a discarded run-ahead step may still be in flight)
+    // the loop's wall time, as the reference counts it (engine.cpp:102-134): up to the last token the host saw.  A run-ahead step queued
+    // behind what turned out to be the end (EOS, the callback, the token budget) is drained AFTER the clock stops: it decoded no counted
+    // token.  (After run() the device position and the KV cache may therefore be one step past the returned tokens; every run re-bases
+    // both -- set_device_pos -- before it decodes.)
     stats_.decode_ms = ms_since(d0);
+    if (opt_.fused) { const int sr = model_.sync(); if (rc == NTK_OK) rc = sr; }
     if (rc == NTK_OK && opt_.fused) rc = model_.check_persistent();
     if (rc != NTK_OK) err_ = std::string("decode failed: ") + ntk_status_string(rc);
     return rc;

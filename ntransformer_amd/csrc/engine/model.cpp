@@ -306,6 +306,7 @@ int Model::finish_load(int /*max_context*/) {
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
     if (repack_) NT_TRY(repack_all());
+    if (persistent_wanted_) set_persistent(true);
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
     fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights%s)\nFree VRAM: %.1f GB\n",
@@ -387,8 +388,6 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
         for (const auto& sh : shapes) gemm_ws_bytes_ = std::max(gemm_ws_bytes_, ntk_gemm_quant_workspace_bytes(sh[0], sh[1]));
     }
     gemm_ws_ = dev(gemm_ws_bytes_, false);
-    if (const char* e = getenv("NTK_BF16_PREFILL")) bf16_prefill_ = atoi(e) != 0;
-    if (const char* e = getenv("NTK_FUSE_ATTENTION")) fuse_attention_ = atoi(e) != 0;
     if (tp_world_ > 1) {   // communication buffer: flags + two slots of one prompt's worth of hidden vectors
         tp_max_floats_ = S * H;
         tp_comm_ = ntk_tp_comm_alloc(ntk_tp_comm_bytes(tp_max_floats_));   // fine-grained: csrc/tp.hip
@@ -699,13 +698,19 @@ int Model::wait_token(int pos, int* token) {
     for (unsigned spins = 0;; ++spins) {
         const unsigned long long v = *slot;
         if ((unsigned)(v >> 32) == want) { *token = (int)(unsigned)v; return NTK_OK; }
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
         if ((spins & 0xFFFFu) == 0xFFFFu) {
             const auto now = std::chrono::steady_clock::now();
             if (spins == 0xFFFFu) wait_t0_ = now;
             else if (std::chrono::duration<double>(now - wait_t0_).count() > 2.0) break;
         }
     }
+    static bool warned = false;
+    if (!warned) { warned = true; fprintf(stderr, "warning: the pinned token ring was not seen updating for 2 s (host memory not coherent with a running kernel?); falling back to a stream synchronisation per token\n"); }
     NT_TRY(ntk_stream_synchronize(stream_));
     const unsigned long long v = *slot;
     if ((unsigned)(v >> 32) != want) { err_ = "decode step finished without publishing its token"; return NTK_E_LAUNCH; }
@@ -946,6 +951,10 @@ bool Model::use_persistent_now() const {
 
 void Model::set_persistent(bool on) {
     persistent_on_ = false;
+    persistent_wanted_ = on;   // (asked before the load: finish_load() applies it)
+#ifndef NTK_EXPERIMENTS
+    if (on) fprintf(stderr, "note: the persistent token kernel is an EXPERIMENTS=1 build option (libntransformer_hip_exp.so); this library decodes with fused launches\n");
+#endif
     if (!on || tp_world_ != 1 || layers_.empty()) return;
     if (!persistent_plan_) (void)build_persistent_plan();   // built on first use (EXPERIMENTS=1 builds only): it allocates device memory
     persistent_on_ = persistent_plan_ != nullptr;

@@ -200,6 +200,7 @@ private:
     ModelConfig cfg_full_;           // the unsliced configuration (cfg_ holds the local head / FFN counts)
     void* persistent_plan_ = nullptr;
     bool persistent_on_ = false;   // opt-in until it beats the launch path on the bench (set_persistent / "persistent" option)
+    bool persistent_wanted_ = false;   // the option as last set (re-applied after a load)
 };
 
 }  // namespace nt

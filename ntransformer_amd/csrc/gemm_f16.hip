@@ -963,13 +963,13 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     }
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
     // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) while fewer than one workgroup per CU exists.
-    static const int map8 = [] { const char* e = getenv("NTK_GEMM_MAP"); return e ? atoi(e) : 1; }();
+    static const int map8 = NTK_TUNE_ENV_INT("NTK_GEMM_MAP", 1);   // (tuning builds only)
     p.map8 = map8;
-    static const int force_rt = [] { const char* e = getenv("NTK_GEMM_RT"); return e ? atoi(e) : 0; }();
+    static const int force_rt = NTK_TUNE_ENV_INT("NTK_GEMM_RT", 0);   // (tuning builds only)
     // K is split (in whole trips) until every CU has two workgroups -- from 4 chunks (193 tokens) on; below that one per CU: the partial
     // sums of many splits cost more than the idle half buys (same box, 8B Q8_0: 256 tokens 16 370 -> 17 000 tok/s, 512 19 830 -> 20 950;
     // 64 tokens 8 090 -> 7 570 with the same rule, which is why it stops there)
-    static const int want_env = [] { const char* e = getenv("NTK_GEMM_WGS"); return e ? atoi(e) : 0; }();
+    static const int want_env = NTK_TUNE_ENV_INT("NTK_GEMM_WGS", 0);   // (tuning builds only)
     const int want_wgs = want_env ? want_env : (p.chunks >= 4 ? 512 : 256);
     int rt = out_total >= 2048 ? 2 : 1;
     if (force_rt == 1 || force_rt == 2) rt = force_rt;
@@ -988,8 +988,8 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     // AL: every row starts on a dword boundary, so that the decoders' LDS dword reads are aligned (Q8_0 / Q4_0: in a multiple of 64, Q6_K: of
     // 512 -- every projection of the target models; other row pitches take the same kernel with 2-byte aligned reads, slower)
     const bool al = row_bytes % DeqI<DT>::ROW_ALIGN == 0;
-    static const int no_pf = [] { const char* e = getenv("NTK_GEMM_NO_PF"); return e ? atoi(e) : 0; }();
-    static const int force_cw = [] { const char* e = getenv("NTK_GEMM_CW"); return e ? atoi(e) : 0; }();
+    static const int no_pf = NTK_TUNE_ENV_INT("NTK_GEMM_NO_PF", 0);   // (tuning builds only)
+    static const int force_cw = NTK_TUNE_ENV_INT("NTK_GEMM_CW", 0);   // (tuning builds only)
     constexpr bool PFD = DeqI<DT>::PF, CW2_OK = !DeqI<DT>::SPLIT16 && DT != NTK_DT_Q5_K;   // (Q5_K: 15 registers over the budget in that form)
     // K splits of a plan with `groups` workgroup columns: doubled while the grid is short of `want_wgs`, whole trips, and
     // splits x 64-token chunks within the partial-sum area (gb_split_rows)

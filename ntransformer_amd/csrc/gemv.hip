@@ -47,15 +47,11 @@ namespace ntk {
 struct AttnFuse {};             // (the ATT instantiations exist in EXPERIMENTS=1 builds only)
 #endif
 
-template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false, bool XI = false, bool DMA = false>
+template <int DT, bool NORM, bool XFAST, bool A16, bool ATT = false, bool XI = false>
 __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int bid, const int nblk, const AttnFuse* attp = nullptr) {   // workgroup bid of nblk
     using F = Fmt<DT>;
     constexpr int NL = F::NL;
-    // DMA form (rows of one column slice, fast prologue): the wave's staging area is a ring of NB row slots filled by LDS-DMA
-    static_assert(!DMA || (XFAST && !ATT && DMA_OK<DT>), "DMA form: fast prologue, K-quants");
-    constexpr int NB = DMA ? F::NBUF : 1;
-    constexpr int SLOT = DMA_SLOT<DT>;
-    constexpr int STAGE = DMA ? NB * SLOT : NL * 1024 + 64;
+    constexpr int STAGE = NL * 1024 + 64;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef NTK_GEMV_TRACE
     unsigned long long gv_t[GT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -178,33 +174,6 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             pf[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + off));
         }
     };
-    // ---- DMA form: ring bookkeeping (all wave-uniform).  vm_issued counts every vector-memory operation of the wave from here on
-    //      (DMA pieces, the residual's DMA, the y stores); d_mark[slot] = its value right after the slot's last DMA piece ----
-    unsigned vm_issued = 0;
-    int d_seg[NB], d_row[NB], d_shift[NB];
-    unsigned d_mark[NB];
-    const uint32_t lds_stage = (uint32_t)(uintptr_t)stage;   // generic -> LDS byte address: the low 32 bits
-    auto dma_issue = [&](const int slot) {   // the item under the cursor -> ring slot `slot`
-        d_seg[slot] = cu_seg; d_row[slot] = cu_row;
-        const unsigned rel = (unsigned)p.seg[cu_seg].delta + (unsigned)cu_row * p.row_bytes + slice_byte0;
-        d_shift[slot] = (int)(rel & 15u);
-        const unsigned last = ((rel & 15u) + slice_bytes - 1u) & ~15u;
-        const uint8_t* a = p.seg[cu_seg].W + (rel & ~15u);
-        const uint32_t dst = lds_stage + (uint32_t)(slot * SLOT);
-        if (p.resid != nullptr) {   // the row's residual travels with it (last 16 bytes of the slot): no register waits for it
-            if (lane == 0) dma4(__builtin_amdgcn_readfirstlane(dst + (uint32_t)(SLOT - 16)), p.resid + cu_row);
-            ++vm_issued;
-        }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            if (1024u * (unsigned)j <= last) {   // uniform: the piece exists (then lane 0 of it does)
-                const unsigned off = 16u * (unsigned)(lane + 64 * j);
-                if (off <= last) dma16(__builtin_amdgcn_readfirstlane(dst + 1024u * (unsigned)j), a + off);
-                ++vm_issued;
-            }
-        }
-        d_mark[slot] = vm_issued;
-    };
     if (n_my <= 0) { cu_seg = 0; cu_row = 0; }   // a wave without rows still prefetches (row 0): keeps the prologue branch-free
 
     // ---- prologue: this lane's 64 activations into registers (through a padded LDS image: coalesced
@@ -267,11 +236,6 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             // asm "uses" them, so the compiler's own wait sits in front of it.
             asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
             if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
-            if constexpr (DMA) {   // rows 0 .. NB-2 of the wave start their way into the ring (LDS-DMA: no registers involved)
-#pragma unroll
-                for (int k = 0; k + 1 < NB; ++k)
-                    if (k < n_my) { if (k > 0) cursor_advance(); dma_issue(k); }
-            } else
             issue();   // unconditional (a wave without rows re-reads row 0)
             GV_STAMP(8);   // first weight row requested
             }
@@ -512,41 +476,6 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
     // Every wave walks its own list of (segment,row) items; the valid ones are a prefix of length n_my.
     // All loads / LDS writes are unpredicated (lanes past the slice end re-read its last chunk) so the loop
     // body is straight-line code: hipcc then waits for the prefetch exactly once, right before the ds_writes.
-    if constexpr (DMA) {
-        // NB - 1 rows are on their way; per row: wait for its pieces (in-order completion: count what was issued after them), start
-        // the row NB - 1 ahead into the slot the previous row has just left, decode from the slot, reduce, store.  Unrolled by NB so
-        // that slot numbers are constants.  p.ns == 1 (host).
-        for (int q0 = 0; q0 < n_my; q0 += NB) {
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int q = q0 + u;
-                if (q >= n_my) break;
-                wait_vm(vm_issued - d_mark[u]);
-                if (q + NB - 1 < n_my) { cursor_advance(); dma_issue((u + NB - 1) % NB); }
-                const uint8_t* st = stage + u * SLOT;
-                const int seg = d_seg[u], row = d_row[u], shift = A16 ? 0 : d_shift[u];
-                float acc;
-                if constexpr (XI && DT == NTK_DT_Q6_K) acc = DotI<DT>::run(st, shift, lane, ncols, xi);
-                else if constexpr (XI) acc = DotI<DT>::run(st, lane, ncols, xi);
-                else acc = Dot<DT, A16>::run(st, shift, lane, ncols, x2, sx16, sx32);
-                const float tot = wave_sum_lane63(acc);   // valid in lane 63
-                if (p.silu_pair) {
-                    if ((q & 1) == 0) { if (lane == 63) gate_carry = tot; }
-                    else {
-                        if (lane == 63) p.seg[0].y[row] = gate_carry / (1.0f + expf(-gate_carry)) * tot;   // reference gemm.cu:719-724
-                        ++vm_issued;
-                    }
-                } else {
-                    if (lane == 63) {
-                        float v = tot;
-                        if (p.resid != nullptr && seg == 0) v = *reinterpret_cast<const float*>(st + SLOT - 16) + v;   // elementwise.cu:23-32
-                        p.seg[seg].y[row] = v;
-                    }
-                    ++vm_issued;
-                }
-            }
-        }
-    } else
     for (int q = 0; q < n_my; ++q) {
         const int seg = pf_seg, row = pf_row, shift = A16 ? 0 : pf_shift;
         const float res = pf_res;
@@ -634,28 +563,17 @@ __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_kernel(const Ge
     gemv_quant_body<DT, NORM, XFAST, A16>(p, (int)blockIdx.x, (int)gridDim.x);
 }
 // integer-activation form (Q4_K, aligned fast prologue, rows of <= 16384 columns): gemv_core.hip.h XInt / DotI
-template <int DT, bool NORM, bool DMA = false>
+template <int DT, bool NORM>
 __global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_xi_kernel(const GemvParams p) {
-    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, true, DMA>(p, (int)blockIdx.x, (int)gridDim.x);
+    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
 }
-#ifdef NTK_EXPERIMENTS
-// LDS-DMA row ring (K-quants, rows of one column slice, aligned fast prologue): float activations
-template <int DT, bool NORM>
-__global__ __launch_bounds__(512, Fmt<DT>::MINW) void gemv_quant_dma_kernel(const GemvParams p) {
-    gemv_quant_body<DT, NORM, true, A16_OK<DT>, false, false, true>(p, (int)blockIdx.x, (int)gridDim.x);
-}
-#else
-template <int DT, bool NORM>
-__global__ void gemv_quant_dma_kernel(const GemvParams) {}   // (never launched: DMA_OK is false)
-#endif
-
 // Two weight formats in ONE launch (llama.cpp's Q4_K_M stores attn_v as Q6_K / Q5_K next to Q4_K attn_q / attn_k): the first
 // `split` workgroups run format A on its segments, the rest format B on its own -- the two halves share nothing but x.  One
 // launch instead of two for the fused norm + Q|K|V projection of those layers (16 of 32 at 8B, all 80 at 70B).
-template <int DTA, int DTB, bool NORM, bool DMA = false>
+template <int DTA, int DTB, bool NORM>
 __global__ __launch_bounds__(512, 4) void gemv_quant_pair_kernel(const GemvParams pa, const GemvParams pb, const int split) {
-    if ((int)blockIdx.x < split) gemv_quant_body<DTA, NORM, true, A16_OK<DTA>, false, false, DMA>(pa, (int)blockIdx.x, split);
-    else gemv_quant_body<DTB, NORM, true, A16_OK<DTB>, false, false, DMA>(pb, (int)blockIdx.x - split, (int)gridDim.x - split);
+    if ((int)blockIdx.x < split) gemv_quant_body<DTA, NORM, true, A16_OK<DTA>>(pa, (int)blockIdx.x, split);
+    else gemv_quant_body<DTB, NORM, true, A16_OK<DTB>>(pb, (int)blockIdx.x - split, (int)gridDim.x - split);
 }
 
 #ifdef NTK_EXPERIMENTS
@@ -718,15 +636,8 @@ struct GemvLaunch {
     int grid, nwaves;
     size_t lds;
     bool xfast, a16;
-    bool dma;          // eligible for the LDS-DMA row ring (K-quants, one column slice, aligned fast prologue)
-    size_t lds_dma;    // ... and its LDS footprint
 };
 
-// NTK_GEMV_DMA=0: the register-prefetch form everywhere (A/B on one build)
-static bool dma_enabled() {
-    static const bool on = [] { const char* e = getenv("NTK_GEMV_DMA"); return !(e && atoi(e) == 0); }();
-    return on;
-}
 static bool raise_lds_limit(const void* fn) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
 }
@@ -766,7 +677,7 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     p.slice_cols = ((in + p.ns - 1) / p.ns + align - 1) / align * align;
     if (p.ns > 8 || (long)(p.ns - 1) * p.slice_cols >= in) return NTK_E_SHAPE;   // in_features > 32768 not supported
     // waves per workgroup = ns * rw ~ 8: one x prologue feeds eight row streams
-    static const int env_waves = [] { const char* e = getenv("NTK_GEMV_WAVES"); return e ? std::max(1, atoi(e)) : 8; }();
+    static const int env_waves = std::max(1, NTK_TUNE_ENV_INT("NTK_GEMV_WAVES", 8));   // (tuning builds only)
     p.rw = std::max(1, env_waves / p.ns);   // (6-wave workgroups for the 3-waves/SIMD formats measured 30 % slower)
     L.nwaves = p.ns * p.rw;
     p.x_vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
@@ -796,22 +707,23 @@ static int prepare_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int
     bool a16 = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K);
     for (int i = 0; i < nseg; ++i) a16 = a16 && p.seg[i].delta == 0;
     L.a16 = a16;
-    L.dma = DMA_OK<DT> && dma_enabled() && L.xfast && p.ns == 1 && a16 == A16_OK<DT> && !(kAblate & 7);
-    L.lds_dma = image_bytes + (size_t)L.nwaves * F::NBUF * DMA_SLOT<DT> + (size_t)(2 * p.rw * p.ns * RB + 16 + 16) * sizeof(float);
     return NTK_OK;
 }
 
-// smallest launch (bytes of weights) that takes the integer-activation form of the Q4_K GEMV; ntk_gemv_tune_xi_min_bytes moves it
-static size_t g_xi_min_bytes = [] { const char* e = getenv("NTK_GEMV_XI_MIN_MB"); return (size_t)(e ? std::max(0, atoi(e)) : 48) << 20; }();
+// smallest launch (bytes of weights) that takes the integer-activation form of the Q4_K / Q6_K GEMV: 48 MiB (measured, section 3.1 of DESIGN.md:
+// below it the conversion in the prologue costs what the decode saves).  A constant of the library; the parity tests reach the form on
+// small launches through the per-call argument of ntk_debug_gemv_fused_form.
+constexpr size_t kXiMinBytes = (size_t)48 << 20;
+enum { XI_DEFAULT = -1, XI_NEVER = 0, XI_ALWAYS = 1 };
 
 static int max_workgroups() {
-    static const int max_wg = [] { const char* e = getenv("NTK_GEMV_MAX_WG"); return e ? std::max(1, atoi(e)) : 512; }();
+    static const int max_wg = std::max(1, NTK_TUNE_ENV_INT("NTK_GEMV_MAX_WG", 512));   // (tuning builds only)
     return max_wg;
 }
 
 template <int DT>
 static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w, float eps,
-                        const float* resid, int silu_pair, hipStream_t st) {
+                        const float* resid, int silu_pair, hipStream_t st, int xi_mode = XI_DEFAULT) {
     GemvLaunch L;
     const int rc = prepare_quant<DT>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, max_workgroups(), L);
     if (rc != NTK_OK) return rc;
@@ -837,7 +749,7 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
 #ifdef NTK_EXPERIMENTS
     if constexpr (DT == NTK_DT_Q8_0) {
         // column-split form (gemv_colsplit.hip.h): rows of exactly 4096 columns, everything 16-byte aligned.  Opt-in: NTK_GEMV_COLSPLIT=1.
-        static const int cs_mode = [] { const char* e = getenv("NTK_GEMV_COLSPLIT"); return e ? atoi(e) : 0; }();
+        static const int cs_mode = NTK_TUNE_ENV_INT("NTK_GEMV_COLSPLIT", 0);
         bool cs = cs_mode != 0 && in == CS_COLS && L.xfast && !(kAblate & 7);
         for (int i = 0; i < nseg && cs; ++i) cs = L.p.seg[i].delta == 0;
         if (cs) {
@@ -861,25 +773,15 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
     L.p.trace_slot = trace_counter++;
 #endif
     if constexpr (DT == NTK_DT_Q4_K || DT == NTK_DT_Q6_K) {
-        static const bool xi_off = [] { const char* e = getenv("NTK_GEMV_NO_XI"); return e && atoi(e) != 0; }();
         // the integer-activation form: registers of the fast prologue cover the row, one image pass
         // ... and only the launches that are VALU-bound gain: long ones (measured, tools/gemv_bench.py: 70B gate|up 53.0 -> 49.1 us,
         // Q4_K LM head 56.6 -> 54.0, 8B gate|up 20.0 -> 17.1-18.8; under ~48 MiB -- 70B Q|K|V, the 8B down projection -- nothing is
         // gained or the conversion in the prologue costs more than the decode saves)
         const size_t launch_bytes = (size_t)L.p.total_rows * (silu_pair ? 2 : 1) * L.p.row_bytes;
-        if (!xi_off && L.xfast && (L.a16 || DT == NTK_DT_Q6_K) && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves && launch_bytes >= g_xi_min_bytes) {
+        const bool want = xi_mode == XI_ALWAYS || (xi_mode == XI_DEFAULT && launch_bytes >= kXiMinBytes);
+        if (want && L.xfast && (L.a16 || DT == NTK_DT_Q6_K) && L.p.ns <= 2 && in <= 8 * 4 * 64 * L.nwaves) {
             using XFn = void (*)(const GemvParams);
             static const XFn xt[2] = {gemv_quant_xi_kernel<DT, false>, gemv_quant_xi_kernel<DT, true>};
-            if constexpr (DMA_OK<DT>) {
-                if (L.dma) {   // integer activations + LDS-DMA row ring
-                    static const XFn xd[2] = {gemv_quant_xi_kernel<DT, false, true>, gemv_quant_xi_kernel<DT, true, true>};
-                    static const bool ok = raise_lds_limit((const void*)xd[0]) && raise_lds_limit((const void*)xd[1]);
-                    if (ok && L.lds_dma <= 160 * 1024) {
-                        hipLaunchKernelGGL(xd[norm_w ? 1 : 0], g, b, L.lds_dma, st, L.p);
-                        return last_launch_status();
-                    }
-                }
-            }
             if (L.lds > 64 * 1024) {
                 static bool once2 = hipFuncSetAttribute((const void*)xt[0], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
                                     hipFuncSetAttribute((const void*)xt[1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
@@ -887,17 +789,6 @@ static int launch_quant(const ntk_gemv_seg* segs, int nseg, const float* x, int 
             }
             hipLaunchKernelGGL(xt[norm_w ? 1 : 0], g, b, L.lds, st, L.p);
             return last_launch_status();
-        }
-    }
-    if constexpr (DMA_OK<DT>) {
-        if (L.dma) {   // LDS-DMA row ring, float activations
-            using DFn = void (*)(const GemvParams);
-            static const DFn dt_[2] = {gemv_quant_dma_kernel<DT, false>, gemv_quant_dma_kernel<DT, true>};
-            static const bool ok = raise_lds_limit((const void*)dt_[0]) && raise_lds_limit((const void*)dt_[1]);
-            if (ok && L.lds_dma <= 160 * 1024) {
-                hipLaunchKernelGGL(dt_[norm_w ? 1 : 0], g, b, L.lds_dma, st, L.p);
-                return last_launch_status();
-            }
         }
     }
     hipLaunchKernelGGL(table[norm_w ? 1 : 0][L.xfast ? 1 : 0][L.a16 ? 1 : 0], g, b, L.lds, st, L.p);
@@ -943,17 +834,6 @@ static int launch_pair(const ntk_gemv_seg* sa, int na, const ntk_gemv_seg* sb, i
     if (!A.xfast || !B.xfast || A.nwaves != B.nwaves || A.a16 != A16_OK<DTA> || B.a16 != A16_OK<DTB>) return NTK_E_ALIGN;
     for (int i = 0; i < na; ++i) if (A.p.seg[i].delta != 0 && A16_OK<DTA>) return NTK_E_ALIGN;
     using PairFn = void (*)(const GemvParams, const GemvParams, int);
-    if constexpr (DMA_OK<DTA> && DMA_OK<DTB>) {
-        if (A.dma && B.dma) {   // both halves on the LDS-DMA row ring
-            static const PairFn td[2] = {gemv_quant_pair_kernel<DTA, DTB, false, true>, gemv_quant_pair_kernel<DTA, DTB, true, true>};
-            static const bool ok = raise_lds_limit((const void*)td[0]) && raise_lds_limit((const void*)td[1]);
-            const size_t ld = std::max(A.lds_dma, B.lds_dma);
-            if (ok && ld <= 160 * 1024) {
-                hipLaunchKernelGGL(td[norm_w ? 1 : 0], dim3(A.grid + B.grid), dim3(64 * A.nwaves), ld, st, A.p, B.p, A.grid);
-                return last_launch_status();
-            }
-        }
-    }
     const size_t lds = std::max(A.lds, B.lds);
     static const PairFn table[2] = {gemv_quant_pair_kernel<DTA, DTB, false>, gemv_quant_pair_kernel<DTA, DTB, true>};
     if (lds > 64 * 1024) {
@@ -966,13 +846,13 @@ static int launch_pair(const ntk_gemv_seg* sa, int na, const ntk_gemv_seg* sb, i
 }
 
 static int dispatch_quant(int dt, const ntk_gemv_seg* segs, int nseg, const float* x, int in, const float* norm_w,
-                          float eps, const float* resid, int silu_pair, hipStream_t st) {
+                          float eps, const float* resid, int silu_pair, hipStream_t st, int xi_mode = XI_DEFAULT) {
     switch (dt) {
         case NTK_DT_Q8_0: return launch_quant<NTK_DT_Q8_0>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
         case NTK_DT_Q4_0: return launch_quant<NTK_DT_Q4_0>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
-        case NTK_DT_Q4_K: return launch_quant<NTK_DT_Q4_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        case NTK_DT_Q4_K: return launch_quant<NTK_DT_Q4_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st, xi_mode);
         case NTK_DT_Q5_K: return launch_quant<NTK_DT_Q5_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
-        case NTK_DT_Q6_K: return launch_quant<NTK_DT_Q6_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st);
+        case NTK_DT_Q6_K: return launch_quant<NTK_DT_Q6_K>(segs, nseg, x, in, norm_w, eps, resid, silu_pair, st, xi_mode);
         default: return NTK_E_DTYPE;
     }
 }
@@ -992,7 +872,6 @@ static int launch_dense(float* y, const void* W, const float* x, int out, int in
 
 extern "C" {
 
-void ntk_gemv_tune_xi_min_bytes(size_t bytes) { ntk::g_xi_min_bytes = bytes; }
 #ifdef NTK_GEMV_TRACE
 int ntk_debug_gemv_trace(unsigned long long* out, size_t n) {   // n <= GT_SLOTS * GT_WG * GT_EV
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemv_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
@@ -1045,8 +924,8 @@ int ntk_attention_gemv_fused(float* attn_out, const float* q, const float* k, co
 }
 #endif
 
-int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
-                   const float* resid, int silu_pair, void* stream) {
+static int gemv_fused_form(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                           const float* resid, int silu_pair, void* stream, int xi_mode) {
     if (!segs || !x) return NTK_E_NULL;
     if (nseg < 1 || nseg > ntk::MAX_SEG) return NTK_E_SHAPE;
     ntk_gemv_seg a[3], b[3];
@@ -1058,7 +937,7 @@ int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_fe
         else return NTK_E_DTYPE;   // three formats in one call
     }
     hipStream_t st = ntk::resolve_stream(stream);
-    if (nb == 0) return ntk::dispatch_quant(segs[0].dtype, segs, nseg, x, in_features, norm_w, eps, resid, silu_pair, st);
+    if (nb == 0) return ntk::dispatch_quant(segs[0].dtype, segs, nseg, x, in_features, norm_w, eps, resid, silu_pair, st, xi_mode);
     // two formats: supported as one launch for the K-quant mixes of llama.cpp's Q4_K_M, plain projections only
     if (resid || silu_pair) return NTK_E_DTYPE;
     const int da = a[0].dtype, db = b[0].dtype;
@@ -1067,6 +946,18 @@ int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_fe
     if (da == NTK_DT_Q4_K && db == NTK_DT_Q5_K) return ntk::launch_pair<NTK_DT_Q4_K, NTK_DT_Q5_K>(a, na, b, nb, x, in_features, norm_w, eps, st);
     if (da == NTK_DT_Q5_K && db == NTK_DT_Q4_K) return ntk::launch_pair<NTK_DT_Q4_K, NTK_DT_Q5_K>(b, nb, a, na, x, in_features, norm_w, eps, st);
     return NTK_E_DTYPE;
+}
+
+int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                   const float* resid, int silu_pair, void* stream) {
+    return gemv_fused_form(segs, nseg, x, in_features, norm_w, eps, resid, silu_pair, stream, ntk::XI_DEFAULT);
+}
+// parity instrumentation: ntk_gemv_fused with the activation form of the Q4_K / Q6_K launches chosen by the CALL (1: the integer-activation
+// decoders whenever the launch is eligible, 0: never, -1: the library's size rule) -- so that the tests reach both decoders at small sizes
+int ntk_debug_gemv_fused_form(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
+                              const float* resid, int silu_pair, int integer_activations, void* stream) {
+    if (integer_activations < -1 || integer_activations > 1) return NTK_E_SHAPE;
+    return gemv_fused_form(segs, nseg, x, in_features, norm_w, eps, resid, silu_pair, stream, integer_activations);
 }
 
 }  // extern "C"

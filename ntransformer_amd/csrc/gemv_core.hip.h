@@ -42,8 +42,7 @@ template <int DT> struct Fmt;
 // BW/BB: weights / bytes per GGUF block; NL: 1 KiB chunks per <=4096-column slice (+15 alignment bytes);
 // MINW: waves per SIMD the register allocator must leave room for (4 -> <=128 VGPRs, 3 -> <=168: the 5/6-bit
 // decoders keep more packed dwords live and would otherwise spill the prefetch registers)
-// NBUF: row slices per wave in the LDS-DMA ring (gemv.hip, DMA form: NBUF - 1 rows in flight beside the one being decoded), sized
-// so that two 8-wave workgroups still fit a CU's 160 KB (image 17 KB + 8 x NBUF x slice)
+// NBUF: row slices per wave of an LDS-DMA ring (EXPERIMENTS=1 builds: the persistent token kernel)
 template <> struct Fmt<NTK_DT_Q8_0> { static constexpr int BW = 32, BB = 34, NL = 5, MINW = 4, NBUF = 1; };
 template <> struct Fmt<NTK_DT_Q4_0> { static constexpr int BW = 32, BB = 18, NL = 3, MINW = 4, NBUF = 3; };
 template <> struct Fmt<NTK_DT_Q4_K> { static constexpr int BW = 256, BB = 144, NL = 3, MINW = 4, NBUF = 3; };
@@ -51,16 +50,10 @@ template <> struct Fmt<NTK_DT_Q5_K> { static constexpr int BW = 256, BB = 176, N
 template <> struct Fmt<NTK_DT_Q6_K> { static constexpr int BW = 256, BB = 210, NL = 4, MINW = 4, NBUF = 2; };
 // bytes of one ring slot: a <= 4096-column slice + its alignment shift, rounded to 16, + 16 (the row's residual value)
 template <int DT> constexpr int DMA_SLOT = ((4096 / Fmt<DT>::BW * Fmt<DT>::BB + 30) / 16) * 16 + 16;
-// Formats that have the DMA form.  EXPERIMENTS=1 builds only: measured in round 3 (profiles/r03_gemv_lds_dma_ring_experiment.txt), two
-// or three row slices in flight per wave instead of one change NOTHING -- Q4_K gate|up 16.7 -> 16.3 us, LM head 52.8 -> 52.7, 70B
-// gate|up 48.7 -> 49.1, 8B Q4_K_M decode 632 -> 629 tok/s, 70B 104.3 -> 104.7: the long K-quant launches are bound by VALU issue (84 % of
-// the SIMD's issue slots, profiles/r02_kquant_valu_experiments.txt), not by bytes in flight.  Correct (all GEMV parity tests ran on
-// it), kept as an opt-in record beside the persistent kernel and the attention-in-Wo launch.
-#ifdef NTK_EXPERIMENTS
-template <int DT> constexpr bool DMA_OK = (DT == NTK_DT_Q4_K || DT == NTK_DT_Q5_K || DT == NTK_DT_Q6_K);
-#else
-template <int DT> constexpr bool DMA_OK = false;
-#endif
+// (Round 3 also built the row stream of gemv.hip on such a ring -- two or three row slices in flight per wave instead of one -- and measured
+// NOTHING: Q4_K gate|up 16.7 -> 16.3 us, LM head 52.8 -> 52.7, 70B gate|up 48.7 -> 49.1 (profiles/r03_gemv_lds_dma_ring_experiment.txt):
+// the long K-quant launches were bound by VALU issue, not by bytes in flight.  That form was removed in round 4, when the matrix-core
+// GEMV of gemv_rp.hip took the K-quant launches of the engine.)
 
 // ---- LDS-DMA: up to 1 KiB per wave instruction straight from HBM into the wave's ring slot (no VGPR bounce, no ds_write) ----
 // lds_dst: wave-uniform LDS byte address the wave's lane 0 writes (lane l writes lds_dst + 16 l / 4 l); gsrc: this lane's source.

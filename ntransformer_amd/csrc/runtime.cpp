@@ -173,6 +173,10 @@ void nt_hip_memset(void* p, int v, size_t n) { if (n) (void)hipMemset(p, v, n); 
 void* nt_hip_malloc_host(size_t size) {
     if (ensure_ready() != NTK_OK) return nullptr;
     void* p = nullptr;
+    // coherent (fine-grained): the engine polls pinned words a RUNNING kernel writes (Model::wait_token); a non-coherent mapping would only
+    // show them at the kernel's end
+    if (hipHostMalloc(&p, size ? size : 1, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) return p;
+    (void)hipGetLastError();
     return hipHostMalloc(&p, size ? size : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
 }
 void nt_hip_free_host(void* p) { if (p) (void)hipHostFree(p); }

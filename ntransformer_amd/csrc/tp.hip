@@ -94,8 +94,7 @@ size_t ntk_tp_comm_bytes(size_t max_floats) { return TP_HDR + 2 * ((max_floats +
 // NTK_TP_COARSE=1; freed with nt_hip_free
 void* ntk_tp_comm_alloc(size_t bytes) {
     void* p = nullptr;
-    const char* coarse = getenv("NTK_TP_COARSE");
-    if (!(coarse && atoi(coarse) != 0)) {
+    if (NTK_TUNE_ENV_INT("NTK_TP_COARSE", 0) == 0) {   // (tuning builds: ordinary device memory, for an A/B on real multi-GPU hardware)
         if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) == hipSuccess && p) return p;
         (void)hipGetLastError();
         p = nullptr;

@@ -157,13 +157,19 @@ def launch_cosine_similarity(result, a, b, size, stream=None):
 
 
 # ---- engine-level fused operators -----------------------------------------------------------------------
-def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resid=None, silu_pair=False, stream=None):
-    """segs: [(W, y, rows, dtype), ...] (<= 3, same dtype)."""
+def gemv_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resid=None, silu_pair=False, stream=None,
+               integer_activations=None):
+    """segs: [(W, y, rows, dtype), ...] (<= 3, same dtype).  integer_activations (True / False): ntk_debug_gemv_fused_form, the
+    activation form of the Q4_K / Q6_K launches chosen by the call instead of by the library's size rule."""
     arr = (GemvSeg * len(segs))()
     for i, (W, y, rows, dt) in enumerate(segs):
         arr[i].W, arr[i].y, arr[i].rows, arr[i].dtype = _p(W), _p(y), rows, int(dt)
-    check(_lib.lib().ntk_gemv_fused(arr, len(segs), _p(x), in_features, _p(norm_w), eps, _p(resid), int(silu_pair),
-                                    stream), "gemv_fused")
+    if integer_activations is None:
+        check(_lib.lib().ntk_gemv_fused(arr, len(segs), _p(x), in_features, _p(norm_w), eps, _p(resid), int(silu_pair),
+                                        stream), "gemv_fused")
+    else:
+        check(_lib.lib().ntk_debug_gemv_fused_form(arr, len(segs), _p(x), in_features, _p(norm_w), eps, _p(resid), int(silu_pair),
+                                                   1 if integer_activations else 0, stream), "gemv_fused_form")
 
 
 def rp_bytes(dtype, rows, in_features) -> int:

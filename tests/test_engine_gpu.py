@@ -390,12 +390,16 @@ def test_device_sampling_gives_the_host_samplers_token_stream(cfg, tmp_path):
 @pytest.mark.parametrize("switch", ["NTK_GEMM_CW=2", "NTK_GEMM_CW=1", "NTK_GEMM_NO_PF=1", "NTK_GEMM_MAP=0", "NTK_GEMM_WGS=4096"])
 def test_prompt_gemm_forms_behind_the_tuning_switches_keep_parity(switch):
     """The prompt GEMM (csrc/gemm_f16.hip) picks among forms by launch size: one or two 64-token chunks per workgroup, the plane
-    prefetch, the (row tile, chunk) order per XCD, the K split.  The switches that force each form (read once per process) must give
-    the same parity: every FP16-GEMM kernel test and the engine's prompt tests, in a subprocess per switch."""
+    prefetch, the (row tile, chunk) order per XCD, the K split.  The switches that force each form exist in the TUNING build of the
+    library only (make tune: libntransformer_hip_tune.so reads them once per process; the shipping library has none); each must give the
+    same parity: every FP16-GEMM kernel test and the engine's prompt tests, in a subprocess per switch on that library."""
     import subprocess
     import sys
+    tune = os.path.join(os.path.dirname(E.__file__), "libntransformer_hip_tune.so")
+    if not os.path.exists(tune):
+        pytest.skip("libntransformer_hip_tune.so not built (make -C ntransformer_amd/csrc tune)")
     k, v = switch.split("=")
-    env = dict(os.environ, **{k: v})
+    env = dict(os.environ, NTK_LIB_PATH=tune, **{k: v})
     here = os.path.dirname(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_hip_kernels.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "gemm_quant_f16"], env=env, capture_output=True, text=True, timeout=900)

@@ -407,14 +407,10 @@ def test_gemv_fused_norm_qkv(qname, in_f, rows):
                                                        (1024, 8192, True, False, True), (96, 2048, False, False, True), (40, 8192, False, True, False)])
 def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu, outliers):
     """The integer-activation form of the Q4_K / Q6_K GEMV (activations as three int8 digit planes per 32-column sub-block, products on
-    v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 48 MiB -- forced for every eligible launch and
+    v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 48 MiB -- asked for by the call (ntk_debug_gemv_fused_form) and
     compared with the oracle at the GEMV's tolerance: plain, RMSNorm prologue, residual epilogue, gate|up + SiLU.  `outliers`: a few
     channels 1000 x the rest, the shape real Llama activations have and the synthetic ones lack (no checkpoint exists offline): the
     31 neighbours of an outlier in its sub-block keep 2^-23 of the OUTLIER as their error, which is what the form trades."""
-    from ntransformer_amd import _lib
-    L = _lib.lib()
-    L.ntk_gemv_tune_xi_min_bytes.argtypes = [C.c_size_t]
-    L.ntk_gemv_tune_xi_min_bytes.restype = None
     gt = QUANT[qname]
     dt = G.GGML_TO_DT[gt]
     r = rng(out_f + in_f + 3 * norm + 5 * resid + 7 * silu + gt)
@@ -430,17 +426,14 @@ def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu, out
         up = O.gemv(W2, xin, out_f, in_f, dt)
         ref = (ref / (1.0 + np.exp(-ref.astype(np.float64))) * up).astype(np.float32)
     if resid: ref = ref + R
-    L.ntk_gemv_tune_xi_min_bytes(0)
-    try:
-        xd, nwd = DB.from_numpy(x), DB.from_numpy(nw)
-        yd = DB.from_numpy(R.copy() if resid else np.full(out_f, np.nan, np.float32))
-        y2 = DB.zeros(out_f * 4)
-        Wd, W2d = DB.from_numpy(W), DB.from_numpy(W2)
-        segs = [(Wd, yd, out_f, dt)] + ([(W2d, y2, out_f, dt)] if silu else [])
-        ops.gemv_fused(segs, xd, in_f, norm_w=nwd if norm else None, eps=1e-5, resid=yd if resid else None, silu_pair=silu)
-        got = yd.numpy()
-    finally:
-        L.ntk_gemv_tune_xi_min_bytes(48 << 20)
+    xd, nwd = DB.from_numpy(x), DB.from_numpy(nw)
+    yd = DB.from_numpy(R.copy() if resid else np.full(out_f, np.nan, np.float32))
+    y2 = DB.zeros(out_f * 4)
+    Wd, W2d = DB.from_numpy(W), DB.from_numpy(W2)
+    segs = [(Wd, yd, out_f, dt)] + ([(W2d, y2, out_f, dt)] if silu else [])
+    ops.gemv_fused(segs, xd, in_f, norm_w=nwd if norm else None, eps=1e-5, resid=yd if resid else None, silu_pair=silu,
+                   integer_activations=True)   # (the form chosen by the call: ntk_debug_gemv_fused_form)
+    got = yd.numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() <= tol_for(ref, in_f) * (4 if silu else 1), np.abs(got - ref).max()
 
@@ -506,15 +499,9 @@ def test_gemv_fused_norm_gate_up_silu(qname, in_f, inter):
     ops.synchronize()
     assert np.abs(od.numpy() - ref).max() <= 4 * tol_for(ref, in_f)
     if qname in ("Q4_K", "Q6_K") and inter >= 6144:   # ... and through the integer-activation decoders (every eligible launch)
-        from ntransformer_amd import _lib
-        L = _lib.lib()
-        L.ntk_gemv_tune_xi_min_bytes(0)
-        try:
-            od2 = DB.from_numpy(np.full(inter, np.nan, np.float32))
-            ops.gemv_fused([(gd, od2, inter, dt), (ud, scratch, inter, dt)], xd, in_f, norm_w=nd, eps=1e-5, silu_pair=True)
-            ops.synchronize()
-        finally:
-            L.ntk_gemv_tune_xi_min_bytes(48 << 20)
+        od2 = DB.from_numpy(np.full(inter, np.nan, np.float32))
+        ops.gemv_fused([(gd, od2, inter, dt), (ud, scratch, inter, dt)], xd, in_f, norm_w=nd, eps=1e-5, silu_pair=True, integer_activations=True)
+        ops.synchronize()
         assert np.abs(od2.numpy() - ref).max() <= 4 * tol_for(ref, in_f)
 
 

@@ -362,13 +362,14 @@ def test_depth_70b_q4_k_m_all_80_layers_layerwise():
 def test_depth_8b_q4_k_m_outlier_channels():
     """Real Llama activations have a few channels hundreds of times larger than the rest; the seeded synthetic tensors do not (no
     checkpoint exists offline).  This model gets them: eight channels of every RMSNorm weight vector (F32 tensors of the GGUF) x 60, so
-    that the inputs of every Q|K|V, gate|up and LM-head launch carry outliers -- with the integer-activation GEMV forced for every
-    eligible launch (its block-floating digit planes are what outliers stress) and the prompt through the two-piece FP16 GEMM.  8B
+    that the inputs of every Q|K|V, gate|up and LM-head launch carry outliers.  Since round 4 every K-quant launch of the fused decode
+    path is the matrix-core GEMV over the engine's repack (csrc/gemv_rp.hip): digit planes with ONE exponent per 256-column super-block --
+    exactly what outliers stress (the 255 neighbours of an outlier keep 2^-23 of the OUTLIER as their error) -- and the prompt goes through
+    the two-piece FP16 GEMM.  8B
     width, Q4_K_M mix, 6 layers, the same bars as the other depth tests.  (End to end such a model amplifies F16 rounding flips --
     0.017 of a logit RMS of 5 with or without the integer form, same box -- which is why it is judged layer by layer and against the
     arbiter, like the others.)"""
-    import ctypes as C
-    from ntransformer_amd import _lib, gguf as G
+    from ntransformer_amd import gguf as G
     chans = [5, 77, 1033, 2047, 2500, 3001, 3333, 4000]
 
     def patch(path):
@@ -383,16 +384,9 @@ def test_depth_8b_q4_k_m_outlier_channels():
                     v = np.frombuffer(fh.read(4), np.float32)[0]
                     fh.seek(base + 4 * c)
                     fh.write(np.float32(v * 60.0).tobytes())
-    L = _lib.lib()
-    L.ntk_gemv_tune_xi_min_bytes.argtypes = [C.c_size_t]
-    L.ntk_gemv_tune_xi_min_bytes.restype = None
-    L.ntk_gemv_tune_xi_min_bytes(0)
-    try:
-        # The model is adversarial for F32 itself: the ORACLE (the reference's arithmetic) sits 2.0e-4 from the float64 arbiter forced
-        # to its own roundings here, 20 x its distance on the seeded models, and a flipped half moves a layer output 6e-4 of its RMS
-        # against 1e-4.  Hence flip_scale 6; abs_scale 10 (the forced-arbiter bar on logits is the north star's 1e-3 itself, not a
-        # tenth of it); kv_scale 5.  Observed (profiles/r03_parity_outlier_channels.txt): per layer 2.1e-5 of the RMS with the integer
-        # form forced (7e-6 without), logits 3.0e-4 / 7.8e-5 from the forced arbiter, the FP16 prompt GEMM 2.2e-4.
-        _depth_parity("8b_q4_k_m_outlier_channels_6_layers", "8b", "Q4_K_M", 6, 20, 3, patch=patch, flip_scale=6.0, abs_scale=10.0, kv_scale=5.0)
-    finally:
-        L.ntk_gemv_tune_xi_min_bytes(48 << 20)
+    # The model is adversarial for F32 itself: the ORACLE (the reference's arithmetic) sits 2.0e-4 from the float64 arbiter forced
+    # to its own roundings here, 20 x its distance on the seeded models, and a flipped half moves a layer output 6e-4 of its RMS
+    # against 1e-4.  Hence flip_scale 6; abs_scale 10 (the forced-arbiter bar on logits is the north star's 1e-3 itself, not a
+    # tenth of it); kv_scale 5.  Round 3 (integer form of gemv.hip forced, 32-column exponents): per layer 2.1e-5 of the RMS (7e-6 with
+    # float activations), logits 3.0e-4 / 7.8e-5 from the forced arbiter, the FP16 prompt GEMM 2.2e-4 (profiles/r03_parity_outlier_channels.txt).
+    _depth_parity("8b_q4_k_m_outlier_channels_6_layers", "8b", "Q4_K_M", 6, 20, 3, patch=patch, flip_scale=6.0, abs_scale=10.0, kv_scale=5.0)

@@ -4,13 +4,18 @@ global_load_dwordx4 and read by inline-asm ds_write_b128, with explicit s_waitcn
 are asynchronous, so the build is only correct if NO compiler-generated instruction reads or copies those registers.  This script
 compiles the kernel to ISA and checks, per instantiation, that every VGPR written by a ring load appears in no other instruction
 than ring loads and the ds_write_b128 that consume them.
-usage: python tools/check_gemm_isa.py   (exit code 1 on a violation)"""
-import os, re, subprocess, sys, tempfile
+usage: python tools/check_gemm_isa.py [--hipcc HIPCC] [--flags "HIPFLAGS"]   (exit code 1 on a violation)
+The Makefile runs it on the exact compiler and flags of every build of the library (shipping, trace, tuning, experiments)."""
+import argparse, hashlib, os, re, shlex, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--hipcc", default="/opt/rocm/bin/hipcc")
+ap.add_argument("--flags", default="--offload-arch=gfx950 -O3 -std=c++17 -fPIC")
+a = ap.parse_args()
 src = os.path.join(ROOT, "ntransformer_amd", "csrc", "gemm_f16.hip")
-out = os.path.join(tempfile.gettempdir(), "gemm_f16_check.s")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", src, "-o", out],
-                      cwd=tempfile.gettempdir(), stderr=subprocess.DEVNULL)
+flags = [f for f in shlex.split(a.flags) if f not in ("-c",)]
+out = os.path.join(tempfile.gettempdir(), "gemm_f16_check_%s.s" % hashlib.sha1(a.flags.encode()).hexdigest()[:8])
+subprocess.check_call([a.hipcc] + flags + ["-S", "--cuda-device-only", src, "-o", out], cwd=tempfile.gettempdir(), stderr=subprocess.DEVNULL)
 txt = open(out).read()
 bad = 0
 def regs(tok):
