@@ -196,9 +196,15 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     pos += warmup
     elapsed, _, out = timed(lambda k: eng.decode_greedy_steps(tok, pos, k), steps)
     pos_end = pos + steps
-    try:   # the shader clock right behind the timed region (DVFS moves in milliseconds): lets a profiled pass be compared with an un-profiled one
+    sclk = None
+    try:   # the average shader clock of the same workload, over 32 more steps right behind the timed region (a one-wave kernel beside them on
+        # another stream: ntk_debug_sclk_begin / _end): lets a profiled pass be compared with an un-profiled one
         from ntransformer_amd import ops as _ops
-        sclk = round(_ops.sclk_mhz(), 1)
+        if pos_end + 32 <= args.ctx and out:
+            with _ops.SclkSpan() as c:
+                eng.decode_greedy_steps(out[-1], pos_end, 32)
+                sync()
+            sclk = round(c.mhz, 1) if c.mhz else None
     except Exception:
         sclk = None
     res = {"spec": spec, "elapsed": elapsed, "pos": pos, "pos_end": pos_end, "t_load": t_load, "sclk_mhz": sclk,

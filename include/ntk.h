@@ -291,6 +291,12 @@ int ntk_argmax_advance(const float* logits, int n, int* d_out_token, int* h_mirr
 /* measurement instrumentation: the shader clock right now.  d_out2 (DEVICE, 3 x 8 bytes): [0] shader cycles (s_memtime) and [1] 10 ns ticks
  * (s_memrealtime) over ~50 us of one spinning wave: MHz = 100 * [0] / [1].  bench.py records it right behind the timed region. */
 int ntk_debug_sclk(unsigned long long* d_out2, void* stream);
+/* ... and the AVERAGE shader clock over a span of work: _begin starts a one-wave kernel on `side_stream` (a stream other than the workload's,
+ * e.g. ntk_stream(1)) that sleeps and polls until _end raises d_flag (4 DEVICE bytes) through `other_stream` (e.g. ntk_stream(2)), or 3 s
+ * pass; after synchronising side_stream, d_out2 = {shader cycles, 10 ns ticks} of the span.  bench.py runs it over extra decode steps right
+ * behind the timed region (never inside it). */
+int ntk_debug_sclk_begin(unsigned* d_flag, unsigned long long* d_out2, void* side_stream);
+int ntk_debug_sclk_end(unsigned* d_flag, void* other_stream);
 
 /* *d_pos += 1 (one thread); keeps positions on the device across graph replays */
 int ntk_advance_pos(int* d_pos, void* stream);

@@ -101,6 +101,8 @@ def lib() -> C.CDLL:
         "ntk_argmax": (i, [vp, i, vp, vp, vp, vp]),
         "ntk_advance_pos": (i, [vp, vp]),
         "ntk_debug_sclk": (i, [vp, vp]),
+        "ntk_debug_sclk_begin": (i, [vp, vp, vp]),
+        "ntk_debug_sclk_end": (i, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here = the .so does not export what include/ntk.h declares

@@ -26,6 +26,37 @@ __device__ __forceinline__ void unpack8(const u32x4 r, float (&f)[8]) {
     f[6] = h2f((uint16_t)(r.w & 0xFFFF)); f[7] = h2f((uint16_t)(r.w >> 16));
 }
 
+// acc[0..7] += (the eight halves of r) * p, one v_fma_mix_f32 each: the instruction converts its F16 operand on the fly (exactly: the same
+// bits as v_cvt_f32_f16 + v_fma_f32).  hipcc folds the conversion of the K rows into it by itself but turns the P.V update into v_cvt +
+// v_pk_fma_f32 -- 1.5 issue slots per product (a packed FMA costs two, tools/probes/mfma_valu_probe.hip) against 1 here.  One asm block
+// per position, behind an s_nop: p comes straight out of v_exp_f32, and a VALU instruction that reads a transcendental's result needs a
+// wait state the compiler supplies for its own instructions but cannot supply inside opaque asm (without it the first product of every
+// position read the PREVIOUS p in the lanes the quarter-rate v_exp had not written yet: found by the parity tests).
+#ifdef NTK_ATTN_NO_ASM
+__device__ __forceinline__ void pv_update(float (&acc)[8], const u32x4 r, const float p) {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[2 * i] = fmaf(p, h2f((uint16_t)(w[i] & 0xFFFFu)), acc[2 * i]);
+        acc[2 * i + 1] = fmaf(p, h2f((uint16_t)(w[i] >> 16)), acc[2 * i + 1]);
+    }
+}
+#else
+__device__ __forceinline__ void pv_update(float (&acc)[8], const u32x4 r, const float p) {
+    asm("s_nop 1\n\t"
+        "v_fma_mix_f32 %0, %8, %12, %0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %8, %12, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %9, %12, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %9, %12, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %10, %12, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %10, %12, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %6, %11, %12, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %7, %11, %12, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "v"(p));
+}
+#endif
+
 // rotation of one (x0, x1) pair, reference rotary.cu:46-60
 __device__ __forceinline__ void rope_pair(float& x0, float& x1, int pos, int pair_idx, int head_dim, float theta, float fscale) {
     // powf evaluated in double and rounded once: reproduces a correctly-rounded powf (what IEEE libm gives the
@@ -271,12 +302,19 @@ __device__ __forceinline__ void attention_decode_walk(
     }
 
     // (after the loads RoPE waits for: a CU serves its requests roughly in order)
+    // Rows are addressed by 32-bit byte offsets inside the layer's cache (max_seq * row bytes < 4 GiB: host-checked), advanced by a constant
+    // per batch and clamped to the last row: an add and a min per row where the 64-bit form spent a quarter-rate multiply and a 64-bit
+    // multiply-add (36 of the walk's ~250 issue slots per batch of 4 positions).
+    const unsigned row_bytes = (unsigned)stride * 2u, off_max = (unsigned)pmax * row_bytes, adv = (unsigned)(stepG * D) * row_bytes;
+    const char* kb = reinterpret_cast<const char*>(kbase);
+    const char* vb = reinterpret_cast<const char*>(vbase);
+    unsigned roff[D];
     u32x4 kraw[D], vraw[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        const size_t row = (size_t)min(first + g + stepG * d, pmax) * stride;
-        kraw[d] = *reinterpret_cast<const u32x4*>(kbase + row);
-        vraw[d] = *reinterpret_cast<const u32x4*>(vbase + row);
+        roff[d] = min((unsigned)(first + g + stepG * d) * row_bytes, off_max);
+        kraw[d] = *reinterpret_cast<const u32x4*>(kb + roff[d]);
+        vraw[d] = *reinterpret_cast<const u32x4*>(vb + roff[d]);
     }
     const int pos = *d_pos;
     const size_t cache_row = (size_t)pos * stride + (size_t)kv_head * hd;
@@ -322,7 +360,8 @@ __device__ __forceinline__ void attention_decode_walk(
     // ~15-instruction expf: the walk is bound by its VALU work (one wave per SIMD), 75 -> 45 instructions per position and head
     // (round 3; measured: 8 rows in flight or 8-wave workgroups instead changed nothing, profiles/r03_attention_kv_head_form.txt).
     // Invalid positions (past the token, or a clamped row) are exact no-ops.
-    auto batch = [&](const float (*kf)[8], const float (*vf)[8], const bool* valid, const int np) {
+    // MASKED = false: every one of the np positions exists (all batches but the last): no selects.  V stays packed (two halves per dword).
+    auto batch = [&](const float (*kf)[8], const u32x4* vr, const bool* valid, const int np, const bool masked) {
         float sc[D];
         float mn = m;
 #pragma unroll
@@ -332,7 +371,7 @@ __device__ __forceinline__ void attention_decode_walk(
 #pragma unroll
             for (int j = 0; j < 8; ++j) t = fmaf(qreg[j], kf[d][j], t);
             t = group_sum<LPR>(t) * scale;
-            sc[d] = valid[d] ? t : EMPTY;
+            sc[d] = (!masked || valid[d]) ? t : EMPTY;
             mn = fmaxf(mn, sc[d]);
         }
         const float a = __expf(m - mn);
@@ -342,43 +381,51 @@ __device__ __forceinline__ void attention_decode_walk(
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (d >= np) continue;
-            const float pw = valid[d] ? __expf(sc[d] - mn) : 0.0f;
+            const float pw = (!masked || valid[d]) ? __expf(sc[d] - mn) : 0.0f;
             l += pw;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(pw, vf[d][j], acc[j]);
+            pv_update(acc, vr[d], pw);
         }
         m = mn;
     };
-    for (int base = first; base < pos; base += stepG * D) {   // uniform trip count
-        float kf[D][8], vf[D][8];
+    auto walk_batch = [&](const int base, const bool masked) {
+        float kf[D][8];
+        u32x4 vr[D];
         bool valid[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             valid[d] = base + g + stepG * d < pos;
-            u32x4 vr = vraw[d];
-            if (!valid[d]) vr = u32x4{0u, 0u, 0u, 0u};   // rows past the position hold anything (0 * NaN)
+            vr[d] = vraw[d];
+            if (masked && !valid[d]) vr[d] = u32x4{0u, 0u, 0u, 0u};   // rows past the position hold anything (0 * NaN)
             unpack8(kraw[d], kf[d]);
-            unpack8(vr, vf[d]);
         }
         __builtin_amdgcn_sched_barrier(0);   // the ring registers are free: the next batch may land in them
         if (base + stepG * D < pos) {   // uniform: another batch follows
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const size_t row = (size_t)min(base + stepG * D + g + stepG * d, pmax) * stride;
-                kraw[d] = *reinterpret_cast<const u32x4*>(kbase + row);
-                vraw[d] = *reinterpret_cast<const u32x4*>(vbase + row);
+                roff[d] = min(roff[d] + adv, off_max);
+                kraw[d] = *reinterpret_cast<const u32x4*>(kb + roff[d]);
+                vraw[d] = *reinterpret_cast<const u32x4*>(vb + roff[d]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        batch(kf, vf, valid, D);
-    }
+        batch(kf, vr, valid, D, masked);
+    };
+    int base = first;
+    for (; base + stepG * (D - 1) + G <= pos; base += stepG * D) walk_batch(base, false);   // whole batches: every position of every group exists
+    if (base < pos) walk_batch(base, true);                                                  // (uniform) the last one, masked
     {   // the token being decoded: from LDS (another workgroup is writing its cache row), by the group whose turn it is
-        float kf[D][8], vf[D][8];
+        float kf[D][8];
+        u32x4 vr[D];
         bool valid[D];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { kf[0][j] = kx[8 * part_i + j]; vf[0][j] = vx[8 * part_i + j]; }
+        for (int j = 0; j < 8; ++j) kf[0][j] = kx[8 * part_i + j];
+        {   // vx holds the value rounded through half: its half bits again (exact)
+            const float* vxp = vx + 8 * part_i;
+            vr[0].x = (uint32_t)f2h(vxp[0]) | ((uint32_t)f2h(vxp[1]) << 16); vr[0].y = (uint32_t)f2h(vxp[2]) | ((uint32_t)f2h(vxp[3]) << 16);
+            vr[0].z = (uint32_t)f2h(vxp[4]) | ((uint32_t)f2h(vxp[5]) << 16); vr[0].w = (uint32_t)f2h(vxp[6]) | ((uint32_t)f2h(vxp[7]) << 16);
+        }
         valid[0] = first + g == pos % stepG;
-        batch(kf, vf, valid, 1);
+        batch(kf, vr, valid, 1, true);
     }
     if (part_i == 0) { ms[g] = m; ls[g] = l; }
 #pragma unroll
@@ -451,17 +498,35 @@ __global__ __launch_bounds__(256) void attention_decode_split_kernel(
 
 __global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __restrict__ output, const float* __restrict__ part,
                                                                       int hd, int nsplit) {
-    const int head = blockIdx.x;
+    // One workgroup per head.  Every memory round trip is taken ONCE for all splits: thread s fetches split s's (m, l); the weights
+    // exp(m_s - M) go through LDS; the sum over splits of a thread's output element runs in split order with its loads issued eight at a
+    // time.  (Round 3's form walked the splits in two rolled loops -- a dependent L2 round trip per split and loop: 0.35 us per split, 2.8 us
+    // of the 8-split launch pair and the reason 16 splits lost to 8 at every context; profiles/r03_attention_by_context.txt.)
+    __shared__ float wsh[1024], lsh[1024];
+    const int head = blockIdx.x, tid = threadIdx.x;
     const float* ph = part + (size_t)head * nsplit * (hd + 2);
+    for (int s0 = tid; s0 < nsplit; s0 += blockDim.x) {
+        const float* ps = ph + (size_t)s0 * (hd + 2);
+        wsh[s0] = ps[hd];
+        lsh[s0] = ps[hd + 1];
+    }
+    __syncthreads();
     float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, ph[(size_t)s * (hd + 2) + hd]);
-    for (int d = threadIdx.x; d < hd; d += blockDim.x) {
-        float L = 0.0f, o = 0.0f;
-        for (int s = 0; s < nsplit; ++s) {
-            const float* ps = ph + (size_t)s * (hd + 2);
-            const float w = (ps[hd] == -INFINITY) ? 0.0f : expf(ps[hd] - M);
-            L = fmaf(w, ps[hd + 1], L);
-            o = fmaf(w, ps[d], o);
+    for (int s0 = 0; s0 < nsplit; ++s0) M = fmaxf(M, wsh[s0]);
+    __syncthreads();
+    for (int s0 = tid; s0 < nsplit; s0 += blockDim.x) wsh[s0] = (wsh[s0] == -INFINITY) ? 0.0f : expf(wsh[s0] - M);
+    __syncthreads();
+    float L = 0.0f;
+    for (int s0 = 0; s0 < nsplit; ++s0) L = fmaf(wsh[s0], lsh[s0], L);   // split order, like the output sums
+    for (int d = tid; d < hd; d += blockDim.x) {
+        float o = 0.0f;
+        for (int s0 = 0; s0 < nsplit; s0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = ph[(size_t)min(s0 + u, nsplit - 1) * (hd + 2) + d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) o = fmaf(wsh[s0 + u], v[u], o);
         }
         output[(size_t)head * hd + d] = o / L;
     }
@@ -730,6 +795,7 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
     if (!output || !q || !k || !v || !k_cache || !v_cache || !d_pos) return NTK_E_NULL;
     if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || head_dim <= 0 || (head_dim & 1) || max_seq <= 0)
         return NTK_E_SHAPE;
+    if ((size_t)max_seq * n_kv_heads * head_dim * 2 >= 0xF0000000ull) return NTK_E_SHAPE;   // (32-bit row offsets inside one layer's cache)
     hipStream_t st = ntk::resolve_stream(stream);
     const bool aligned = (reinterpret_cast<uintptr_t>(k_cache) & 15) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 15) == 0;
     uint16_t* k16 = static_cast<uint16_t*>(k_cache);
@@ -766,6 +832,7 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || max_seq <= 0 || nsplit < 1 || nsplit > 1024)
         return NTK_E_SHAPE;
     if (head_dim != 128 && head_dim != 64 && head_dim != 256) return NTK_E_SHAPE;   // 16-byte row pieces: the engine falls back to the single pass otherwise
+    if ((size_t)max_seq * n_kv_heads * head_dim * 2 >= 0xF0000000ull) return NTK_E_SHAPE;   // (32-bit row offsets inside one layer's cache)
     if ((reinterpret_cast<uintptr_t>(k_cache) & 15) || (reinterpret_cast<uintptr_t>(v_cache) & 15)) return NTK_E_ALIGN;
     hipStream_t st = ntk::resolve_stream(stream);
     uint16_t* k16 = static_cast<uint16_t*>(k_cache);
@@ -774,7 +841,9 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
 #define NTK_ATTSP(...) hipLaunchKernelGGL((ntk::attention_decode_split_kernel<__VA_ARGS__>), dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \
                                            v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
-    if (head_dim == 128) NTK_ATTSP(16, 4);
+    static const int split_d = NTK_TUNE_ENV_INT("NTK_ATTN_SPLIT_D", 4);   // (tuning builds: rows in flight per position group)
+    if (head_dim == 128 && split_d == 8) NTK_ATTSP(16, 8);
+    else if (head_dim == 128) NTK_ATTSP(16, 4);
     else if (head_dim == 64) NTK_ATTSP(8, 4);
     else NTK_ATTSP(32, 4);
 #undef NTK_ATTSP

@@ -185,6 +185,20 @@ __global__ __launch_bounds__(64) void sclk_probe_kernel(unsigned long long* out)
     if (acc == 12345.678f) out[2] = 0;   // (keeps the spin's arithmetic alive; never true)
 }
 
+// One wave that lives as long as a workload running beside it (another stream) and reports the shader cycles and 10 ns ticks of its
+// lifetime: the AVERAGE shader clock the workload ran at.  Sleeps between polls of the stop flag; gives up after 3 s by itself.
+__global__ __launch_bounds__(64) void sclk_span_kernel(const unsigned* flag, unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    for (;;) {
+        __builtin_amdgcn_s_sleep(64);
+        r1 = __builtin_amdgcn_s_memrealtime();
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u || r1 - r0 > 300000000ull) break;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+}
+
 // stage 2 of the greedy tail of a token (ntk_argmax_advance): final arg-max, the token to the device word and to the pinned host ring
 // -- slot (position & 3), ONE 8-byte store {token, position + 1}: the host can poll it while the next token's launches are already
 // queued, and a token that runs one ahead cannot overwrite what the host has not read yet -- and the position advanced, in one launch
@@ -332,6 +346,20 @@ int ntk_debug_sclk(unsigned long long* d_out2, void* stream) {
     if (!d_out2) return NTK_E_NULL;
     hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, resolve_stream(stream), d_out2);
     return last_launch_status();
+}
+// ... and over a span: _begin starts a one-wave kernel on `side_stream` (NOT the stream of the workload) that runs until _end raises the flag
+// (or 3 s pass); afterwards, with `side_stream` synchronised, d_out2 = {shader cycles, 10 ns ticks} of that span.  d_flag: 4 device bytes.
+int ntk_debug_sclk_begin(unsigned* d_flag, unsigned long long* d_out2, void* side_stream) {
+    if (!d_flag || !d_out2 || !side_stream) return NTK_E_NULL;
+    hipStream_t st = static_cast<hipStream_t>(side_stream);
+    if (hipMemsetAsync(d_flag, 0, 4, st) != hipSuccess) return NTK_E_LAUNCH;
+    hipLaunchKernelGGL(sclk_span_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)d_flag, d_out2);
+    return last_launch_status();
+}
+int ntk_debug_sclk_end(unsigned* d_flag, void* other_stream) {
+    if (!d_flag || !other_stream) return NTK_E_NULL;
+    static const unsigned one = 1u;
+    return hipMemcpyAsync(d_flag, &one, 4, hipMemcpyHostToDevice, static_cast<hipStream_t>(other_stream)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
 }
 int ntk_advance_pos(int* d_pos, void* stream) {
     if (!d_pos) return NTK_E_NULL;

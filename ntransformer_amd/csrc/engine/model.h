@@ -50,12 +50,12 @@ public:
     int decode_step_fused(bool greedy, bool use_graph);
     int set_device_token(int token);
     int set_device_pos(int pos);
-    // attention regime by context length: the single-pass kernel walks a head's cache serially (49 us per layer at 4095),
-    // so long contexts split each head over 8 / 16 workgroups (ntk_attention_decode_split)
-    // (measured, tools/attn_bench.py, round 3 after the batched softmax update: single pass 6.2 us at 255 / 8.4 at 512 / 12.9 at 1024 /
-    //  38.9 at 4095; 8 splits 9.5 / 9.6 / 10.5 / 14.3: the lines cross near position 675; 16 splits only pay beyond the 4096-token
-    //  contexts this engine caps at)
-    static int attention_regime(int pos) { return pos < 672 ? 0 : pos < 8192 ? 1 : 2; }
+    // attention regime by context length: the single-pass kernel walks a head's cache serially (30.7 us per layer at 4095), so long
+    // contexts split each head over 8 workgroups + a combine launch (ntk_attention_decode_split)
+    // (measured, tools/attn_bench.py, round 4 -- 32-bit row offsets, masks only in the last batch, P.V on v_fma_mix_f32, combine with
+    //  one round trip for all splits: single pass 4.5 us at 128 / 6.4 at 320 / 7.5 at 512 / 10.9 at 1024 / 30.7 at 4095; 8 splits
+    //  7.65 at 512 / 8.4 at 1024 / 9.6 at 2048 / 11.5 at 4095: the lines cross near 540 (672 in round 3); 16 splits 12.4 at 4095)
+    static int attention_regime(int pos) { return pos < 544 ? 0 : pos < 16384 ? 1 : 2; }
     void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)

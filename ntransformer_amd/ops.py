@@ -283,3 +283,26 @@ def sclk_mhz(stream=None) -> float:
     synchronize(stream)
     v = b.numpy(np.uint64)
     return 100.0 * float(v[0]) / max(float(v[1]), 1.0)
+
+
+class SclkSpan:
+    """with SclkSpan() as c: <work on the compute stream, synchronised before the block ends> ; c.mhz = the average shader clock of the
+    span (ntk_debug_sclk_begin / _end: a one-wave kernel beside the work, on the library's second stream)"""
+
+    def __enter__(self):
+        L = _lib.lib()
+        self.flag, self.out = DeviceBuffer.zeros(8), DeviceBuffer.zeros(24)
+        self.mhz = None
+        check(L.ntk_debug_sclk_begin(_p(self.flag), _p(self.out), L.ntk_stream(1)), "sclk begin")
+        return self
+
+    def __exit__(self, *exc):
+        import numpy as np
+        L = _lib.lib()
+        check(L.ntk_debug_sclk_end(_p(self.flag), L.ntk_stream(2)), "sclk end")
+        check(L.ntk_stream_synchronize(L.ntk_stream(2)), "sync")
+        check(L.ntk_stream_synchronize(L.ntk_stream(1)), "sync")
+        v = self.out.numpy(np.uint64)
+        if v[1] > 0:
+            self.mhz = 100.0 * float(v[0]) / float(v[1])
+        return False

@@ -169,15 +169,15 @@ def test_batched_prefill_fills_the_same_kv_cache(mix, tmp_path):
 
 
 def test_long_context_decode_uses_split_attention_and_matches_the_oracle(tmp_path):
-    """Decode at positions 668..678 crosses the engine's attention regimes (single pass -> 8 KV splits at 672,
-    Model::attention_regime) and 1020..1030 runs well inside the split regime.  Every mode -- the reference's 1:1 launcher
+    """Decode at positions 540..550 crosses the engine's attention regimes (single pass -> 8 KV splits at 544,
+    Model::attention_regime), 668..678 and 1020..1030 run inside the split regime.  Every mode -- the reference's 1:1 launcher
     sequence, the fused launches, the fused launches replayed from a hipGraph -- is held to the ORACLE (reference
     attention.cu:108-202 over a cache of hundreds of rows, transformer.cpp:604-669), teacher-forced on one token stream, at the
     north-star tolerance; the modes' agreement with each other is a corollary, not the test."""
     path, z = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)   # head_dim 128, GQA 4, context 2048
     r = np.random.Generator(np.random.Philox(key=[20260925, 777]))
     observed = {}
-    for start in (668, 1020):
+    for start in (540, 668, 1020):
         prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, start - 1)]
         cont = [int(t) for t in r.integers(0, 256, 10)]
         m = O.OracleModel(path, 2048)

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--tp", type=int, default=0, help="ranks (only with --share-gpu; under torch.distributed.run it is WORLD_SIZE)")
+    ap.add_argument("--gpus", type=int, default=0, help="accepted for the driver's command line (bench.py's flag): the rank count is WORLD_SIZE")
     ap.add_argument("--share-gpu", action="store_true")
     a = ap.parse_args()
     out = {}
@@ -94,11 +95,15 @@ def main():
         dist.all_gather(gathered, mine)
         same = all(bool((g == gathered[0]).all()) for g in gathered)
         errs = [out[0][2]]
-    if rank == 0:
-        print(json.dumps({"metric": "decode tokens/sec, one sequence over %d tensor-parallel ranks (%s %s)" % (world, a.model, a.mix),
+    if rank == 0:   # one line in bench.py's format: `python -m torch.distributed.run --nproc-per-node N ... tools/tp_bench.py --gpus N --steps K --warmup W`
+        print(json.dumps({"metric": "decode tokens/sec, ONE sequence over %d tensor-parallel ranks (%s %s, resident, greedy, batch 1)" % (world, a.model, a.mix),
                           "value": round(a.steps / elapsed, 3), "unit": "tokens/s", "n_gpus": 1 if a.share_gpu else world, "tp": world,
-                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4), "scaling": "strong",
-                          "ranks_share_one_gpu": bool(a.share_gpu), "token_streams_identical": same, "tp_error": errs}), flush=True)
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "Llama-3.1-%s-shaped %s, %d-token prompt, greedy decode, every rank holds 1/%d of each projection "
+                                                 "(csrc/tp.hip: two peer-read all-reduces of the hidden vector per layer)" % (a.model.upper(), a.mix, a.prompt_len, world),
+                                     "ctx": a.ctx, "parallelism": "tp%d" % world, "ranks_share_one_gpu": bool(a.share_gpu)},
+                          "token_streams_identical": same, "tp_error": errs}), flush=True)
 
 
 if __name__ == "__main__":
