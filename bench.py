@@ -371,7 +371,7 @@ def _pmc_traffic(model, mix):
     key = "%s_%s" % (model, mix.lower())
     try:
         d = json.load(open(path))[key]
-        g = d.get("ntk::gemv_quant_*") or d["ntk::gemv_quant_kernel"]   # all forms of the GEMV pooled (tools/pmc_summary.py)
+        g = d.get("ntk::gemv_quant_*") or d["ntk::gemv_quant_kernel"]   # all forms of the GEMV pooled, rp_gemv_kernel included (tools/pmc_summary.py)
         return int(g["fetch_bytes_per_launch"] + g["write_bytes_per_launch_raw"]), "profiles/pmc_traffic.json[%s]" % key
     except Exception:
         return None, None

@@ -14,6 +14,7 @@
 
 // Tuning switches exist in tuning builds only (make tune: -DNTK_TUNE -> libntransformer_hip_tune.so, used by tools/*_bench.py and by the
 // tests that force a kernel form); the shipping library has the measured constants and reads no environment variable but NTK_DEVICE.
+#define NTK_EXTRA_API extern "C" __attribute__((visibility("default")))   // entry points of tuning / trace builds (not in include/*.h)
 #ifdef NTK_TUNE
 #include <cstdlib>
 #define NTK_TUNE_ENV_INT(name, dflt) ([] { const char* e__ = getenv(name); return e__ ? atoi(e__) : (dflt); }())

@@ -1060,10 +1060,10 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
 extern "C" {
 
 #ifdef NTK_GEMM_TRACE
-int ntk_debug_gemm_f16_trace(unsigned long long* out, size_t n) {   // n <= 4 * GBT_STEPS * GBT_EV
+__attribute__((visibility("default"))) int ntk_debug_gemm_f16_trace(unsigned long long* out, size_t n) {   // n <= 4 * GBT_STEPS * GBT_EV
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemm_f16_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
-int ntk_debug_gemm_f16_clock(unsigned long long* out) {   // 4 values
+__attribute__((visibility("default"))) int ntk_debug_gemm_f16_clock(unsigned long long* out) {   // 4 values
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemm_f16_clock), 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif

@@ -873,7 +873,7 @@ static int launch_dense(float* y, const void* W, const float* x, int out, int in
 extern "C" {
 
 #ifdef NTK_GEMV_TRACE
-int ntk_debug_gemv_trace(unsigned long long* out, size_t n) {   // n <= GT_SLOTS * GT_WG * GT_EV
+NTK_EXTRA_API int ntk_debug_gemv_trace(unsigned long long* out, size_t n) {   // n <= GT_SLOTS * GT_WG * GT_EV
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_gemv_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
 }
 #endif

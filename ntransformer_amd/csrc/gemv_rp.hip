@@ -753,9 +753,9 @@ int ntk_gemv_rp(float* y, const void* rp, const float* x, int out_features, int 
 
 #ifdef NTK_TUNE
 // tuning builds (make tune): waves per workgroup / workgroups per CU of every rp launch, 0 = the planner's choice
-void ntk_tune_rp_plan(int nw, int per_cu) { ntk::g_rp_force_nw = nw; ntk::g_rp_force_per_cu = per_cu; }
-void ntk_tune_rp_waves(int nw) { ntk_tune_rp_plan(nw, 0); }
-void ntk_tune_rp_last_plan(int* out3) { out3[0] = ntk::g_rp_last_nw; out3[1] = ntk::g_rp_last_grid; out3[2] = ntk::g_rp_last_lds; }
+NTK_EXTRA_API void ntk_tune_rp_plan(int nw, int per_cu) { ntk::g_rp_force_nw = nw; ntk::g_rp_force_per_cu = per_cu; }
+NTK_EXTRA_API void ntk_tune_rp_waves(int nw) { ntk_tune_rp_plan(nw, 0); }
+NTK_EXTRA_API void ntk_tune_rp_last_plan(int* out3) { out3[0] = ntk::g_rp_last_nw; out3[1] = ntk::g_rp_last_grid; out3[2] = ntk::g_rp_last_lds; }
 #endif
 
 int ntk_debug_rp_prologue(uint8_t* out, const float* x, const float* norm_w, float eps, int in_features, int nsub, int nwaves, void* stream) {

@@ -5,15 +5,13 @@ lives here and not under tests/).  What it asserts:
   * each committed bench line's own numbers are mutually consistent: value == n_gpus * steps / time, roofline.frac == achieved / peak,
     hbm_fraction_of_8TBs_end_to_end == bytes x rate / peak, vs_baseline == value / 48.9 and vs_baseline_per_gpu == vs_baseline / n_gpus;
   * for every workload that has a same-commit trio in profiles/ (r0N_bench_<key>.json, r0N_rocprofv3_kernel_trace_<key>.txt,
-    pmc_traffic.json[<key>]): the trace's kernel time per token does not exceed the un-profiled line's ms_per_step by more than the
-    profiling slack below, the pooled GEMV rate recomputed from the trace agrees with the bench line's live HIP-event figure within
-    12 % either way (events read high: they contain the boundaries inside a run of launches; profiled kernels read long), and the
-    PMC traffic per GEMV launch is within [0.97, 1.08] x the algorithmic bytes.
-Slack on "trace kernel time vs un-profiled ms_per_step": 10 %.  A process under rocprofv3 runs its kernels at a lower clock
-(MI355X_MICROARCH.md, DVFS: profiled passes 1.89-1.95 GHz against 2.02 un-profiled) -- measured in the final passes of round 3 (each one box,
-one commit) +0.6...1.7 % on the HBM-bound Q8_0 kernels, +3...5 % / +7.5...8.5 % on the VALU-bound K-quant ones (8B / 70B Q4_K_M) -- so the trace of a
-correct run can exceed the un-profiled step time by that much; a trace that exceeded it by clearly more would mean the two files are
-not of the same tree."""
+    pmc_traffic.json[<key>]): the trace's kernel time per token, SCALED by the ratio of the shader clocks the two passes recorded
+    (r0N_bench_<key>_profiled.json = the bench line the profiled process printed; `sclk_mhz` = the average clock of the same workload over
+    32 steps right behind the timed region, ntk_debug_sclk_begin / _end), does not exceed the un-profiled line's ms_per_step by more
+    than 2 %; the pooled GEMV rate recomputed from the trace agrees with the bench line's live HIP-event figure within 12 % either way
+    (events read high: they contain the boundaries inside a run of launches); and the PMC traffic per GEMV launch is within
+    [0.97, 1.12] x the algorithmic bytes (the repacked K-quant tensors are 1.000 ... 1.028 x the GGUF bytes).
+Rounds 1-3 (no recorded clocks): 10 % slack, as their header stated."""
 import json
 import os
 import re
@@ -62,6 +60,10 @@ for name in sorted(os.listdir(PROF)):
         if "vs_baseline_per_gpu" in b and abs(b["vs_baseline_per_gpu"] * b["n_gpus"] - b["vs_baseline"]) > 2e-2:
             fail(name + ": vs_baseline_per_gpu x n_gpus != vs_baseline")
     for a in b.get("config", {}).get("also", []):
+        if "k" in a:   # round 4: compact entries
+            if a.get("value") and abs(b["n_gpus"] * 1e3 / a["ms"] / a["value"] - 1) > 3e-3:
+                fail("%s: also[%s] value vs ms" % (name, a["k"]))
+            continue
         if a.get("value") and abs(1e3 / a["ms_per_step"] / a["value"] - 1) > 2e-3:
             fail("%s: also[%s] value vs ms_per_step" % (name, a["workload"][:24]))
         if a.get("value") and abs(a["algorithmic_bytes_per_token"] * a["value"] / 8e12 - a["frac"]) > 2e-3:
@@ -89,8 +91,15 @@ for name in sorted(os.listdir(PROF)):
             fail(name + ": summary lines not found")
         continue   # (summaries of rounds 1-2 predate the per-token line)
     busy_us = float(mt.group(1))
-    if busy_us > 1.10 * 1e3 * b["ms_per_step"]:
-        fail("%s: kernel time per token %.1f us exceeds %s's ms_per_step %.1f us" % (name, busy_us, bname, 1e3 * b["ms_per_step"]))
+    slack, clk = 1.10, ""
+    pname = "%s_bench_%s_profiled.json" % (rnd, key)
+    if pname in lines and lines[pname].get("sclk_mhz") and b.get("sclk_mhz"):   # round 4 on: both passes recorded their clock
+        ratio = lines[pname]["sclk_mhz"] / b["sclk_mhz"]
+        busy_us *= ratio
+        slack, clk = 1.02, " (x %.4f: shader clock %.0f MHz profiled / %.0f un-profiled)" % (ratio, lines[pname]["sclk_mhz"], b["sclk_mhz"])
+    if busy_us > slack * 1e3 * b["ms_per_step"]:
+        fail("%s: kernel time per token %.1f us%s exceeds %s's ms_per_step %.1f us by more than %d %%"
+             % (name, busy_us, clk, bname, 1e3 * b["ms_per_step"], round(100 * (slack - 1))))
     gbs = float(mg.group(4))
     live = b["roofline"]["achieved"]
     if not (0.88 <= live / gbs <= 1.12):
@@ -100,7 +109,7 @@ for name in sorted(os.listdir(PROF)):
     g = pmc.get(key, {}).get("ntk::gemv_quant_*")
     if g and g.get("algorithmic_bytes_per_launch"):
         ratio = (g["fetch_bytes_per_launch"] + g["write_bytes_per_launch_raw"]) / g["algorithmic_bytes_per_launch"]
-        if not (0.97 <= ratio <= 1.08):
+        if not (0.97 <= ratio <= 1.12):
             fail("pmc_traffic.json[%s]: HBM traffic / algorithmic bytes = %.3f" % (key, ratio))
         print("%-14s PMC: %.2f MB fetched + written per GEMV launch = %.3f x algorithmic" % (key, (g["fetch_bytes_per_launch"] + g["write_bytes_per_launch_raw"]) / 1e6, ratio))
 print("evidence ok" if not bad else "%d problems" % bad)

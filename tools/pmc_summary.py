@@ -51,8 +51,9 @@ def main():
         print(f"{base}: {n} launches, FETCH_SIZE {fb / n / 1e6:.3f} MB raw -> {2 * fb / n / 1e6:.3f} MB corrected per launch, WRITE_SIZE {wb / n / 1e6:.4f} MB raw per launch")
         out[base] = {"launches": n, "fetch_bytes_per_launch_raw": fb / n, "fetch_bytes_per_launch": 2 * fb / n,
                      "write_bytes_per_launch_raw": wb / n}
-    # every form of the GEMV (plain, integer-activation, two-format) pooled: what bench.py's roofline block calls "the GEMV launches"
-    gk = [k for k in out if k.startswith('ntk::gemv_quant_')]
+    # every form of the GEMV (plain, integer-activation, two-format, matrix-core over the repack) pooled: what bench.py's roofline block calls
+    # "the GEMV launches" (the key keeps its round-1 name)
+    gk = [k for k in out if k.startswith('ntk::gemv_quant_') or k.startswith('ntk::rp_gemv_kernel')]
     if gk:
         n = sum(out[k]['launches'] for k in gk)
         out['ntk::gemv_quant_*'] = {"launches": n,
@@ -60,7 +61,7 @@ def main():
                                     "fetch_bytes_per_launch": sum(out[k]['fetch_bytes_per_launch'] * out[k]['launches'] for k in gk) / n,
                                     "write_bytes_per_launch_raw": sum(out[k]['write_bytes_per_launch_raw'] * out[k]['launches'] for k in gk) / n}
         g = out['ntk::gemv_quant_*']
-        print(f"ntk::gemv_quant_* pooled: {n} launches, FETCH_SIZE {g['fetch_bytes_per_launch'] / 1e6:.3f} MB corrected per launch, WRITE_SIZE {g['write_bytes_per_launch_raw'] / 1e6:.4f} MB raw per launch")
+        print(f"GEMV launches (ntk::gemv_quant_* + ntk::rp_gemv_kernel) pooled: {n} launches, FETCH_SIZE {g['fetch_bytes_per_launch'] / 1e6:.3f} MB corrected per launch, WRITE_SIZE {g['write_bytes_per_launch_raw'] / 1e6:.4f} MB raw per launch")
         if a.algorithmic_bytes_per_launch:
             out['ntk::gemv_quant_*']['algorithmic_bytes_per_launch'] = a.algorithmic_bytes_per_launch
             print(f"gemv launches: corrected fetch / algorithmic = {g['fetch_bytes_per_launch'] / a.algorithmic_bytes_per_launch:.3f}")
