@@ -200,7 +200,11 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     try:   # the average shader clock of the same workload, over 32 more steps right behind the timed region (a one-wave kernel beside them on
         # another stream: ntk_debug_sclk_begin / _end): lets a profiled pass be compared with an un-profiled one
         from ntransformer_amd import ops as _ops
-        if pos_end + 32 <= args.ctx and out:
+        profiled = (any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ)
+                    or "rocprof" in os.environ.get("LD_PRELOAD", ""))   # rocprofv3 serialises kernels: nothing can run BESIDE the steps
+        if profiled:
+            sclk = round(_ops.sclk_mhz(), 1)       # ... so there: one wave spinning for 50 us right behind the timed region
+        elif pos_end + 32 <= args.ctx and out:
             with _ops.SclkSpan() as c:
                 eng.decode_greedy_steps(out[-1], pos_end, 32)
                 sync()

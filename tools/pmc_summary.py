@@ -25,7 +25,8 @@ def load(path, counter):
     first = next((i for i, r in enumerate(dec) if 'attention_decode_fused' in r[1]), 0)
     first_embed = max((i for i in range(first) if 'embed_rows' in dec[i][1]), default=0)
     per = collections.defaultdict(list)
-    for _, name, v in dec[first_embed:]: per[name].append(v)
+    for _, name, v in dec[first_embed:]:
+        if 'sclk_' not in name: per[name].append(v)   # (the clock probes of bench.py are not part of the token)
     return per
 
 def main():

@@ -21,7 +21,7 @@ def main():
     # drop everything up to the end of prefill's token (final norm + LM head + first argmax): start at first fused attention
     first = next((i for i, r in enumerate(dec) if "attention_decode_fused" in r[0]), 0)
     first_embed = max((i for i in range(first) if "embed_rows" in dec[i][0]), default=0)
-    dec = dec[first_embed:]
+    dec = [r for r in dec[first_embed:] if "sclk_" not in r[0]]   # (the clock probes of bench.py are not part of the token)
     n_tokens = sum(1 for r in dec if "embed_rows" in r[0])
     stats = collections.OrderedDict()
     for name, s, e, gx, wx, vg, lds in dec:
