@@ -65,8 +65,7 @@ __device__ __forceinline__ void rope_pair(float& x0, float& x1, int pos, int pai
     const float angle = pos * freq * fscale;
     const float c = cosf(angle), s = sinf(angle);
     const float a = x0, b = x1;
-    x0 = a * c - b * s;
-    x1 = b * c + a * s;
+    rope_rotate(a, b, c, s, x0, x1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -328,7 +327,8 @@ __device__ __forceinline__ void attention_decode_walk(
             const float angle = pos * f * fscale;
             float c, sn;
             sincosf(angle, &sn, &c);   // one argument reduction; bit-identical to sinf / cosf on gfx950 (tools/micro/sincos_check.hip)
-            const float ra = a * c - b * sn, rb = b * c + a * sn;
+            float ra, rb;
+            rope_rotate(a, b, c, sn, ra, rb);
             if (role == 0) { qs[i] = ra; qs[i + half_dim] = rb; }
             else {
                 ha = f2h(ra); hb = f2h(rb);   // attention.cu:338 (__float2half, RNE)
@@ -496,20 +496,33 @@ __global__ __launch_bounds__(256) void attention_decode_split_kernel(
                                         n_kv_heads, hd, max_seq, scale, theta, fscale, head, sp, nsplit);
 }
 
-__global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __restrict__ output, const float* __restrict__ part,
-                                                                      int hd, int nsplit) {
-    // One workgroup per head.  Every memory round trip is taken ONCE for all splits: thread s fetches split s's (m, l); the weights
-    // exp(m_s - M) go through LDS; the sum over splits of a thread's output element runs in split order with its loads issued eight at a
-    // time.  (Round 3's form walked the splits in two rolled loops -- a dependent L2 round trip per split and loop: 0.35 us per split, 2.8 us
-    // of the 8-split launch pair and the reason 16 splits lost to 8 at every context; profiles/r03_attention_by_context.txt.)
+__global__ __launch_bounds__(128) void attention_split_combine_kernel(float* __restrict__ output, const float* __restrict__ part,
+                                                                      int hd, int nsplit, int n_kv_heads) {
+    // One workgroup per head, ONE memory round trip for everything: thread s requests split s's (m, l), then every thread requests its
+    // output element of up to 32 splits at once; the weights exp(m_s - M) go through LDS while those loads are in flight; the sums run in
+    // split order.  (Round 3 walked the splits in two rolled loops -- a dependent round trip per split; round 4's first form took one per
+    // 8 splits: 32 splits cost 4 us more than 8, profiles/r04_attention_by_context.txt.)  Workgroup b serves head
+    // (b % n_kv_heads) * group + b / n_kv_heads: on the XCD (b % 8) whose L2 the partial states of that KV head were written through.
     __shared__ float wsh[1024], lsh[1024];
-    const int head = blockIdx.x, tid = threadIdx.x;
+    const int group = (int)gridDim.x / n_kv_heads;
+    const int head = ((int)blockIdx.x % n_kv_heads) * group + (int)blockIdx.x / n_kv_heads, tid = threadIdx.x;
     const float* ph = part + (size_t)head * nsplit * (hd + 2);
-    for (int s0 = tid; s0 < nsplit; s0 += blockDim.x) {
-        const float* ps = ph + (size_t)s0 * (hd + 2);
-        wsh[s0] = ps[hd];
-        lsh[s0] = ps[hd + 1];
+    float mreg[8], lreg[8];   // nsplit <= 1024 = 8 x 128 threads
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s0 = min(tid + 128 * u, nsplit - 1);
+        mreg[u] = -INFINITY; lreg[u] = 0.0f;
+        if (128 * u < nsplit) { mreg[u] = ph[(size_t)s0 * (hd + 2) + hd]; lreg[u] = ph[(size_t)s0 * (hd + 2) + hd + 1]; }   // (uniform)
     }
+    constexpr int B = 32;
+    const int d0 = min(tid, hd - 1);
+    float v0[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) v0[u] = ph[(size_t)min(u, nsplit - 1) * (hd + 2) + d0];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (tid + 128 * u < nsplit) { wsh[tid + 128 * u] = mreg[u]; lsh[tid + 128 * u] = lreg[u]; }
     __syncthreads();
     float M = -INFINITY;
     for (int s0 = 0; s0 < nsplit; ++s0) M = fmaxf(M, wsh[s0]);
@@ -520,12 +533,17 @@ __global__ __launch_bounds__(256) void attention_split_combine_kernel(float* __r
     for (int s0 = 0; s0 < nsplit; ++s0) L = fmaf(wsh[s0], lsh[s0], L);   // split order, like the output sums
     for (int d = tid; d < hd; d += blockDim.x) {
         float o = 0.0f;
-        for (int s0 = 0; s0 < nsplit; s0 += 8) {
-            float v[8];
+        for (int s0 = 0; s0 < nsplit; s0 += B) {
+            float v[B];
+            if (s0 == 0 && d == d0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ph[(size_t)min(s0 + u, nsplit - 1) * (hd + 2) + d];
+                for (int u = 0; u < B; ++u) v[u] = v0[u];
+            } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < B; ++u) v[u] = ph[(size_t)min(s0 + u, nsplit - 1) * (hd + 2) + d];
+            }
+#pragma unroll
+            for (int u = 0; u < B; ++u)
                 if (s0 + u < nsplit) o = fmaf(wsh[s0 + u], v[u], o);
         }
         output[(size_t)head * hd + d] = o / L;
@@ -674,8 +692,7 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(float* __restrict__ q, f
         float* data = head < n_heads ? q + ((size_t)sp * n_heads + head) * head_dim : k + ((size_t)sp * n_kv_heads + (head - n_heads)) * head_dim;
         const int i0 = interleaved ? 2 * pair : pair, i1 = interleaved ? 2 * pair + 1 : pair + half_dim;
         const float a = data[i0], b = data[i1], c = cs[0][pair], sn = cs[1][pair];
-        data[i0] = a * c - b * sn;
-        data[i1] = b * c + a * sn;
+        rope_rotate(a, b, c, sn, data[i0], data[i1]);
     }
 }
 
@@ -694,6 +711,9 @@ static size_t attn_lds(int hd, int n_keys, int nvec) {
     return sizeof(float) * ((size_t)nvec * hd + 16 + 4 * (size_t)hd + (size_t)n_keys + 1);
 }
 
+int launch_attention_decode_kvhead_mfma(float* part, const float* q, const float* k, const float* v, uint16_t* kc, uint16_t* vc,
+                                        const int* d_pos, const float* inv_freq, int nh, int nkv, int max_seq, float scale, float theta,
+                                        float fscale, int nsplit, hipStream_t st);   // attention_mfma.hip
 int launch_attention_prefill_mfma(float* out, const float* Q, const uint16_t* kc, const uint16_t* vc, int T, int start_pos, int nh, int nkv,
                                   int hd, float scale, hipStream_t st);   // attention_mfma.hip
 
@@ -837,6 +857,19 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     hipStream_t st = ntk::resolve_stream(stream);
     uint16_t* k16 = static_cast<uint16_t*>(k_cache);
     uint16_t* v16 = static_cast<uint16_t*>(v_cache);
+    // head_dim 128, at most 16 query heads per KV head, 16 splits or more: the matrix-core form, one workgroup per (KV head, split), every
+    // cache row read once (attention_mfma.hip).  With fewer splits a wave of that form walks four or more 32-row chunks per 4096 positions
+    // and the per-query-head walk below is faster (measured, tools/attn_bench.py over 40 rotating layer caches, 8B geometry, us per layer
+    // incl. the combine launch: 1023 positions 8.7 (walk, 8 splits) vs 10.2 (matrix cores, 8) -- 2047: 10.1 vs 11.1 (16) -- 4095: 13.5 vs
+    // 12.75 (32); 70B geometry 4095: 16.5 vs 13.5; inside the engine the forms cross near 2300 positions: profiles/r04_attention_kvhead_form.txt)
+    static const int kvhead_form = NTK_TUNE_ENV_INT("NTK_ATTN_KVHEAD", 1);   // (tuning builds: 0 = the per-query-head walk, 2 = the matrix-core form at any split count)
+    if (head_dim == 128 && n_heads / n_kv_heads <= 16 && ((kvhead_form == 1 && nsplit >= 16) || kvhead_form == 2)) {
+        const int rc = ntk::launch_attention_decode_kvhead_mfma(scratch, q, k, v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, max_seq,
+                                                                scale, theta_base, freq_scale, nsplit, st);
+        if (rc != NTK_OK) return rc;
+        hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit, n_kv_heads);
+        return ntk::last_launch_status();
+    }
     const int G = 4 * (64 / (head_dim / 8));
     const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
 #define NTK_ATTSP(...) hipLaunchKernelGGL((ntk::attention_decode_split_kernel<__VA_ARGS__>), dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \
@@ -848,7 +881,7 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     else NTK_ATTSP(32, 4);
 #undef NTK_ATTSP
     if (ntk::last_launch_status() != NTK_OK) return NTK_E_LAUNCH;
-    hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit);
+    hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit, n_kv_heads);
     return ntk::last_launch_status();
 }
 

@@ -234,4 +234,300 @@ int launch_attention_prefill_mfma(float* out, const float* Q, const uint16_t* kc
     return last_launch_status();
 }
 
+// =================================================================================================================================
+// Long-context DECODE attention on the matrix cores: one workgroup per (KV head, split), the query heads that share the KV head are
+// the 16-wide N dimension of the MFMAs (4 of 16 columns live for 8B, 8 for 70B -- the matrix cores are idle in decode anyway).
+//
+// Replaces, beyond a few hundred positions, the per-query-head walk of attention.hip (attention_decode_split_kernel; reference
+// attention.cu:108-214 attention_decode_generic_kernel + rotary.cu:16-62 + attention.cu:316-342): that walk reads every cache row
+// once per query head of the group (4x / 8x through L2) and spends ~45 VALU instructions per (position, head) at one wave per SIMD --
+// 11.5 us per layer at 4095 positions against 2.6 us of cache bytes.  Here a cache row is read ONCE, straight into the A operand of
+//   S^T[key][head] = K . (q scale)^T          (v_mfma_f32_16x16x32_f16, q split into an F16 value + the F16 rounding of the rest)
+// and V goes through a wave-private transposed LDS image into
+//   O^T[dim][head] += V^T . P^T               (P split the same way; the accumulator layout of S^T IS the B operand layout of P^T)
+// exactly as in the prompt kernel above, with a lane owning ONE query head: the online softmax is lane-local plus two cross-lane steps.
+//
+// Work: the positions 0 .. pos (pos = the token being decoded) in chunks of 32 cache rows; chunk c belongs to wave (c mod W) of the
+// W = 4 nsplit waves of a KV head, so a launch sized for its regime gives every wave one or two chunks, all requested in the first
+// microsecond of the kernel (row addresses do not depend on the position: rows past it are loaded and masked by selects, never by
+// arithmetic -- they may hold anything).  The token being decoded: RoPE of the group's queries by all workgroups; RoPE of k and the
+// half rounding of v by the workgroup whose wave owns chunk pos / 32, which takes that row from LDS and stores it to the cache at the end.
+// Output: un-normalised partial states part[head][split] = (acc[128], m, l) for attention_split_combine_kernel (attention.hip).
+// =================================================================================================================================
+constexpr int AD_CK = 32;                       // cache rows per chunk
+constexpr int AD_VP = 40;                       // halves per V^T row in LDS (80 B: the 8-byte operand reads of 32 lanes cover 64 banks)
+constexpr int AD_WAVE_LDS = AM_HD * AD_VP * 2;  // 10240 B per wave: V^T of its chunk; afterwards its partial output [head][128] floats
+
+__global__ __launch_bounds__(256) void attention_decode_kvhead_mfma_kernel(
+    float* __restrict__ part, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
+    const int n_heads, const int n_kv_heads, const int max_seq, const float scale, const float theta, const float fscale) {
+    // one LDS object: [queries 16 x 128 f32][new k row, new v row as halves][4 wave regions][m, l of 4 waves x 16 heads]
+    __shared__ __attribute__((aligned(16))) uint8_t smem[16 * AM_HD * 4 + 2 * AM_HD * 2 + 4 * AD_WAVE_LDS + 2 * 64 * 4];
+    float* qs = reinterpret_cast<float*>(smem);
+    uint16_t* knew = reinterpret_cast<uint16_t*>(smem + 16 * AM_HD * 4);
+    uint16_t* vnew = knew + AM_HD;
+    uint8_t* wl0 = smem + 16 * AM_HD * 4 + 2 * AM_HD * 2;
+    float* ms = reinterpret_cast<float*>(wl0 + 4 * AD_WAVE_LDS);
+    float* ls = ms + 64;
+
+    const int kv_head = blockIdx.x, sp = blockIdx.y, nsplit = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int group = n_heads / n_kv_heads;               // query heads per KV head (<= 16: host-checked)
+    const int W = 4 * nsplit, gw = 4 * sp + wave;         // waves of this KV head, this wave's index among them
+    const unsigned row_bytes = (unsigned)n_kv_heads * AM_HD * 2u;
+    const char* kb = reinterpret_cast<const char*>(kc) + (size_t)kv_head * AM_HD * 2;
+    const char* vb = reinterpret_cast<const char*>(vc) + (size_t)kv_head * AM_HD * 2;
+    const unsigned last_row = (unsigned)(max_seq - 1);
+
+    // ---- the first chunk's rows, requested before anything else (32-bit byte offsets: max_seq * row_bytes < 4 GiB, host-checked) ----
+    // K: block mt (16 keys), head_dim chunk c (32 wide): lane (i, g) holds dims 32c + 8g .. +7 of key 16 mt + i = the A operand itself.
+    // V: combination n of (piece pc = 16 bytes of a row, row group rg = 4 rows): lane p = lane + 64 n -> pc = p & 15, rg = p >> 4.
+    u32x4 kraw[2][4], vraw[2][4];
+    auto request = [&](const int chunk) {
+        const unsigned r0 = (unsigned)chunk * AD_CK;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const unsigned off = min(r0 + 16u * mt + (unsigned)i, last_row) * row_bytes + 16u * g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kraw[mt][c] = *reinterpret_cast<const u32x4*>(kb + off + 64u * c);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int p = lane + 64 * n;
+            const unsigned rbase = r0 + 4u * (unsigned)(p >> 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                vraw[n][r] = *reinterpret_cast<const u32x4*>(vb + min(rbase + r, last_row) * row_bytes + 16u * (p & 15));
+        }
+    };
+    // The token's own inputs are requested FIRST (a CU returns its loads in request order: behind 16 KB of cache rows per wave they
+    // would come back with HBM latency, and RoPE -- which the cache rows do not wait for -- would start two microseconds late).
+    // Thread t: query pairs (ri, ri + 64) of heads t / 64 and t / 64 + 4 ...; threads 0-63 also the key pair, threads 128-255 a value.
+    const int ri = tid & 63;
+    float qa[4], qb[4];                                                  // group <= 16: at most 4 query pairs per thread
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = (tid >> 6) + 4 * u;
+        qa[u] = qb[u] = 0.0f;
+        if (n < group) {
+            const float* src = q + ((size_t)kv_head * group + n) * AM_HD;
+            qa[u] = src[ri]; qb[u] = src[ri + 64];
+        }
+    }
+    float ka_in = 0.0f, kb_in = 0.0f, v_in = 0.0f;
+    if (tid < 64) { const float* src = k + (size_t)kv_head * AM_HD; ka_in = src[tid]; kb_in = src[tid + 64]; }
+    else if (tid >= 128) v_in = v[(size_t)kv_head * AM_HD + tid - 128];
+    const float freq = inv_freq ? inv_freq[ri] : 1.0f / (float)pow((double)theta, (double)((2.0f * ri) / AM_HD));
+    const int pos = *d_pos;
+    __builtin_amdgcn_sched_barrier(0);   // (the compiler may not hoist the cache rows above the token's loads)
+    request(gw);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- the token being decoded: RoPE (reference rotary.cu:46-60, the arithmetic of attention.hip's walk) ----
+    float rc, rs;
+    {
+        const float angle = pos * freq * fscale;
+        sincosf(angle, &rs, &rc);   // one argument reduction for the thread's pairs (same frequency index ri)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int n = (tid >> 6) + 4 * u;
+        if (n < group) {
+            rope_rotate(qa[u], qb[u], rc, rs, qs[n * AM_HD + ri], qs[n * AM_HD + ri + 64]);
+        }
+    }
+    const int own_chunk = pos / AD_CK;                                 // the chunk that contains the token being decoded
+    const bool owner_wg = ((own_chunk % W) >> 2) == sp;                 // (uniform) ... belongs to a wave of this workgroup
+    const bool writer = owner_wg && pos < max_seq;
+    uint16_t st_h[2] = {0, 0};
+    if (owner_wg) {
+        if (tid < 64) {                                                 // key pair (tid, tid + 64): attention.cu:338 (__float2half, RNE)
+            float ra, rb;
+            rope_rotate(ka_in, kb_in, rc, rs, ra, rb);
+            st_h[0] = f2h(ra); st_h[1] = f2h(rb);
+            knew[tid] = st_h[0]; knew[tid + 64] = st_h[1];
+        } else if (tid >= 128) {                                        // value element tid - 128
+            st_h[0] = f2h(v_in);
+            vnew[tid - 128] = st_h[0];
+        }
+    }
+    __syncthreads();
+
+    // Q operand: (q * scale) as hi + lo halves; lane (i, g): head i, dims 32c + 8g .. +7.  Heads past the group: zero columns.
+    f16x8 qh[4], ql[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
+        if (i < group) {
+            const float4 a = *reinterpret_cast<const float4*>(qs + i * AM_HD + 32 * c + 8 * g);
+            const float4 b = *reinterpret_cast<const float4*>(qs + i * AM_HD + 32 * c + 8 * g + 4);
+            x[0] = a.x * scale; x[1] = a.y * scale; x[2] = a.z * scale; x[3] = a.w * scale;
+            x[4] = b.x * scale; x[5] = b.y * scale; x[6] = b.z * scale; x[7] = b.w * scale;
+        }
+        am_split8(x, qh[c], ql[c]);
+    }
+
+    f32x4 o[8];   // O^T: dims 16 ht + 4g + e of head i
+#pragma unroll
+    for (int ht = 0; ht < 8; ++ht) o[ht] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float m_run = -INFINITY, l_run = 0.0f;
+    uint16_t* vt = reinterpret_cast<uint16_t*>(wl0 + wave * AD_WAVE_LDS);   // this wave's V^T image [128 dims][AD_VP]
+    const int nchunks = own_chunk + 1;
+
+    for (int chunk = gw; chunk < nchunks; chunk += W) {
+        const int r0 = chunk * AD_CK;
+        const bool last = chunk == own_chunk;   // (uniform) holds the token being decoded, and rows past it
+        u32x4 ka[2][4], vv[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ka[mt][c] = kraw[mt][c];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vv[n][r] = vraw[n][r];
+        if (last) {   // the new row from LDS; rows past it zeroed (V) -- their scores are masked below
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int key = r0 + 16 * mt + i;
+                if (key == pos) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ka[mt][c] = *reinterpret_cast<const u32x4*>(knew + 32 * c + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int p = lane + 64 * n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = r0 + 4 * (p >> 4) + r;
+                    if (key == pos) vv[n][r] = *reinterpret_cast<const u32x4*>(vnew + 8 * (p & 15));
+                    if (key > pos) vv[n][r] = u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (chunk + W < nchunks) request(chunk + W);   // (uniform) the ring registers are free: the next chunk may land in them
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- V^T image: per head_dim value the four rows' halves as one 8-byte store; key group (4 rows) rg of dim d sits at
+        //      column group rg ^ ((d >> 3) & 7) (the 16 pieces of a row would otherwise hit two banks) ----
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int p = lane + 64 * n, pc = p & 15, rg = p >> 4;
+            const int col = 4 * (rg ^ (pc & 7));
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {   // dword e2 of a piece: dims 8 pc + 2 e2 (low half) and 8 pc + 2 e2 + 1 (high half)
+                const uint32_t w0 = vv[n][0][e2], w1 = vv[n][1][e2], w2 = vv[n][2][e2], w3 = vv[n][3][e2];
+                const u32x2 lo = {__builtin_amdgcn_perm(w1, w0, 0x05040100u), __builtin_amdgcn_perm(w3, w2, 0x05040100u)};
+                const u32x2 hi = {__builtin_amdgcn_perm(w1, w0, 0x07060302u), __builtin_amdgcn_perm(w3, w2, 0x07060302u)};
+                *reinterpret_cast<u32x2*>(vt + (8 * pc + 2 * e2) * AD_VP + col) = lo;
+                *reinterpret_cast<u32x2*>(vt + (8 * pc + 2 * e2 + 1) * AD_VP + col) = hi;
+            }
+        }
+
+        // ---- S^T = K . Q^T: lane (i, g): head i, keys r0 + 16 mt + 4g + e ----
+        f32x4 s[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f16x8 a = __builtin_bit_cast(f16x8, ka[mt][c]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qh[c], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, ql[c], acc, 0, 0, 0);
+            }
+            s[mt] = acc;
+        }
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (last) s[mt][e] = (r0 + 16 * mt + 4 * g + e <= pos) ? s[mt][e] : -INFINITY;   // a select: the row may hold anything
+                m_tile = fmaxf(m_tile, s[mt][e]);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        const float m_new = fmaxf(m_run, m_tile);          // finite: every chunk holds at least one position <= pos
+        const float alpha = __expf(m_run - m_new);         // exp(-inf) = 0 on the wave's first chunk
+        float pv[8], l_tile = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            pv[e] = __expf(s[0][e] - m_new);               // keys r0 + 4g + e
+            pv[4 + e] = __expf(s[1][e] - m_new);           // keys r0 + 16 + 4g + e
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l_tile += pv[e];
+        f16x8 ph, pl;
+        am_split8(pv, ph, pl);
+        l_tile += __shfl_xor(l_tile, 16, 64);
+        l_tile += __shfl_xor(l_tile, 32, 64);
+        l_run = l_run * alpha + l_tile;
+        m_run = m_new;
+
+        // ---- O^T = alpha O^T + V^T . P^T ----
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht) {
+            const int d = 16 * ht + i, sw = (d >> 3) & 7;
+            const uint16_t* vrow = vt + d * AD_VP;
+            const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow + 4 * (g ^ sw));          // keys 4g .. 4g+3
+            const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 4 * ((4 + g) ^ sw));    // keys 16 + 4g .. 16 + 4g+3
+            const f16x8 va = __builtin_bit_cast(f16x8, u32x4{v0.x, v0.y, v1.x, v1.y});
+            f32x4 acc = o[ht] * alpha;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, ph, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pl, acc, 0, 0, 0);
+            o[ht] = acc;
+        }
+    }
+
+    // ---- merge the four waves (un-normalised states), write part[head][sp] = (acc[128], m, l) ----
+    float* mine = reinterpret_cast<float*>(wl0 + wave * AD_WAVE_LDS);   // [head][128] (the wave's own LDS reads are behind it: in order)
+    if (i < group) {
+#pragma unroll
+        for (int ht = 0; ht < 8; ++ht) *reinterpret_cast<f32x4*>(mine + i * AM_HD + 16 * ht + 4 * g) = o[ht];
+        if (g == 0) { ms[wave * 16 + i] = m_run; ls[wave * 16 + i] = l_run; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < group * AM_HD; idx += 256) {
+        const int n = idx >> 7, d = idx & (AM_HD - 1);
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, ms[w * 16 + n]);
+        float L = 0.0f, acc = 0.0f;
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float mw = ms[w * 16 + n];
+                const float wgt = mw > -INFINITY ? expf(mw - M) : 0.0f;
+                L = fmaf(wgt, ls[w * 16 + n], L);
+                acc = fmaf(wgt, reinterpret_cast<const float*>(wl0 + w * AD_WAVE_LDS)[n * AM_HD + d], acc);
+            }
+        }
+        float* out = part + (((size_t)kv_head * group + n) * nsplit + sp) * (AM_HD + 2);
+        out[d] = acc;
+        if (d == 0) { out[AM_HD] = M; out[AM_HD + 1] = L; }
+    }
+    if (writer) {   // the new cache row, at the very end (attention.hip: a store in front of the walk delays the first row)
+        const size_t cache_row = (size_t)pos * n_kv_heads * AM_HD + (size_t)kv_head * AM_HD;
+        if (tid < 64) { kc[cache_row + tid] = st_h[0]; kc[cache_row + tid + 64] = st_h[1]; }
+        else if (tid >= 128) vc[cache_row + tid - 128] = st_h[0];
+    }
+}
+
+// head_dim 128, <= 16 query heads per KV head, 16-byte aligned caches (caller-checked): partial states for attention_split_combine_kernel
+int launch_attention_decode_kvhead_mfma(float* part, const float* q, const float* k, const float* v, uint16_t* kc, uint16_t* vc,
+                                        const int* d_pos, const float* inv_freq, int nh, int nkv, int max_seq, float scale, float theta,
+                                        float fscale, int nsplit, hipStream_t st) {
+    if (nh % nkv != 0 || nh / nkv > 16 || nsplit < 1) return NTK_E_SHAPE;
+    hipLaunchKernelGGL(attention_decode_kvhead_mfma_kernel, dim3(nkv, nsplit), dim3(256), 0, st, part, q, k, v, kc, vc, d_pos, inv_freq,
+                       nh, nkv, max_seq, scale, theta, fscale);
+    return last_launch_status();
+}
+
 }  // namespace ntk

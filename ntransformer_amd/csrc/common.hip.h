@@ -40,6 +40,16 @@ __device__ __forceinline__ uint16_t f2h(float f) {
     return bits;
 }
 
+// ---- the RoPE rotation (reference rotary.cu:56-59): two products and a sum per output, every operation rounded on its own -- no fused
+//      multiply-add.  hipcc is free to contract `a * c - b * s` either way round (or not at all) per call site, so two kernels given
+//      the same inputs could store cache rows that differ in the last bit; one definition with contraction off makes every kernel of the
+//      library -- and the CPU restatement, compiled without FMA -- produce the same bits from the same (a, b, cos, sin). ----
+__device__ __forceinline__ void rope_rotate(const float a, const float b, const float c, const float s, float& ra, float& rb) {
+#pragma clang fp contract(off)
+    ra = a * c - b * s;
+    rb = b * c + a * s;
+}
+
 // ---- wave64 reductions on the DPP path (no LDS traffic, ~6 dependent VALU ops instead of six ds_bpermute round
 //      trips): quad swaps, half-row and row mirrors leave every lane of a 16-lane row with the row total;
 //      row_bcast:15 / row_bcast:31 then chain the four rows, so the wave total lands in lanes 48..63. ----

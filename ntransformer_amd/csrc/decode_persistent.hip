@@ -195,8 +195,10 @@ __device__ __attribute__((noinline)) void p_attention(const POp* op_arg, float* 
             const float freq = op.inv_freq ? op.inv_freq[i] : 1.0f / (float)pow((double)op.theta, (double)((2.0f * i) / hd));
             const float angle = pos * freq * op.fscale;
             const float c = cosf(angle), sn = sinf(angle);
-            qs[i] = a * c - b * sn; qs[i + half_dim] = b * c + a * sn;
-            const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
+            rope_rotate(a, b, c, sn, qs[i], qs[i + half_dim]);
+            float rka, rkb;
+            rope_rotate(ka, kb, c, sn, rka, rkb);
+            const uint16_t ha = f2h(rka), hb = f2h(rkb);   // attention.cu:338 (__float2half, RNE)
             kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
             if (writer) { op.kc[cache_row + i] = ha; op.kc[cache_row + i + half_dim] = hb; }
         }

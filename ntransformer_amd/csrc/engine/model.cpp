@@ -831,7 +831,7 @@ int Model::enqueue_layers(int first, int last_layer) {
         else
             NT_TRY(ntk_attention_decode_split(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
                                               cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale,
-                                              attn_regime_ == 1 ? 8 : 16, attn_scratch_, s));
+                                              attention_splits(attn_regime_), attn_scratch_, s));
         mark(1, false);
         if (tp_world_ > 1) {   // partial sum over this rank's heads -> exchange slot -> hidden += sum over ranks
             NT_TRY(project1(L.wo, tp_slot(), attn_out, nullptr, nullptr, 2));
@@ -1099,14 +1099,14 @@ int Model::build_persistent_plan() { return NTK_E_SHAPE; }
 
 void Model::pick_attention_regime() {
     attn_regime_ = (attn_scratch_ && (cfg_.head_dim == 64 || cfg_.head_dim == 128 || cfg_.head_dim == 256))
-                       ? attention_regime(host_pos_) : 0;
+                       ? attention_regime(host_pos_, cfg_.head_dim) : 0;
     ++host_pos_;   // every fused token ends with ntk_advance_pos on the device; set_device_pos() re-bases both
 }
 
 int Model::decode_step_fused(bool greedy, bool use_graph) {
     pick_attention_regime();
     if (!use_graph) return enqueue_token(greedy);
-    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? 3 : attn_regime_];
+    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? 4 : attn_regime_];
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
         hipGraph_t g = nullptr;

@@ -60,8 +60,10 @@ __device__ __forceinline__ void att_head(const AttnFuse& a, float* lds, int head
         const float freq = a.inv_freq ? a.inv_freq[i] : 1.0f / (float)pow((double)a.theta, (double)((2.0f * i) / hd));
         const float angle = pos * freq * a.fscale;
         const float c = cosf(angle), sn = sinf(angle);
-        qs[i] = qa * c - qb * sn; qs[i + half_dim] = qb * c + qa * sn;
-        const uint16_t ha = f2h(ka * c - kb * sn), hb = f2h(kb * c + ka * sn);   // attention.cu:338 (__float2half, RNE)
+        rope_rotate(qa, qb, c, sn, qs[i], qs[i + half_dim]);
+        float rka, rkb;
+            rope_rotate(ka, kb, c, sn, rka, rkb);
+            const uint16_t ha = f2h(rka), hb = f2h(rkb);   // attention.cu:338 (__float2half, RNE)
         kx[i] = h2f(ha); kx[i + half_dim] = h2f(hb);
         if (writer) { a.kc[cache_row + i] = ha; a.kc[cache_row + i + half_dim] = hb; }
     }

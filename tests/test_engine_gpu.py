@@ -206,6 +206,45 @@ def test_long_context_decode_uses_split_attention_and_matches_the_oracle(tmp_pat
     _log_observed({"test": "long_context_decode_vs_oracle", "model": "small Q8_0 (4 layers, hd 128, GQA 4)", "max_abs_err_vs_oracle": observed})
 
 
+def test_decode_beyond_2304_positions_runs_the_matrix_core_attention_and_matches_the_oracle(tmp_path):
+    """From 2304 positions the engine's split attention is the matrix-core form (one workgroup per (KV head, split), 16 splits; 32 from
+    3328 positions: Model::attention_regime, attention_mfma.hip).  Decode across both borders -- 2300..2309 and 3324..3333 -- in the
+    fused and the graph-replayed mode against the ORACLE (reference attention.cu:108-202 over a cache of thousands of rows), teacher
+    forced, at the north-star tolerance; the cache rows the engine wrote on the way (K within a half ulp: device vs glibc sin / cos;
+    V bit-exact) are checked through the oracle's own cache.  Model: the `small` shape (head_dim 128, GQA 4) with 2 layers and a
+    4096-token context."""
+    import dataclasses
+    shape = dataclasses.replace(G.SMALL, name="small4k", layers=2, ctx=4096)
+    path = str(tmp_path / "small4k_q8_0.gguf")
+    G.make_synthetic_llama(path, shape, "Q8_0", seed=20260926)
+    r = np.random.Generator(np.random.Philox(key=[20260926, 4096]))
+    observed = {}
+    for start in (2300, 3324):
+        prompt = [256] + [int(t) for t in r.integers(0, 256, start - 1)]
+        cont = [int(t) for t in r.integers(0, 256, 10)]
+        m = O.OracleModel(path, 4096)
+        want = [m.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in cont:
+            want.append(m.forward([t], pos))
+            pos += 1
+        want = np.stack(want)
+        for mode in ("fused", "graph"):
+            eng = E.Engine()
+            eng.load(path, 4096)
+            lg = [eng.forward(prompt, 0)]
+            pos = len(prompt)
+            for t in cont:
+                lg.append(eng.decode_fused(t, pos, mode == "graph"))
+                pos += 1
+            eng.close()
+            err = np.abs(np.stack(lg) - want).max(axis=1)
+            observed["%d/%s" % (start, mode)] = float(err.max())
+            assert err.max() <= TOL, (start, mode, [float(e) for e in err])
+    _log_observed({"test": "decode_beyond_2304_positions_vs_oracle", "model": "small Q8_0, 2 layers, hd 128, GQA 4, context 4096",
+                   "max_abs_err_vs_oracle": observed})
+
+
 # ---------------------------------------------------------------------------------------------------
 # Parity at the BASELINE configs' real width, shallow depth (SURVEY 8(d) "Parity procedure"; reference
 # src/model/transformer.cpp:604-669).  Teacher-forced: the oracle runs free greedy decode, the HIP engine is fed the

@@ -692,11 +692,14 @@ def test_attention_decode_fused_equals_rope_store_attend(pos, nh, nkv, hd, table
     assert np.array_equal(kcd.numpy(np.uint16)[: pos * nkv * hd], kc[: pos * nkv * hd])   # older rows untouched
 
 
-@pytest.mark.parametrize("pos", [0, 1, 15, 300, 1023, 2047, 4095])
-@pytest.mark.parametrize("nh,nkv,hd,nsplit", [(32, 8, 128, 8), (32, 8, 128, 32), (64, 8, 128, 32), (4, 2, 64, 3)])
+@pytest.mark.parametrize("pos", [0, 1, 15, 31, 32, 33, 300, 543, 1023, 1024, 2047, 4095])
+@pytest.mark.parametrize("nh,nkv,hd,nsplit", [(32, 8, 128, 8), (32, 8, 128, 32), (64, 8, 128, 32), (4, 2, 64, 3), (32, 8, 128, 1),
+                                              (16, 1, 128, 17), (8, 8, 128, 16), (40, 8, 128, 19), (32, 8, 128, 16)])
 def test_attention_decode_split_equals_oracle_and_single_pass(pos, nh, nkv, hd, nsplit):
     """Split-KV decode attention (long contexts): against the oracle's rope + store + attention and against the single-pass
-    kernel; any number of splits, including more splits than positions."""
+    kernel; any number of splits, including more splits than positions.  head_dim 128 with 16 splits or more runs the matrix-core
+    form (one workgroup per (KV head, split), attention_mfma.hip: 1 / 4 / 5 / 8 / 16 query heads per KV head, chunk boundaries at
+    multiples of 32 positions), everything else the per-query-head walk."""
     r = rng(pos * 3 + nh + nsplit)
     max_seq = 4096 if pos >= 2048 else 2048
     kc, vc = make_cache(r, pos, max_seq, nkv, hd)
@@ -720,8 +723,39 @@ def test_attention_decode_split_equals_oracle_and_single_pass(pos, nh, nkv, hd, 
         caches.append((kcd.numpy(np.uint16), vcd.numpy(np.uint16)))
     assert np.isfinite(outs[0]).all()
     assert np.abs(outs[0] - ref).max() <= 3e-5
-    assert np.abs(outs[0] - outs[1]).max() <= 2e-6                       # same math, different merge order
+    assert np.abs(outs[0] - outs[1]).max() <= 2e-6                       # same math, different merge order (hd 128: q and p as two F16 pieces)
     assert np.array_equal(caches[0][0], caches[1][0]) and np.array_equal(caches[0][1], caches[1][1])   # identical cache rows
+
+
+@pytest.mark.parametrize("pos", [5, 40, 607, 1500])
+@pytest.mark.parametrize("nh,nkv,nsplit", [(32, 8, 8), (32, 8, 16), (64, 8, 32)])
+def test_attention_decode_split_ignores_rows_past_the_position(pos, nh, nkv, nsplit):
+    """Rows past the position (and the position's own row, which the launch writes itself) may hold anything -- NaN, infinities, the
+    rows of an earlier sequence: the matrix-core form loads whole chunks of 32 rows before it knows the position and must mask by
+    selects, never by arithmetic."""
+    hd, max_seq = 128, 2048
+    r = rng(pos * 7 + nh)
+    kc, vc = make_cache(r, pos, max_seq, nkv, hd)
+    junk = np.array([0x7E00, 0xFE00, 0x7C00, 0xFC00, 0x7BFF, 0xFBFF, 0x0001, 0x8000], np.uint16)   # NaN, -NaN, +-inf, +-65504, denormal, -0
+    kc_j, vc_j = kc.copy(), vc.copy()
+    kc_j[pos * nkv * hd:] = junk[r.integers(0, len(junk), kc.size - pos * nkv * hd)]
+    vc_j[pos * nkv * hd:] = junk[r.integers(0, len(junk), vc.size - pos * nkv * hd)]
+    q = r.standard_normal(nh * hd).astype(np.float32)
+    k = r.standard_normal(nkv * hd).astype(np.float32)
+    v = r.standard_normal(nkv * hd).astype(np.float32)
+    scale, theta = float(1 / np.sqrt(hd)), 500000.0
+    outs = []
+    for kc0, vc0 in ((kc, vc), (kc_j, vc_j)):
+        kcd, vcd = DB.from_numpy(kc0), DB.from_numpy(vc0)
+        od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+        ops.attention_decode_split(od, DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v), kcd, vcd,
+                                   DB.from_numpy(np.array([pos], np.int32)), nh, nkv, hd, max_seq, scale, theta, nsplit)
+        outs.append((od.numpy(), kcd.numpy(np.uint16), vcd.numpy(np.uint16)))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0])                         # bit for bit: the junk took no part
+    n_row = (pos + 1) * nkv * hd
+    assert np.array_equal(outs[0][1][:n_row], outs[1][1][:n_row]) and np.array_equal(outs[0][2][:n_row], outs[1][2][:n_row])
+    assert np.array_equal(outs[1][1][n_row:], kc_j[n_row:]) and np.array_equal(outs[1][2][n_row:], vc_j[n_row:])   # later rows untouched
 
 
 # ------------------------------------------------------------------------------- small ops

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Decode attention (ntk_attention_decode_fused: RoPE + KV store + GQA attention, one launch) by context length, at the
 Llama-3.1 8B / 70B head geometries.  KV bytes per launch = 2 * (pos + 1) * n_kv_heads * head_dim * 2 (each KV head read
-once in the algorithmic count).  hipGraph-timed, 64 launches over 8 rotating layer caches.
-usage: python tools/attn_bench.py [--json out.json]"""
+once in the algorithmic count).  hipGraph-timed, 64 launches over rotating layer caches (--layers, default 40: 671 MB of cache at 4096
+positions, past the 256 MB Infinity Cache like the 32 / 80 layers of a model; rounds 1-3 rotated over 8 = 134 MB, which the
+Infinity Cache held).
+usage: python tools/attn_bench.py [--json out.json] [--layers N] [--long]   (--long: only the split regime, 600 .. 4095 positions)"""
 import argparse
 import ctypes as C
 import json
@@ -19,6 +21,10 @@ from ntransformer_amd.ops import DeviceBuffer as DB  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
+    ap.add_argument("--layers", type=int, default=40)
+    ap.add_argument("--long", action="store_true")
+    ap.add_argument("--cases", default=None, help="pos:nsplit,... instead of the built-in table")
+    ap.add_argument("--models", default="8b,70b")
     a = ap.parse_args()
     ops.init(0)
     L = _lib.lib()
@@ -28,7 +34,9 @@ def main():
     stream = L.ntk_stream(0)
     res = []
     for name, nh, nkv, hd in (("8b", 32, 8, 128), ("70b", 64, 8, 128)):
-        max_seq, nl = 4096, 8
+        if name not in a.models.split(","):
+            continue
+        max_seq, nl = 4096, a.layers
         per = nkv * hd
         kc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
         vc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
@@ -37,7 +45,12 @@ def main():
         v = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         out = DB.zeros(nh * hd * 4)
         scratch = DB.zeros(int(L.ntk_attention_split_scratch_bytes(nh, hd, 64)))
-        for pos, nsplit in ((16, 1), (128, 1), (128, 2), (255, 1), (255, 2), (255, 4), (320, 1), (320, 2), (320, 4), (320, 8), (320, 16), (320, 32), (512, 1), (512, 2), (512, 4), (512, 8), (512, 32), (1024, 1), (1024, 4), (1024, 8), (1024, 16), (1024, 32), (2048, 8), (2048, 16), (2048, 32), (4095, 1), (4095, 4), (4095, 8), (4095, 16), (4095, 32), (4095, 64)):
+        cases = ((16, 1), (128, 1), (128, 2), (255, 1), (255, 2), (255, 4), (320, 1), (320, 2), (320, 4), (320, 8), (320, 16), (320, 32), (512, 1), (512, 2), (512, 4), (512, 8), (512, 32), (1024, 1), (1024, 4), (1024, 8), (1024, 16), (1024, 32), (2048, 8), (2048, 16), (2048, 32), (4095, 1), (4095, 4), (4095, 8), (4095, 16), (4095, 32), (4095, 64))
+        if a.long:
+            cases = tuple((p_, n_) for p_ in (600, 1023, 2047, 4095) for n_ in (1, 4, 8, 16, 32) if not (n_ == 1 and p_ > 1023))
+        if a.cases:
+            cases = tuple(tuple(int(t) for t in c.split(":")) for c in a.cases.split(","))
+        for pos, nsplit in cases:
             dpos = DB.from_numpy(np.array([pos], np.int32))
             n = 64
             def launch(i):
