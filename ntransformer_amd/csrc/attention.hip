@@ -861,7 +861,7 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     // cache row read once (attention_mfma.hip).  With fewer splits a wave of that form walks four or more 32-row chunks per 4096 positions
     // and the per-query-head walk below is faster (measured, tools/attn_bench.py over 40 rotating layer caches, 8B geometry, us per layer
     // incl. the combine launch: 1023 positions 8.7 (walk, 8 splits) vs 10.2 (matrix cores, 8) -- 2047: 10.1 vs 11.1 (16) -- 4095: 13.5 vs
-    // 12.75 (32); 70B geometry 4095: 16.5 vs 13.5; inside the engine the forms cross near 2300 positions: profiles/r04_attention_kvhead_form.txt)
+    // 12.75 (32); 70B geometry 4095: 16.5 vs 13.5; inside the engine the forms tie between 2300 and 3300 positions: profiles/r04_attention_kvhead_form.txt)
     static const int kvhead_form = NTK_TUNE_ENV_INT("NTK_ATTN_KVHEAD", 1);   // (tuning builds: 0 = the per-query-head walk, 2 = the matrix-core form at any split count)
     if (head_dim == 128 && n_heads / n_kv_heads <= 16 && ((kvhead_form == 1 && nsplit >= 16) || kvhead_form == 2)) {
         const int rc = ntk::launch_attention_decode_kvhead_mfma(scratch, q, k, v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, max_seq,

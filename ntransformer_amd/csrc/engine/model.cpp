@@ -831,7 +831,7 @@ int Model::enqueue_layers(int first, int last_layer) {
         else
             NT_TRY(ntk_attention_decode_split(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
                                               cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale,
-                                              attention_splits(attn_regime_), attn_scratch_, s));
+                                              attention_splits(attn_regime_, hd), attn_scratch_, s));
         mark(1, false);
         if (tp_world_ > 1) {   // partial sum over this rank's heads -> exchange slot -> hidden += sum over ranks
             NT_TRY(project1(L.wo, tp_slot(), attn_out, nullptr, nullptr, 2));
@@ -1106,7 +1106,7 @@ void Model::pick_attention_regime() {
 int Model::decode_step_fused(bool greedy, bool use_graph) {
     pick_attention_regime();
     if (!use_graph) return enqueue_token(greedy);
-    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? 4 : attn_regime_];
+    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? 3 : attn_regime_];
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
         hipGraph_t g = nullptr;

@@ -53,16 +53,16 @@ public:
     // attention regime by context length (each regime is its own captured graph: the grid of the attention launch is fixed in it).
     // 0: the single-pass kernel, one workgroup per query head, walks the head's cache serially (4.2 us per layer at 16 positions, 7.5 at
     //    512, 30.7 at 4095).  Beyond 544 positions: ntk_attention_decode_split = partial states of `splits` workgroups + a combine launch:
-    // 1: 8 splits -- the per-query-head walk (8.7 us per layer at 1023 positions, 10.1 at 2047);
-    // 2, 3: head_dim 128: 16 splits from 2304 positions, 32 from 3328 -- the matrix-core form, one workgroup per (KV head, split), every
-    //    cache row read once (12.75 us at 4095 where the walk takes 13.5; 70B geometry 13.5 vs 16.5; decode behind a 3900-token prompt
-    //    465 -> 478 tokens/s); other head sizes: the walk with 16 splits from 16384 positions.
+    // 1: 8 splits -- the per-query-head walk (8.7 us per layer at 1023 positions, 10.1 at 2047, 13.5 at 4095);
+    // 2: head_dim 128, from 3072 positions: 32 splits -- the matrix-core form, one workgroup per (KV head, split), every cache row read
+    //    once, one 32-row chunk per wave up to 4096 positions (12.75 us at 4095; 70B geometry 13.5 vs 16.5; decode behind a 3900-token
+    //    prompt 467 -> 482 tokens/s; with 16 splits the two forms tie between 2300 and 3300 positions:
+    //    profiles/r04_attention_kvhead_form.txt); other head sizes: the walk with 16 splits from 16384 positions.
     static int attention_regime(int pos, int head_dim) {
         if (pos < 544) return 0;
-        if (head_dim == 128) return pos < 2304 ? 1 : pos < 3328 ? 2 : 3;
-        return pos < 16384 ? 1 : 2;
+        return pos < (head_dim == 128 ? 3072 : 16384) ? 1 : 2;
     }
-    static int attention_splits(int regime) { return regime <= 1 ? 8 : regime == 2 ? 16 : 32; }
+    static int attention_splits(int regime, int head_dim) { return regime <= 1 ? 8 : head_dim == 128 ? 32 : 16; }
     void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)
@@ -185,7 +185,7 @@ private:
     std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs
     // one captured token per (greedy?, attention regime): regime 0 = single-pass attention, 1 = 8 KV splits, 2 = 16
     // (the persistent form of regime 0 has its own slot, index 3)
-    ihipGraphExec_t* graphs_[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};   // [greedy][attention regime 0..3, 4 = persistent]
+    ihipGraphExec_t* graphs_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [greedy][attention regime 0..2, 3 = persistent]
     int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
     int attn_regime_ = 0;            // regime enqueue_token() emits
     float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention

@@ -206,9 +206,9 @@ def test_long_context_decode_uses_split_attention_and_matches_the_oracle(tmp_pat
     _log_observed({"test": "long_context_decode_vs_oracle", "model": "small Q8_0 (4 layers, hd 128, GQA 4)", "max_abs_err_vs_oracle": observed})
 
 
-def test_decode_beyond_2304_positions_runs_the_matrix_core_attention_and_matches_the_oracle(tmp_path):
-    """From 2304 positions the engine's split attention is the matrix-core form (one workgroup per (KV head, split), 16 splits; 32 from
-    3328 positions: Model::attention_regime, attention_mfma.hip).  Decode across both borders -- 2300..2309 and 3324..3333 -- in the
+def test_decode_beyond_3072_positions_runs_the_matrix_core_attention_and_matches_the_oracle(tmp_path):
+    """From 3072 positions the engine's split attention is the matrix-core form (one workgroup per (KV head, split), 32 splits:
+    Model::attention_regime, attention_mfma.hip).  Decode across the border -- positions 3068..3077 -- and at 3900..3909 in the
     fused and the graph-replayed mode against the ORACLE (reference attention.cu:108-202 over a cache of thousands of rows), teacher
     forced, at the north-star tolerance; the cache rows the engine wrote on the way (K within a half ulp: device vs glibc sin / cos;
     V bit-exact) are checked through the oracle's own cache.  Model: the `small` shape (head_dim 128, GQA 4) with 2 layers and a
@@ -219,7 +219,7 @@ def test_decode_beyond_2304_positions_runs_the_matrix_core_attention_and_matches
     G.make_synthetic_llama(path, shape, "Q8_0", seed=20260926)
     r = np.random.Generator(np.random.Philox(key=[20260926, 4096]))
     observed = {}
-    for start in (2300, 3324):
+    for start in (3068, 3900):
         prompt = [256] + [int(t) for t in r.integers(0, 256, start - 1)]
         cont = [int(t) for t in r.integers(0, 256, 10)]
         m = O.OracleModel(path, 4096)
@@ -241,7 +241,7 @@ def test_decode_beyond_2304_positions_runs_the_matrix_core_attention_and_matches
             err = np.abs(np.stack(lg) - want).max(axis=1)
             observed["%d/%s" % (start, mode)] = float(err.max())
             assert err.max() <= TOL, (start, mode, [float(e) for e in err])
-    _log_observed({"test": "decode_beyond_2304_positions_vs_oracle", "model": "small Q8_0, 2 layers, hd 128, GQA 4, context 4096",
+    _log_observed({"test": "decode_beyond_3072_positions_vs_oracle", "model": "small Q8_0, 2 layers, hd 128, GQA 4, context 4096",
                    "max_abs_err_vs_oracle": observed})
 
 

@@ -341,7 +341,7 @@ def test_depth_70b_width_16_layers(mix):
 def test_depth_8b_q8_0_layerwise_behind_a_704_token_prompt():
     """Layer-wise teacher forcing in the LONG-CONTEXT regime (reference attention.cu:108-202 over hundreds of cache rows): 8B width,
     8 layers, a 704-token prompt run once by the oracle, its cache rows written into the engine (nt_engine_debug_kv_write), then 4
-    decode steps at positions 704..707 -- beyond the switch to the split-KV attention at 672 (Model::attention_regime) -- each layer,
+    decode steps at positions 704..707 -- beyond the switch to the split-KV attention at 544 (Model::attention_regime) -- each layer,
     in each launch mode (1:1 launchers, fused, hipGraph), against the arbiter forced to the engine's own roundings of the rows it
     writes, at the pinned 5e-5 of the layer RMS, and those rows against half an ulp + 2e-5.  Then the same steps once more over a cache
     the ENGINE wrote itself -- 704 rows per layer from its batched prompt pass, the rest from its own decode steps -- with the arbiter
