@@ -197,7 +197,10 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
 
 /* Long-context form of ntk_attention_decode_fused: `nsplit` workgroups share a head (positions interleaved), partial
  * softmax states go through `scratch` (ntk_attention_split_scratch_bytes) and a second launch merges them.  Same
- * arguments and results (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches. */
+ * arguments and results (summation order aside); head_dim 64 / 128 / 256, 16-byte aligned caches.
+ * head_dim 128 with nsplit >= 16 and at most 16 query heads per KV head: one workgroup per (KV head, split) on the F16
+ * matrix cores, every cache row read once (q * scale and the softmax weights enter as two F16 pieces each: <= 2^-22 of
+ * the operand); rows past *d_pos are loaded but take no part whatever they hold. */
 size_t ntk_attention_split_scratch_bytes(int n_heads, int head_dim, int nsplit);
 int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache,
                                void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,
