@@ -8,12 +8,12 @@ cp $S/smoke.log $D/${R}_smoke.log
 cp $S/parity_depth.jsonl $D/${R}_parity_depth.jsonl; cp $S/parity_observed.jsonl $D/${R}_parity_observed.jsonl
 cp $S/bench_default.json $D/${R}_bench_default_8b_q8_0_with_also.json
 cp $S/bench_driver_style_8b_q8_0.json $D/${R}_bench_driver_style_n1_steps20.json
-for K in 8b_q8_0 8b_q4_k_m 70b_q4_k_m 70b_q6_k; do
+for K in 8b_q8_0 8b_q4_k_m 70b_q4_k_m 70b_q6_k 8b_q8_0_ctx3900; do
   [ -f $S/bench_$K.json ] || continue
   cp $S/bench_$K.json $D/${R}_bench_$K.json
   cp $S/trace_$K.json $D/${R}_bench_${K}_profiled.json
   cp $S/summary_trace_$K.txt $D/${R}_rocprofv3_kernel_trace_$K.txt
-  cp $S/pmc_summary_$K.txt $D/${R}_pmc_fetch_write_$K.txt
+  [ -f $S/pmc_summary_$K.txt ] && cp $S/pmc_summary_$K.txt $D/${R}_pmc_fetch_write_$K.txt
 done
 python - $S/pmc_traffic.json $D/pmc_traffic.json <<'PY'
 import json, sys

@@ -29,6 +29,13 @@ for w in "8b Q8_0 32" "8b Q4_K_M 32" "70b Q4_K_M 16" "70b Q6_K 16"; do set -- $w
   timeout 600 python bench.py --model $M --mix $X --steps $ST --warmup 4 --no-cpu-baseline --no-also --prompt-bench 0 > $OUT/bench_$K.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_$K.json
   rm -rf $OUT/trace_$K $OUT/pmc_fetch_$K $OUT/pmc_write_$K
 done
+# the long-context workload (8B Q8_0 behind a 3900-token prompt: split attention on the matrix cores + combine): kernel trace + the same un-profiled
+K=8b_q8_0_ctx3900; read BYTES NL <<< $(python tools/gemv_bytes.py 8b Q8_0)
+prof trace_$K --kernel-trace --stats -d $R/$OUT/trace_$K -o bench -- python $R/bench.py --prompt-len 3900 --steps 16 --warmup 4 --no-cpu-baseline --no-also --prompt-bench 0
+[ -f $OUT/trace_$K/bench_results.db ] || prof trace_$K --kernel-trace --stats -d $R/$OUT/trace_$K -o bench -- python $R/bench.py --prompt-len 3900 --steps 16 --warmup 4 --no-cpu-baseline --no-also --no-graph --prompt-bench 0
+[ -f $OUT/trace_$K/bench_results.db ] && python tools/prof_summary.py $OUT/trace_$K/bench_results.db --gemv-bytes-per-token $BYTES > $OUT/summary_trace_$K.txt && head -12 $OUT/summary_trace_$K.txt
+timeout 600 python bench.py --prompt-len 3900 --steps 64 --warmup 4 --no-cpu-baseline --no-also --prompt-bench 0 > $OUT/bench_$K.json 2>> $OUT/bench.err; cut -c1-200 $OUT/bench_$K.json
+rm -rf $OUT/trace_$K
 ( echo "== raw GGUF blocks (csrc/gemv.hip)"; timeout 300 python tools/gemv_bench.py --dtypes Q8_0,Q4_K,Q6_K; echo "== engine repack, matrix cores (csrc/gemv_rp.hip)"; timeout 300 python tools/gemv_bench.py --rp --dtypes Q4_K,Q5_K,Q6_K ) > $OUT/gemv_bench.txt 2>&1; grep "rp " $OUT/gemv_bench.txt | head -9
 timeout 300 python tools/attn_bench.py > $OUT/attention_by_context.txt 2>&1; grep "^8b" $OUT/attention_by_context.txt | head -8
 timeout 600 python tools/prefill_bench.py --no-kernels --mix Q8_0 --tokens 64,256,1024 --modes 2 > $OUT/prefill_bench.txt 2>&1; timeout 300 python tools/prefill_bench.py --no-kernels --mix Q4_K_M --tokens 64,256,1024 --modes 2 >> $OUT/prefill_bench.txt 2>&1; grep "prompt of" $OUT/prefill_bench.txt

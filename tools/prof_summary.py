@@ -19,7 +19,7 @@ def main():
     last_prefill = max((i for i, r in enumerate(rows) if "attention_kernel<" in r[0]), default=-1)
     dec = rows[last_prefill + 1:]
     # drop everything up to the end of prefill's token (final norm + LM head + first argmax): start at first fused attention
-    first = next((i for i, r in enumerate(dec) if "attention_decode_fused" in r[0]), 0)
+    first = next((i for i, r in enumerate(dec) if "attention_decode_" in r[0]), 0)   # (single pass, split walk or the matrix-core form)
     first_embed = max((i for i in range(first) if "embed_rows" in dec[i][0]), default=0)
     dec = [r for r in dec[first_embed:] if "sclk_" not in r[0]]   # (the clock probes of bench.py are not part of the token)
     n_tokens = sum(1 for r in dec if "embed_rows" in r[0])
