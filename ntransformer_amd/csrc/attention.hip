@@ -500,21 +500,28 @@ __global__ __launch_bounds__(128) void attention_split_combine_kernel(float* __r
                                                                       int hd, int nsplit, int n_kv_heads) {
     // One workgroup per head, ONE memory round trip for everything: thread s requests split s's (m, l), then every thread requests its
     // output element of up to 32 splits at once; the weights exp(m_s - M) go through LDS while those loads are in flight; the sums run in
-    // split order.  (Round 3 walked the splits in two rolled loops -- a dependent round trip per split; round 4's first form took one per
-    // 8 splits: 32 splits cost 4 us more than 8, profiles/r04_attention_by_context.txt.)  Workgroup b serves head
+    // split order.  Every loop over the splits is unrolled in blocks of 32 over tables padded with exact no-ops (weight 0, l 0, m -inf): a
+    // rolled loop pays an LDS round trip per split and sum -- the kernel trace of the 3.9K-context decode showed this launch at 5.1 us,
+    // three quarters of it in three such loops over 32 splits (profiles/r04_rocprofv3_kernel_trace_8b_q8_0_ctx3900.txt, first pass).
+    // (Round 3 walked the splits in two rolled loops of dependent GLOBAL loads.)  Workgroup b serves head
     // (b % n_kv_heads) * group + b / n_kv_heads: on the XCD (b % 8) whose L2 the partial states of that KV head were written through.
-    __shared__ float wsh[1024], lsh[1024];
+    constexpr int B = 32;
+    __shared__ __attribute__((aligned(16))) float wsh[1024], lsh[1024];
     const int group = (int)gridDim.x / n_kv_heads;
     const int head = ((int)blockIdx.x % n_kv_heads) * group + (int)blockIdx.x / n_kv_heads, tid = threadIdx.x;
     const float* ph = part + (size_t)head * nsplit * (hd + 2);
-    float mreg[8], lreg[8];   // nsplit <= 1024 = 8 x 128 threads
+    const int n32 = (nsplit + B - 1) / B * B;   // <= 1024 (host-checked)
+    float mreg[8], lreg[8];                      // thread t: splits t, t + 128 ...
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int s0 = min(tid + 128 * u, nsplit - 1);
         mreg[u] = -INFINITY; lreg[u] = 0.0f;
-        if (128 * u < nsplit) { mreg[u] = ph[(size_t)s0 * (hd + 2) + hd]; lreg[u] = ph[(size_t)s0 * (hd + 2) + hd + 1]; }   // (uniform)
+        if (128 * u < nsplit) {   // (uniform)
+            const int s0 = tid + 128 * u;
+            const float* ps = ph + (size_t)min(s0, nsplit - 1) * (hd + 2) + hd;
+            const float mv = ps[0], lv = ps[1];
+            if (s0 < nsplit) { mreg[u] = mv; lreg[u] = lv; }
+        }
     }
-    constexpr int B = 32;
     const int d0 = min(tid, hd - 1);
     float v0[B];
 #pragma unroll
@@ -522,18 +529,26 @@ __global__ __launch_bounds__(128) void attention_split_combine_kernel(float* __r
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-        if (tid + 128 * u < nsplit) { wsh[tid + 128 * u] = mreg[u]; lsh[tid + 128 * u] = lreg[u]; }
+        if (tid + 128 * u < n32) { wsh[tid + 128 * u] = mreg[u]; lsh[tid + 128 * u] = lreg[u]; }
     __syncthreads();
     float M = -INFINITY;
-    for (int s0 = 0; s0 < nsplit; ++s0) M = fmaxf(M, wsh[s0]);
+    for (int s0 = 0; s0 < n32; s0 += B) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) M = fmaxf(M, wsh[s0 + u]);
+    }
     __syncthreads();
-    for (int s0 = tid; s0 < nsplit; s0 += blockDim.x) wsh[s0] = (wsh[s0] == -INFINITY) ? 0.0f : expf(wsh[s0] - M);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)   // (a split that saw no position: m = -inf, or the walk's finite EMPTY: weight 0 either way)
+        if (tid + 128 * u < n32) wsh[tid + 128 * u] = (mreg[u] == -INFINITY) ? 0.0f : expf(mreg[u] - M);
     __syncthreads();
     float L = 0.0f;
-    for (int s0 = 0; s0 < nsplit; ++s0) L = fmaf(wsh[s0], lsh[s0], L);   // split order, like the output sums
+    for (int s0 = 0; s0 < n32; s0 += B) {
+#pragma unroll
+        for (int u = 0; u < B; ++u) L = fmaf(wsh[s0 + u], lsh[s0 + u], L);   // split order, like the output sums
+    }
     for (int d = tid; d < hd; d += blockDim.x) {
         float o = 0.0f;
-        for (int s0 = 0; s0 < nsplit; s0 += B) {
+        for (int s0 = 0; s0 < n32; s0 += B) {
             float v[B];
             if (s0 == 0 && d == d0) {
 #pragma unroll
@@ -543,8 +558,7 @@ __global__ __launch_bounds__(128) void attention_split_combine_kernel(float* __r
                 for (int u = 0; u < B; ++u) v[u] = ph[(size_t)min(s0 + u, nsplit - 1) * (hd + 2) + d];
             }
 #pragma unroll
-            for (int u = 0; u < B; ++u)
-                if (s0 + u < nsplit) o = fmaf(wsh[s0 + u], v[u], o);
+            for (int u = 0; u < B; ++u) o = fmaf(wsh[s0 + u], v[u], o);   // (past the last split: weight 0 x a finite duplicate)
         }
         output[(size_t)head * hd + d] = o / L;
     }

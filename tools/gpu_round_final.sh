@@ -40,4 +40,14 @@ rm -rf $OUT/trace_$K
 timeout 300 python tools/attn_bench.py > $OUT/attention_by_context.txt 2>&1; grep "^8b" $OUT/attention_by_context.txt | head -8
 timeout 600 python tools/prefill_bench.py --no-kernels --mix Q8_0 --tokens 64,256,1024 --modes 2 > $OUT/prefill_bench.txt 2>&1; timeout 300 python tools/prefill_bench.py --no-kernels --mix Q4_K_M --tokens 64,256,1024 --modes 2 >> $OUT/prefill_bench.txt 2>&1; grep "prompt of" $OUT/prefill_bench.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log; tail -3 $OUT/smoke.log
+# optional same-box A/B against an older build of the library (ntransformer_amd/libntransformer_hip_old.so, a tuning build; not committed)
+if [ -f ntransformer_amd/libntransformer_hip_old.so ]; then
+  SH="8b.qkv_fused,8b.o+res,8b.gate|up+silu,8b.down+res,70b.o+res,70b.down+res"
+  for V in old tune tune_nx; do L=$PWD/ntransformer_amd/libntransformer_hip_$V.so; [ -f $L ] || continue
+    echo "== $V"; NTK_LIB_PATH=$L timeout 200 python tools/gemv_bench.py --rp --dtypes Q4_K --shapes "$SH" 2>&1 | grep "rp " | cut -c1-70
+    NTK_LIB_PATH=$L timeout 200 python bench.py --mix Q4_K_M --no-also --no-cpu-baseline --prompt-bench 0 --steps 64 2>/dev/null | cut -c1-130
+    NTK_LIB_PATH=$L timeout 200 python bench.py --prompt-len 3900 --no-also --no-cpu-baseline --prompt-bench 0 --steps 64 2>/dev/null | cut -c1-130
+  done > $OUT/ab_old_new.txt 2>&1
+  cat $OUT/ab_old_new.txt
+fi
 tail -5 $OUT/bench.err; du -sh $OUT; ls $OUT
