@@ -316,21 +316,16 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
         l_idx += NW;
     };
 
-    // x has landed before the first weights are requested (a CU returns its loads in request order: gemv.hip, prologue)
-#ifndef NTK_RP_NO_XWAIT
+    // The weights are requested right BEHIND x, without waiting for it to land (a CU returns its loads in request order: x, requested
+    // first, still arrives first).  gemv.hip waits for x before its first weight row and gains from it (there a wave's x request is one of
+    // 8 / 16 that the whole workgroup's image needs, and a late wave's request queues behind the early waves' rows); here a wave needs only
+    // its OWN two to seven quads, and the wait was a round trip added to every launch: without it 8B Q4_K_M decodes 675 -> 709-714 tok/s,
+    // Wo 5.02 -> 4.77 us, 70B down 24.5 -> 24.0 (same-box A/B, twice alternated: profiles/r04_gemv_rp_epilogue_experiment.txt).
+    // -DNTK_RP_XWAIT (tuning experiments): the former order.
+#ifdef NTK_RP_XWAIT
 #pragma unroll
     for (int q = 0; q < RP_MAXQ; ++q) asm volatile("" : "+v"(xq[q].x), "+v"(xq[q].y), "+v"(xq[q].z), "+v"(xq[q].w));
 #endif
-    // The residual of the row this thread stores in the epilogue, requested NOW, in front of the weight stream: loaded in the epilogue it
-    // is a dependent L2 round trip at the very end of every Wo / down launch.  Unconditional (a launch without residual reads its own
-    // y, unused): a load under a branch would make the counted waits of the item loop inexact.
-    const bool res = !silu && p.resid != nullptr && sg.wg0 == p.seg[0].wg0;   // the residual belongs to segment 0
-    float res_pre;
-    {
-        const float* rsrc = res ? p.resid : sg.y;
-        const int row = (u0 + (tid >> 4)) * 16 + (tid & 15);
-        res_pre = rsrc[min(row, sg.rows - 1)];
-    }
     // RP_DEPTH items on their way, UNCONDITIONALLY (the s_waitcnt of the steady-state loop is exact only if its entry state is)
     RpItem<DT> ring[RP_DEPTH];
 #pragma unroll
@@ -494,9 +489,7 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     auto tile_sum = [&](const int tl, const int r) {
         const float* q = part + (size_t)tl * NW * 64 + r;
         float t = 0.0f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w)   // (unrolled: the LDS reads of all waves' shares are requested at once; the sum stays in wave order)
-            if (w < NW) t += (q[w * 64] + q[w * 64 + 16]) + (q[w * 64 + 32] + q[w * 64 + 48]);
+        for (int w = 0; w < NW; ++w) t += (q[w * 64] + q[w * 64 + 16]) + (q[w * 64 + 32] + q[w * 64 + 48]);
         return t;
     };
     if (silu) {
@@ -508,11 +501,12 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
             }
         }
     } else {
+        const bool res = p.resid != nullptr && sg.wg0 == p.seg[0].wg0;   // the residual belongs to segment 0
         for (int e = tid; e < ntl * 16; e += (int)blockDim.x) {
             const int tl = e >> 4, r = e & 15, row = (u0 + tl) * 16 + r;
             if (row < sg.rows) {
                 float v = tile_sum(tl, r);
-                if (res) v = (e == tid ? res_pre : p.resid[row]) + v;   // reference elementwise.cu:23-32 (first element: requested in the prologue)
+                if (res) v = p.resid[row] + v;   // reference elementwise.cu:23-32
                 sg.y[row] = v;
             }
         }
