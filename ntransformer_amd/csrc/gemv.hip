@@ -234,8 +234,13 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             // wave (tools/gemv_trace.py: x landed 0.25 us after its request in wave 0, activations in registers 2 us later; round 1
             // had already moved a wave's own x request in front of its weights, worth 3 us per launch).  Ordinary loads: the empty
             // asm "uses" them, so the compiler's own wait sits in front of it.
+            // (-DNTK_GEMV_NO_XWAIT, tuning experiments: the first row right behind the x requests.  The matrix-core GEMV gained 5 % end to
+            //  end from dropping its wait, gemv_rp.hip; here every wave needs the whole workgroup's image, which is why round 2 measured
+            //  the wait as a gain -- untested since the prologue changed: DESIGN.md section 8, item 1.)
+#ifndef NTK_GEMV_NO_XWAIT
             asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
             if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));
+#endif
             issue();   // unconditional (a wave without rows re-reads row 0)
             GV_STAMP(8);   // first weight row requested
             }
