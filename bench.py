@@ -159,7 +159,7 @@ def _gemv_bytes_per_token(spec, mix):
 ACTIVATION_FORMS = {
     "f32": "F32 activations x integer weights, F32 accumulate (csrc/gemv.hip)",
     "int24-block": "K-quant launches of the fused decode path: x as three int8 digit planes of rint(x 2^(22-e)), e per 256-column super-block "
-                   "(<= 2^-23 of the block's largest |x| per term), exact integer dot products on v_mfma_i32_16x16x64_i8 over the engine's "
+                   "(<= 2^-22 of the block's largest |x| per term), exact integer dot products on v_mfma_i32_16x16x64_i8 over the engine's "
                    "load-time repack (csrc/gemv_rp.hip); scales, minima and summation in F32",
 }
 

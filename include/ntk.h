@@ -168,7 +168,7 @@ int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_fe
  * 7.1 step 7 / 8(b) "Ownership": repack buffers belong to the engine object, the 1:1 ntk_gemv above keeps taking raw GGUF).  Q4_K, Q5_K,
  * Q6_K; in_features % 256 == 0 and <= 32768; rows padded to tiles of 16 inside the buffer.  Same integers, same scales (ntk_rp_dequant gives
  * the GGUF dequantisation bit for bit), 1.028 x / 1.023 x / 1.000 x the GGUF bytes.  Arithmetic: x -> per 256-column super-block three
- * signed base-256 digit planes of rint(x 2^(22-e)) (e = exponent of the block's largest |x|: <= 2^-23 of it per term), exact integer dot
+ * signed base-256 digit planes of rint(x 2^(22-e)) (e = exponent of the block's largest |x|: <= 2^-22 of it per term), exact integer dot
  * products per sub-block on v_mfma_i32_16x16x64_i8, the reference's factorisation (gemm.cu:190-244, 297-354, 421-459) around them.
  *   ntk_rp_bytes        size of the repacked form (0: unsupported dtype / shape)
  *   ntk_rp_pack         raw GGUF [rows][in] -> dst (16-byte aligned, ntk_rp_bytes); stream ordered

@@ -263,7 +263,7 @@ template <bool A16> struct Dot<NTK_DT_Q4_K, A16> {   // reference gemm.cu:190-24
 
 // ---- integer activations (round 2): the lane's 64 activations as three byte planes per 32-column sub-block ------------------
 // x_k ~ X_k * 2^(e-22) with X_k = rint(x_k * 2^(22-e)), e = exponent of the sub-block's largest |x| (so |X_k| < 2^22: the error per
-// term, 2^-23 of that maximum, is at the level of the F32 rounding of the sub-block sum it replaces).  X_k in two's complement
+// term, half a unit = at most 2^-22 of that maximum, is at the level of the F32 rounding of the sub-block sum it replaces).  X_k in two's complement
 // = b0 + 256 b1 + 65536 s2 with b0, b1 unsigned bytes and s2 the signed top byte: plane p of four consecutive columns is one dword,
 // and sum_k n_k X_k = udot4(n, b0) + 256 udot4(n, b1) + 65536 sdot4(n, s2) -- v_dot4_u32_u8 / v_dot4_i32_i8 issue at the rate of
 // the byte converts (profiles/r02_valu_issue_rates.txt), so 8 weights cost 3 mask operations + 6 dot instructions instead of 2 masks

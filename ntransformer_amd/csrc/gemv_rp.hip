@@ -6,7 +6,7 @@
 //      y[r] = sum_sb  d * ( sum_j sc_j * sum_{k in j} q_k x_k )  -  dmin * sum_j m_j * sum_{k in j} x_k          (Q4_K / Q5_K)
 //      y[r] = sum_sb  d * ( sum_j sc_j * sum_{k in j} q_k x_k )  -  32 d * sum_j sc_j * sum_{k in j} x_k          (Q6_K)
 // with the inner sums as EXACT integer dot products: x is converted once per workgroup into three signed base-256 digit planes
-// X_k = rint(x_k 2^(22-e)) (e = exponent of the largest |x| of the 256-column super-block; error per term <= 2^-23 of that maximum,
+// X_k = rint(x_k 2^(22-e)) (e = exponent of the largest |x| of the 256-column super-block; error per term <= half a unit, at most 2^-22 of that maximum,
 // the level of the F32 rounding it replaces), and v_mfma_i32_16x16x64_i8 multiplies 16 weight rows x 64 columns by the digit
 // planes of the two (four) sub-blocks the 64 columns span.  Why: the VALU decoders of gemv.hip issue ~250 vector instructions per
 // 4096 weights and are bound by that (84 % VALU issue, 0.51-0.67 of HBM on the long launches, profiles/r03_gemv_microbench.txt);

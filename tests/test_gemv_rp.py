@@ -14,6 +14,7 @@ from ntransformer_amd import _lib
 from ntransformer_amd import gguf as G
 from ntransformer_amd import ops
 from ntransformer_amd.ops import DeviceBuffer as DB
+from oracle import int_activation as IA
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -54,30 +55,8 @@ def test_mfma_i8_lane_maps():
 
 
 def expected_image(x, nsub):
-    """numpy restatement of rp_convert_quad: digit planes, zero plane, sub-block-sum digits, 2^(e-22) per super-block"""
-    in_f = x.size
-    nsb = in_f // 256
-    img = np.zeros(4 * in_f + 68 * nsb, np.uint8)
-    inv = np.zeros(nsb, np.float32)
-    for sb in range(nsb):
-        v = x[256 * sb:256 * sb + 256].astype(np.float32)
-        am = np.float32(np.abs(v).max())
-        e = int(np.frexp(am)[1]) if am > 0 else 0
-        e = max(e, -100)
-        X = np.rint(v.astype(np.float64) * 2.0 ** (22 - e)).astype(np.int64)
-        assert np.abs(X).max() <= 2 ** 22
-        Y = (X + 0x808080) ^ 0x808080
-        for p in range(3):
-            img[p * in_f + 256 * sb:p * in_f + 256 * sb + 256] = ((Y >> (8 * p)) & 0xFF).astype(np.uint8)
-        w = 256 // nsub
-        S = X.reshape(nsub, w).sum(1)
-        YS = (S + 0x80808080) ^ 0x80808080
-        for dg in range(4):
-            base = 4 * in_f + 64 * sb + 16 * dg
-            img[base:base + nsub] = ((YS >> (8 * dg)) & 0xFF).astype(np.uint8)
-        inv[sb] = np.float32(2.0 ** (e - 22))
-    img[4 * in_f + 64 * nsb:] = inv.view(np.uint8)
-    return img
+    """numpy restatement of rp_convert_quad (oracle/int_activation.py; its own CPU tests: tests/test_int_activation_cpu.py)"""
+    return IA.digit_image(x, nsub)
 
 
 @pytest.mark.parametrize("nsub", [8, 16])

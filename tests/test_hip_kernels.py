@@ -410,7 +410,7 @@ def test_gemv_integer_activation_form(qname, out_f, in_f, norm, resid, silu, out
     v_dot4; gemv_core.hip.h XInt / DotI) -- normally taken only by launches of >= 48 MiB -- asked for by the call (ntk_debug_gemv_fused_form) and
     compared with the oracle at the GEMV's tolerance: plain, RMSNorm prologue, residual epilogue, gate|up + SiLU.  `outliers`: a few
     channels 1000 x the rest, the shape real Llama activations have and the synthetic ones lack (no checkpoint exists offline): the
-    31 neighbours of an outlier in its sub-block keep 2^-23 of the OUTLIER as their error, which is what the form trades."""
+    31 neighbours of an outlier in its sub-block keep up to 2^-22 of the OUTLIER as their error, which is what the form trades."""
     gt = QUANT[qname]
     dt = G.GGML_TO_DT[gt]
     r = rng(out_f + in_f + 3 * norm + 5 * resid + 7 * silu + gt)

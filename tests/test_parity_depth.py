@@ -364,7 +364,7 @@ def test_depth_8b_q4_k_m_outlier_channels():
     checkpoint exists offline).  This model gets them: eight channels of every RMSNorm weight vector (F32 tensors of the GGUF) x 60, so
     that the inputs of every Q|K|V, gate|up and LM-head launch carry outliers.  Since round 4 every K-quant launch of the fused decode
     path is the matrix-core GEMV over the engine's repack (csrc/gemv_rp.hip): digit planes with ONE exponent per 256-column super-block --
-    exactly what outliers stress (the 255 neighbours of an outlier keep 2^-23 of the OUTLIER as their error) -- and the prompt goes through
+    exactly what outliers stress (the 255 neighbours of an outlier keep up to 2^-22 of the OUTLIER as their error) -- and the prompt goes through
     the two-piece FP16 GEMM.  8B
     width, Q4_K_M mix, 6 layers, the same bars as the other depth tests.  (End to end such a model amplifies F16 rounding flips --
     0.017 of a logit RMS of 5 with or without the integer form, same box -- which is why it is judged layer by layer and against the
