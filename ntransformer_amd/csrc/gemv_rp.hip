@@ -178,6 +178,16 @@ struct RpSeg {
     int wg0, nwg;        // workgroups [wg0, wg0 + nwg) of the grid work on this segment
     int kb, krem;        // workgroup wl owns kb + (wl < krem) tiles (pairs of tiles in the SiLU form) from wl * kb + min(wl, krem)
 };
+// Timeline of a launch (trace builds only, make trace: -DNTK_GEMV_TRACE; tools/gemv_trace.py --rp): thread 0 of every workgroup stamps the
+// constant 100 MHz clock at the phase boundaries of rp_body; read back with ntk_debug_rp_trace().
+#ifdef NTK_GEMV_TRACE
+constexpr int RT_SLOTS = 64, RT_WG = 512, RT_EV = 12;
+__device__ unsigned long long g_rp_trace[RT_SLOTS][RT_WG][RT_EV];
+#define RP_STAMP(ev) do { asm volatile("" ::: "memory"); rp_t[ev] = __builtin_amdgcn_s_memrealtime(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define RP_STAMP(ev) do {} while (0)
+#endif
+
 struct RpParams {
     RpSeg seg[3];
     int nseg, nseg_a;    // segments [0, nseg_a) have the kernel's format A, the rest format B
@@ -187,6 +197,9 @@ struct RpParams {
     float eps;
     const float* resid;
     int silu_pair;       // seg[0] = gate, seg[1] = up (same shape, same format); their workgroups are seg[0]'s
+#ifdef NTK_GEMV_TRACE
+    int trace_slot;      // trace builds: which record of g_rp_trace this launch fills
+#endif
 };
 
 // LDS: [0, 4 in) digit planes 0..2 + a plane of zeros | sub-block-sum digits, 64 B per super-block | 2^(e-22) per super-block |
@@ -258,6 +271,10 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     const int NW = (int)(blockDim.x >> 6);
     const int in = p.in, nsb = p.nsb;
     const int bid = (int)blockIdx.x;
+#ifdef NTK_GEMV_TRACE
+    unsigned long long rp_t[RT_EV] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RP_STAMP(0);   // entry
 
     // ---- x (and the norm weights) first: everything below runs under their latency ----
     float4 xq[RP_MAXQ], wq[RP_MAXQ];
@@ -328,8 +345,10 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
 #endif
     // RP_DEPTH items on their way, UNCONDITIONALLY (the s_waitcnt of the steady-state loop is exact only if its entry state is)
     RpItem<DT> ring[RP_DEPTH];
+    RP_STAMP(1);   // x requested, row bookkeeping done
 #pragma unroll
     for (int u = 0; u < RP_DEPTH; ++u) load_item(ring[u]);
+    RP_STAMP(2);   // first items requested
 
     // ---- prologue: RMSNorm (reference rmsnorm.cu:16-70), digit planes ----
     float* red = reinterpret_cast<float*>(smem + 4 * (size_t)in + 68 * (size_t)nsb);
@@ -377,6 +396,7 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
         }
     }
     if (!priv) __syncthreads();
+    RP_STAMP(3);   // x landed, (RMSNorm,) digit image of the first quad(s) written
 
     // ---- lane constants of the A operands (digit planes) ----
     const int m16 = lane & 15;            // entry m = 4 jj + p of the first MFMA operand
@@ -476,14 +496,17 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
 #pragma unroll
         for (int u = 0; u < RP_DEPTH; ++u) { process(ring[u]); load_item(ring[u]); }
     }
+    RP_STAMP(4);   // steady-state loop done (all items but the last 2 RP_DEPTH of wave 0)
 #pragma unroll
     for (int u = 0; u < RP_DEPTH; ++u)
         if (p_idx < N) { process(ring[u]); if (p_idx + (RP_DEPTH - 1) * NW < N) load_item(ring[u]); }
 #pragma unroll
     for (int u = 0; u < RP_DEPTH; ++u)
         if (p_idx < N) process(ring[u]);
+    { asm volatile("" :: "v"(racc)); RP_STAMP(5); }   // wave 0's last item accumulated
     while (p_tl < ntl) flush();
     __syncthreads();
+    RP_STAMP(6);   // every wave's share is in LDS
 
     // ---- row sums of the workgroup's tiles: the waves' shares in wave order (and the four sub-block lanes of a row), epilogue, store ----
     auto tile_sum = [&](const int tl, const int r) {
@@ -511,6 +534,13 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
             }
         }
     }
+    RP_STAMP(7);   // results stored (requests issued)
+#ifdef NTK_GEMV_TRACE
+    if (tid == 0 && bid < RT_WG) {
+        rp_t[8] = (unsigned long long)N; rp_t[9] = (unsigned long long)NW;
+        for (int e = 0; e < RT_EV; ++e) g_rp_trace[p.trace_slot & (RT_SLOTS - 1)][bid][e] = rp_t[e];
+    }
+#endif
 }
 
 template <int DTA, int DTB, bool NORM>
@@ -749,6 +779,10 @@ int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in
 #ifdef NTK_TUNE
     g_rp_last_nw = plan.nw; g_rp_last_grid = plan.grid; g_rp_last_lds = (int)plan.lds;
 #endif
+#ifdef NTK_GEMV_TRACE
+    static int trace_counter = 0;
+    p.trace_slot = trace_counter++;
+#endif
     hipLaunchKernelGGL(fn, dim3((unsigned)plan.grid), dim3((unsigned)(64 * plan.nw)), plan.lds, resolve_stream(stream), p);
     return last_launch_status();
 }
@@ -763,6 +797,12 @@ int ntk_gemv_rp(float* y, const void* rp, const float* x, int out_features, int 
 NTK_EXTRA_API void ntk_tune_rp_plan(int nw, int per_cu) { ntk::g_rp_force_nw = nw; ntk::g_rp_force_per_cu = per_cu; }
 NTK_EXTRA_API void ntk_tune_rp_waves(int nw) { ntk_tune_rp_plan(nw, 0); }
 NTK_EXTRA_API void ntk_tune_rp_last_plan(int* out3) { out3[0] = ntk::g_rp_last_nw; out3[1] = ntk::g_rp_last_grid; out3[2] = ntk::g_rp_last_lds; }
+#endif
+
+#ifdef NTK_GEMV_TRACE
+NTK_EXTRA_API int ntk_debug_rp_trace(unsigned long long* out, size_t n) {   // n <= RT_SLOTS * RT_WG * RT_EV
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ntk::g_rp_trace), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -3;
+}
 #endif
 
 int ntk_debug_rp_prologue(uint8_t* out, const float* x, const float* norm_w, float eps, int in_features, int nsub, int nwaves, void* stream) {
