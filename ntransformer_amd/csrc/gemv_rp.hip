@@ -503,7 +503,10 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
 #pragma unroll
     for (int u = 0; u < RP_DEPTH; ++u)
         if (p_idx < N) process(ring[u]);
-    { asm volatile("" :: "v"(racc)); RP_STAMP(5); }   // wave 0's last item accumulated
+#ifdef NTK_GEMV_TRACE
+    asm volatile("" :: "v"(racc));
+#endif
+    RP_STAMP(5);   // wave 0's last item accumulated
     while (p_tl < ntl) flush();
     __syncthreads();
     RP_STAMP(6);   // every wave's share is in LDS
