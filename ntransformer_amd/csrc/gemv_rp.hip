@@ -549,6 +549,20 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
 template <int DTA, int DTB, bool NORM>
 __global__ __launch_bounds__(1024) void rp_gemv_kernel(const RpParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rp_smem[];
+#ifdef NTK_RP_KERNARG_TOUCH
+    {
+        // (tuning experiments, untested on hardware -- DESIGN.md section 8, item 2.)  RpParams is four kernel-argument cache lines; hipcc
+        // fetches x / in (line 2-3) first and the segment table (line 0) only in front of the first weight request: a second scalar-cache
+        // miss between the x requests and the weight requests (ISA of rp_gemv_kernel<Q4_K, Q4_K, false>: s_waitcnt lgkmcnt(0) at
+        // instruction 120, first weight load at 362).  gemv.hip touches all its lines at once and gains 0.7 % from it.
+        const auto* ka = __builtin_amdgcn_kernarg_segment_ptr();
+        unsigned d0, d1, d2, d3;
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     if constexpr (DTA == DTB) {
         rp_body<DTA, NORM>(p, 0, p.nseg, rp_smem);
     } else {
