@@ -507,6 +507,17 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     asm volatile("" :: "v"(racc));
 #endif
     RP_STAMP(5);   // wave 0's last item accumulated
+#ifdef NTK_RP_RESID_LATE
+    // (tuning experiments, untested on hardware -- DESIGN.md section 8, item 2.)  The residual of the row this thread stores, requested
+    // HERE: behind the item loop (requested in the prologue it made hipcc's counted waits of the loop conservative and lost 3 %,
+    // profiles/NEGATIVE_RESULTS.md section 6), in front of the flush and the barrier, whose time the L2 round trip then overlaps.
+    float res_late = 0.0f;
+    {
+        const bool res_l = !silu && p.resid != nullptr && sg.wg0 == p.seg[0].wg0;
+        const int row_l = (u0 + (tid >> 4)) * 16 + (tid & 15);
+        if (res_l && tid < ntl * 16 && row_l < sg.rows) res_late = p.resid[row_l];
+    }
+#endif
     while (p_tl < ntl) flush();
     __syncthreads();
     RP_STAMP(6);   // every wave's share is in LDS
@@ -532,7 +543,11 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
             const int tl = e >> 4, r = e & 15, row = (u0 + tl) * 16 + r;
             if (row < sg.rows) {
                 float v = tile_sum(tl, r);
+#ifdef NTK_RP_RESID_LATE
+                if (res) v = (e == tid ? res_late : p.resid[row]) + v;
+#else
                 if (res) v = p.resid[row] + v;   // reference elementwise.cu:23-32
+#endif
                 sg.y[row] = v;
             }
         }
