@@ -235,8 +235,8 @@ __device__ __forceinline__ void gemv_quant_body(const GemvParams& p, const int b
             // had already moved a wave's own x request in front of its weights, worth 3 us per launch).  Ordinary loads: the empty
             // asm "uses" them, so the compiler's own wait sits in front of it.
             // (-DNTK_GEMV_NO_XWAIT, tuning experiments: the first row right behind the x requests.  The matrix-core GEMV gained 5 % end to
-            //  end from dropping its wait, gemv_rp.hip; here every wave needs the whole workgroup's image, which is why round 2 measured
-            //  the wait as a gain -- untested since the prologue changed: DESIGN.md section 8, item 1.)
+            //  end from dropping its wait, gemv_rp.hip; here every wave needs the whole workgroup's image.  Round 5, same-box A/B
+            //  alternated three times: 8B Q8_0 553.6 -> 546.8 tok/s, Wo 5.6 -> 6.5 us -- the wait stays.  profiles/r05_ab_variants.txt)
 #ifndef NTK_GEMV_NO_XWAIT
             asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
             if constexpr (NORM) asm volatile("" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]));

@@ -507,10 +507,11 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
     asm volatile("" :: "v"(racc));
 #endif
     RP_STAMP(5);   // wave 0's last item accumulated
-#ifdef NTK_RP_RESID_LATE
-    // (tuning experiments, untested on hardware -- DESIGN.md section 8, item 2.)  The residual of the row this thread stores, requested
-    // HERE: behind the item loop (requested in the prologue it made hipcc's counted waits of the loop conservative and lost 3 %,
-    // profiles/NEGATIVE_RESULTS.md section 6), in front of the flush and the barrier, whose time the L2 round trip then overlaps.
+#ifndef NTK_RP_RESID_EPILOGUE
+    // The residual of the row this thread stores, requested HERE: behind the item loop (requested in the prologue it made hipcc's counted
+    // waits of the loop conservative and lost 3 %, profiles/NEGATIVE_RESULTS.md section 6), in front of the flush and the barrier, whose
+    // time the L2 round trip then overlaps.  Round 5, same-box A/B alternated three times (profiles/r05_ab_variants.txt): +0.4 % alone,
+    // +2.3 % together with the kernel-argument touch below (8B Q4_K_M 711 -> 728 tok/s).  -DNTK_RP_RESID_EPILOGUE: the former order.
     float res_late = 0.0f;
     {
         const bool res_l = !silu && p.resid != nullptr && sg.wg0 == p.seg[0].wg0;
@@ -543,8 +544,8 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
             const int tl = e >> 4, r = e & 15, row = (u0 + tl) * 16 + r;
             if (row < sg.rows) {
                 float v = tile_sum(tl, r);
-#ifdef NTK_RP_RESID_LATE
-                if (res) v = (e == tid ? res_late : p.resid[row]) + v;
+#ifndef NTK_RP_RESID_EPILOGUE
+                if (res) v = (e == tid ? res_late : p.resid[row]) + v;   // reference elementwise.cu:23-32
 #else
                 if (res) v = p.resid[row] + v;   // reference elementwise.cu:23-32
 #endif
@@ -564,12 +565,13 @@ __device__ __forceinline__ void rp_body(const RpParams& p, const int seg_lo, con
 template <int DTA, int DTB, bool NORM>
 __global__ __launch_bounds__(1024) void rp_gemv_kernel(const RpParams p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t rp_smem[];
-#ifdef NTK_RP_KERNARG_TOUCH
+#ifndef NTK_RP_NO_KERNARG_TOUCH
     {
-        // (tuning experiments, untested on hardware -- DESIGN.md section 8, item 2.)  RpParams is four kernel-argument cache lines; hipcc
-        // fetches x / in (line 2-3) first and the segment table (line 0) only in front of the first weight request: a second scalar-cache
-        // miss between the x requests and the weight requests (ISA of rp_gemv_kernel<Q4_K, Q4_K, false>: s_waitcnt lgkmcnt(0) at
-        // instruction 120, first weight load at 362).  gemv.hip touches all its lines at once and gains 0.7 % from it.
+        // RpParams is four kernel-argument cache lines; hipcc fetches x / in (line 2-3) first and the segment table (line 0) only in front
+        // of the first weight request: a second scalar-cache miss between the x requests and the weight requests (ISA of
+        // rp_gemv_kernel<Q4_K, Q4_K, false>: s_waitcnt lgkmcnt(0) at instruction 120, first weight load at 362).  Touching all four lines
+        // at once: 8B Q4_K_M 711 -> 726 tok/s (+2.0 %, round 5 same-box A/B alternated three times, profiles/r05_ab_variants.txt);
+        // gemv.hip does the same and gains 0.7 % from it.
         const auto* ka = __builtin_amdgcn_kernarg_segment_ptr();
         unsigned d0, d1, d2, d3;
         asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80\n\ts_load_dword %3, %4, 0xc0\n\t"
