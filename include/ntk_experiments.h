@@ -68,6 +68,19 @@ int  ntk_persistent_grid(void* plan);
 /* debugging aid: per-operator timestamps of two workgroups (see decode_persistent.hip); returns the operator count */
 int  ntk_persistent_debug(void* plan, int enable, unsigned long long* out, int cap_ops);
 
+/* Round 5: the same operator table as ONE persistent launch on the loader / consumer engine (csrc/layer_engine.hip): per CU one LDS-DMA
+ * loader wave that streams the CU's weight rows into a ring of 16 KiB slots and runs ahead across operator edges, three consumer waves that
+ * decode out of the ring, activations handed between CUs as 8-byte {tag, value} granules (one sc1 store each, gathered by sweeping; no
+ * flag, no drain, no grid barrier).  Q8_0 matrices with rows <= 16 KiB, RMSNorm inputs <= 4096 columns, head_dim 64 / 128, the single-pass
+ * attention regime; anything else: NTK_E_SHAPE / NTK_E_DTYPE from plan_create and the caller keeps the launch path.  `wait` / `arrive`
+ * of ntk_pop are ignored (the dependencies follow from the vectors the operators name). */
+int  ntk_layer_engine_plan_create(const ntk_pop* ops, int nops, void** plan_out);
+void ntk_layer_engine_plan_destroy(void* plan);
+int  ntk_layer_engine_launch(void* plan, const int* d_pos, void* stream);          /* memset of the granules + the kernel; capturable */
+int  ntk_layer_engine_error(void* plan, unsigned* code_out);                        /* after a synchronise; code = 1 + op + 4096 what + 65536 cu */
+int  ntk_layer_engine_info(void* plan, int* geometry4);                             /* grid, ring slots, LDS bytes, operators */
+int  ntk_layer_engine_debug(void* plan, int enable, unsigned long long* out);       /* out [grid][nops][8] stamps of the 100 MHz clock */
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,7 +92,8 @@ int  nt_engine_max_context(nt_engine_t e);
 /* which form the fused decode step takes at the current position: "fused (5 launches/layer)", or (EXPERIMENTS=1 builds with the
  * "persistent" option on) "persistent (...)" */
 const char* nt_engine_decode_path(nt_engine_t e);
-void* nt_engine_persistent_plan(nt_engine_t e);   /* plan handle for ntk_persistent_debug; NULL outside EXPERIMENTS=1 builds */
+void* nt_engine_persistent_plan(nt_engine_t e);   /* plan handle for ntk_persistent_debug / ntk_layer_engine_debug; NULL outside EXPERIMENTS=1 builds */
+int   nt_engine_persistent_kind(nt_engine_t e);   /* 0 none, 1 decode_persistent.hip, 2 layer_engine.hip ("persistent" = "2") */
 /* Tensor-parallel decoding over `world` GPUs, one engine (normally one process) per rank -- SURVEY 8(f) rank 4, no reference
  * counterpart.  nt_engine_tp_configure BEFORE load: the engine then keeps rows [rank/world) of Wq/Wk/Wv/gate/up (whole heads) and
  * the matching columns of Wo/down; n_heads, n_kv_heads and the FFN width must divide by `world`, column slices must be whole

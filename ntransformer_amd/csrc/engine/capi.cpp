@@ -56,7 +56,7 @@ int nt_engine_set_option(nt_engine_t e, const char* key, const char* value) {
     else if (k == "f16_prefill" || k == "bf16_prefill") E(e)->model().set_bf16_prefill(on);   // (the round-2 name stays accepted)
     else if (k == "fuse_attention") E(e)->model().set_fuse_attention(on);
     else if (k == "repack") E(e)->model().set_repack(on);
-    else if (k == "persistent") { E(e)->options().persistent = on; E(e)->model().set_persistent(on); }
+    else if (k == "persistent") { E(e)->options().persistent = on; E(e)->model().set_persistent(atoi(value)); }   // 1: decode_persistent.hip, 2: layer_engine.hip
     else if (k == "synth_threads") E(e)->options().synth_threads = atoi(value);
     else return NTK_E_SHAPE;
     return NTK_OK;
@@ -152,6 +152,7 @@ int nt_engine_debug_kv_write(nt_engine_t e, int layer, int pos0, int n, const ui
 }
 
 void* nt_engine_persistent_plan(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().persistent_plan() : nullptr; }
+int nt_engine_persistent_kind(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().persistent_kind() : 0; }
 const char* nt_engine_decode_path(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().decode_path() : ""; }
 
 // ---- tensor parallelism (one engine per rank; csrc/tp.hip) ---------------------------------------------------------------

@@ -35,7 +35,7 @@ void Model::free_all() {
             gx = nullptr;
         }
 #ifdef NTK_EXPERIMENTS
-    if (persistent_plan_) ntk_persistent_plan_destroy(persistent_plan_);
+    if (persistent_plan_) { if (persistent_kind_ == 2) ntk_layer_engine_plan_destroy(persistent_plan_); else ntk_persistent_plan_destroy(persistent_plan_); }
 #endif
     persistent_plan_ = nullptr;
     persistent_on_ = false;
@@ -306,7 +306,7 @@ int Model::finish_load(int /*max_context*/) {
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
     if (repack_) NT_TRY(repack_all());
-    if (persistent_wanted_) set_persistent(true);
+    if (persistent_wanted_) set_persistent(persistent_wanted_);
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
     fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights%s)\nFree VRAM: %.1f GB\n",
@@ -653,7 +653,7 @@ int Model::enqueue_token(bool greedy) {
     if (est != NTK_OK && est != NTK_E_DTYPE) return est;
 #ifdef NTK_EXPERIMENTS
     if (use_persistent_now()) {   // every layer and the LM head in one launch
-        NT_TRY(ntk_persistent_launch(persistent_plan_, d_pos_, s));
+        NT_TRY(persistent_kind_ == 2 ? ntk_layer_engine_launch(persistent_plan_, d_pos_, s) : ntk_persistent_launch(persistent_plan_, d_pos_, s));
         if (greedy) NT_TRY(ntk_argmax_advance(logits_, cfg_.vocab_size, d_token_, h_token_, h_ring_, d_pos_, argmax_scratch_, s));
         else NT_TRY(ntk_advance_pos(d_pos_, s));
         return NTK_OK;
@@ -949,19 +949,30 @@ bool Model::use_persistent_now() const {
     return persistent_plan_ && persistent_on_ && attn_regime_ == 0 && !prof_;
 }
 
-void Model::set_persistent(bool on) {
+void Model::set_persistent(int level) {   // 0 off, 1 the round-2 token kernel (decode_persistent.hip), 2 the loader / consumer engine (layer_engine.hip)
+    const bool on = level != 0;
     persistent_on_ = false;
-    persistent_wanted_ = on;   // (asked before the load: finish_load() applies it)
+    persistent_wanted_ = level;   // (asked before the load: finish_load() applies it)
 #ifndef NTK_EXPERIMENTS
-    if (on) fprintf(stderr, "note: the persistent token kernel is an EXPERIMENTS=1 build option (libntransformer_hip_exp.so); this library decodes with fused launches\n");
+    if (on) fprintf(stderr, "note: the persistent token kernels are an EXPERIMENTS=1 build option (libntransformer_hip_exp.so); this library decodes with fused launches\n");
+#else
+    if (persistent_plan_ && persistent_kind_ != (level == 2 ? 2 : 1)) {   // the other kernel's plan: drop it and its captured graphs
+        (void)sync();
+        for (auto& row : graphs_) { if (row[3]) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(row[3])); row[3] = nullptr; }
+        if (persistent_kind_ == 2) ntk_layer_engine_plan_destroy(persistent_plan_); else ntk_persistent_plan_destroy(persistent_plan_);
+        persistent_plan_ = nullptr;
+    }
 #endif
     if (!on || tp_world_ != 1 || layers_.empty()) return;
-    if (!persistent_plan_) (void)build_persistent_plan();   // built on first use (EXPERIMENTS=1 builds only): it allocates device memory
+    if (!persistent_plan_) (void)build_persistent_plan(level == 2 ? 2 : 1);   // built on first use (EXPERIMENTS=1 builds only): it allocates device memory
     persistent_on_ = persistent_plan_ != nullptr;
 }
 
 // what decode_step_fused() emits at the CURRENT position (the persistent form covers the single-pass attention regime only)
 const char* Model::decode_path() const {
+    if (persistent_plan_ && persistent_on_ && persistent_kind_ == 2)
+        return attn_regime_ == 0 ? "persistent layer engine (1 launch per token: loader / consumer waves, granule hand-offs; fused launches beyond the single-pass attention regime)"
+                                 : "fused (5 launches/layer; persistent layer engine below the split-attention regime)";
     if (persistent_plan_ && persistent_on_)
         return attn_regime_ == 0 ? "persistent (1 launch per token in the single-pass attention regime, fused launches beyond)"
                                  : "fused (5 launches/layer; persistent below the split-attention regime)";
@@ -987,7 +998,15 @@ int Model::check_persistent() {
     }
     if (!persistent_plan_ || !persistent_on_) return NTK_OK;
     int op = -1;
-    const int st = ntk_persistent_error(persistent_plan_, &op);
+    int st;
+    if (persistent_kind_ == 2) {
+        unsigned code = 0;
+        st = ntk_layer_engine_error(persistent_plan_, &code);
+        op = code ? (int)((code - 1u) & 4095u) : -1;
+        if (st != NTK_OK) fprintf(stderr, "layer engine: error word %u (operator %d, wait kind %u, CU %u)\n", code, op, ((code - 1u) >> 12) & 15u, (code - 1u) >> 16);
+    } else {
+        st = ntk_persistent_error(persistent_plan_, &op);
+    }
     if (st != NTK_OK) {
         persistent_on_ = false;
         err_ = "persistent decode kernel: a bounded grid wait gave up at operator " + std::to_string(op) + "; falling back to launches";
@@ -1001,7 +1020,7 @@ int Model::check_persistent() {
 
 #ifdef NTK_EXPERIMENTS
 // The token's operator table for the persistent kernel: exactly the sequence enqueue_token() launches.
-int Model::build_persistent_plan() {
+int Model::build_persistent_plan(int kind) {
     const int H = cfg_.hidden_size, I = cfg_.intermediate_size, hd = cfg_.head_dim, nh = cfg_.n_heads, nkv = cfg_.n_kv_heads;
     const int qd = nh * hd, kvd = nkv * hd;
     if (hd != 64 && hd != 128) return NTK_E_SHAPE;
@@ -1091,10 +1110,12 @@ int Model::build_persistent_plan() {
         gemv_group(ws, ys, 1, hidden_, &output_norm_, nullptr, true, false, true);
     }
     if (!ok) return NTK_E_DTYPE;
+    persistent_kind_ = kind;
+    if (kind == 2) return ntk_layer_engine_plan_create(ops.data(), (int)ops.size(), &persistent_plan_);
     return ntk_persistent_plan_create(ops.data(), (int)ops.size(), &persistent_plan_);
 }
 #else
-int Model::build_persistent_plan() { return NTK_E_SHAPE; }
+int Model::build_persistent_plan(int) { return NTK_E_SHAPE; }
 #endif
 
 void Model::pick_attention_regime() {

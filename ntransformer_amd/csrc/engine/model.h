@@ -90,7 +90,8 @@ public:
     // One decode token as ONE persistent launch (csrc/decode_persistent.hip) instead of 5 launches per layer.  On by default
     // when the model qualifies (quantised matrices, head_dim 64 / 128); short contexts only (single-pass attention regime),
     // longer ones keep the launch path.  Turned off for good if the kernel ever reports a bounded wait that gave up.
-    void set_persistent(bool on);   // EXPERIMENTS=1 builds only; otherwise stays off
+    void set_persistent(int level);   // 0 off, 1 decode_persistent.hip, 2 layer_engine.hip (round 5); EXPERIMENTS=1 builds only, otherwise stays off
+    int persistent_kind() const { return persistent_plan_ ? persistent_kind_ : 0; }
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
     // Decode GEMVs of the K-quant matrices from the load-time repack (ntk_gemv_rp_fused) instead of the raw GGUF blocks (ntk_gemv_fused).
     // The repack is made at load unless the option was switched off BEFORE the load; the switch itself works at any time.
@@ -146,7 +147,7 @@ private:
     int layers_1to1(int T, int start_pos, int first, int last);   // the layer loop of forward()
     void prof_mark(int cls, bool begin);
     bool use_persistent_now() const;
-    int build_persistent_plan();      // the same operator sequence as a table for ntk_persistent_launch (nullptr plan if unsupported)
+    int build_persistent_plan(int kind);   // the same operator sequence as a table for ntk_persistent_launch / ntk_layer_engine_launch (nullptr plan if unsupported)
 
     ModelConfig cfg_;
     GgufVocab vocab_;
@@ -207,7 +208,8 @@ private:
     ModelConfig cfg_full_;           // the unsliced configuration (cfg_ holds the local head / FFN counts)
     void* persistent_plan_ = nullptr;
     bool persistent_on_ = false;   // opt-in until it beats the launch path on the bench (set_persistent / "persistent" option)
-    bool persistent_wanted_ = false;   // the option as last set (re-applied after a load)
+    int persistent_wanted_ = 0;    // the option as last set (re-applied after a load)
+    int persistent_kind_ = 1;      // which kernel persistent_plan_ belongs to
 };
 
 }  // namespace nt

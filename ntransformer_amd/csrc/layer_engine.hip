@@ -1,0 +1,956 @@
+// layer_engine.hip -- one decode token as ONE persistent launch on gfx950, second design (round 5).
+//
+// Replaces, for the engine's decode step at short contexts, the 5-launches-per-layer sequence of engine/model.cpp (the fused form of the
+// reference's 15 launches per layer: reference src/model/transformer.cpp:604-669, attention.cpp:120-211, ffn.cpp:85-134).  Same operators,
+// same arithmetic per weight block (gemv_core.hip.h: Dot<Q8_0>, reference gemm.cu:129-141) and per attention head (attention.hip's
+// single-pass online softmax); what changes is how bytes and activations move.  The first persistent kernel (decode_persistent.hip, round
+// 2) lost 20 % to the launch path: every wave loaded AND decoded, and activations crossed workgroups through a drain + a grid-wide counter
+// + a re-read.  This one follows the loader / consumer recipe priced in MI355X_MICROARCH.md (rows prefetch-credit, ldsdma-fill,
+// handoff-1to1, allgather, engine-vs-launches):
+//
+//   * One workgroup of FOUR waves per CU (one per SIMD), resident for the whole token.  Wave 0 is the LOADER: it streams the CU's share
+//     of every weight matrix by LDS-DMA (global_load_lds_dwordx4 ... nt, 1 KiB per instruction) into a ring of 16 KiB slots and NEVER
+//     stops at an operator edge -- weights do not depend on activations -- so while the CU waits for the activations of operator k + 1,
+//     HBM keeps filling the ring with that operator's rows.  Waves 1-3 are CONSUMERS: they decode rows out of the ring (the lane <-> column
+//     decomposition of gemv.hip, the activations of the row in registers) and never touch HBM for weights.  Loader and consumers talk
+//     through LDS words only (fills landed / slots consumed); there is no s_barrier after the first instruction of the kernel.
+//   * A CU owns the SAME contiguous range of output rows in every operator, so the residual stream of its rows never leaves its LDS.
+//   * Activations cross CUs as 8-byte {tag, value} granules, ONE sc1 (write-through) store each: the data is the flag.  A consumer wave
+//     gathers the vector it needs by sweeping the granules with sc1 loads until every tag matches the producing operator's, and writes the
+//     values into the LDS image its CU's consumers fill their registers from.  No flag word, no store drain, no fence, no grid barrier;
+//     every granule array is zeroed by a memset node in front of the launch and tags count operators within the launch.
+//   * Attention heads are table entries: the consumers of CU h run head h (RoPE, KV store, single-pass online softmax over the cache) while
+//     the other CUs' loaders run ahead into the Wo rows.
+//   * Every spin is bounded; a wait that gives up raises a device error word (the engine then falls back to launches for good).
+//
+// Scope of this form: Q8_0 matrices with rows <= 16 KiB (<= 15 360 columns), RMSNorm inputs <= 4096 columns, head_dim 64 / 128, the
+// single-pass attention regime (short contexts).  Everything else keeps the launch path (plan_create returns NTK_E_SHAPE / NTK_E_DTYPE).
+// HBM-bound like the GEMVs it is made of: algorithmic bytes per token = the weight matrices, once.
+#include "gemv_core.hip.h"
+#include "../../include/ntk_experiments.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace ntk {
+
+typedef unsigned long long le_u64;
+typedef __attribute__((address_space(1))) le_u64 le_gu64;        // granules live in GLOBAL memory and are never accessed flat
+typedef __attribute__((address_space(1))) unsigned le_gu32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef volatile __attribute__((address_space(3))) unsigned le_ctl_t;   // control words: explicit LDS address space (a volatile GENERIC access
+                                                                          // compiles to flat_load ... sc0 sc1, which also counts in vmcnt behind the DMA)
+
+constexpr int LE_T = 512;                 // 8 waves: the loader, 6 consumers (two groups of 3: a fill belongs to ONE group), one spare
+constexpr int LE_NC = 6;                  // consumer waves
+constexpr int LE_GW = 3;                  // waves per group = rows per fill (whole-row form) = slice owners (split form)
+constexpr int LE_SLOT = 16384;            // one ring slot = one fill = <= 16 DMA instructions
+constexpr int LE_CTL_BYTES = 8192;
+constexpr int LE_GPL = 32;                // granules per lane and gather pass (2048 per wave-pass = 16 KB in flight)
+constexpr int LE_DBG = 16;                // debug words per (CU, operator)
+constexpr int LE_SLICE = 4096;            // columns per slice (64 lanes x 64 columns)
+constexpr int LE_SLICE_BYTES = LE_SLICE / 32 * 34;
+constexpr unsigned LE_SPIN_LDS = 1u << 18, LE_SPIN_GRAN = 1u << 14;
+enum { LE_GEMV = 0, LE_ATTN = 1 };
+enum { LF_NORM = 1, LF_SILU = 2, LF_RESID = 4, LF_RESID_PLAIN = 8, LF_XPLAIN = 16, LF_SPLIT = 32 };
+// control words (LDS, behind the ring and the activation image)
+enum { C_FILLED = 0, C_ABORT = 1, C_ATT = 2, C_DONE = 8, C_XDONE = 16, C_XLOADED = 24, C_SSQ = 32, C_HID = 40, C_RCNT = 104, C_RPART = 112,
+       C_ATTM = 136, C_ATTL = 144, C_ATTACC = 152, C_ROPE = 920, C_WORDS = 1688 };   // ATTACC [6][128], ROPE [6][cos 64 | sin 64]
+static_assert(C_WORDS * 4 <= LE_CTL_BYTES, "control block");
+// what gave up (error word = 1 + op + 4096 * what + 65536 * cu)
+enum { LW_FILL = 1, LW_SLOT = 2, LW_XFREE = 3, LW_GRAN = 4, LW_XDONE = 5, LW_ATTG = 6, LW_ATTM = 7 };
+
+struct LeSeg {
+    const uint8_t* W;     // 16-byte aligned rows
+    le_u64* yg;           // granules of the output vector (nullptr: none)
+    float* yp;            // plain output (nullptr: none)
+    int rows, pad;
+};
+struct LeOp {             // one operator of the token, device resident, read through the scalar cache
+    int kind, flags, in, nseg;
+    LeSeg seg[3];
+    int rows_total;       // SiLU pair: rows of ONE matrix
+    unsigned row_bytes;
+    int rpf, ipr;         // rows per fill, DMA instructions per row
+    float eps;
+    unsigned tag;         // tag of this operator's output granules
+    const float* xp;      // activations: plain vector (written before the launch) ...
+    const le_u64* xg;     // ... or granules carrying xtag
+    unsigned xtag;
+    int nsl;              // column slices
+    const float* norm_w;
+    const float* resid_plain;
+    // attention: q / k / v granules of the Q|K|V operator (xtag), out granules (tag)
+    const le_u64* qg;
+    const le_u64* kg;
+    const le_u64* vg;
+    le_u64* og;
+    uint16_t* kc;
+    uint16_t* vc;
+    const float* inv_freq;
+    int n_heads, n_kv_heads, hd, max_seq;
+    float scale, theta, fscale;
+    int pad2;
+};
+typedef const __attribute__((address_space(4))) LeOp LCOp;   // uniform reads become s_load (see decode_persistent.hip)
+
+__host__ __device__ inline void le_rows(int R, int ncu, int cu, int& r0, int& r1) {   // the CU's contiguous row range, balanced
+    const int b = R / ncu, m = R % ncu;
+    r0 = cu * b + (cu < m ? cu : m);
+    r1 = r0 + b + (cu < m ? 1 : 0);
+}
+__device__ __forceinline__ int le_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned le_ld(le_ctl_t* p) { return (unsigned)le_uni((int)*p); }   // LDS word, wave-uniform
+typedef __attribute__((address_space(3))) float le_lf;
+__device__ __forceinline__ le_lf* le_f(le_ctl_t* p) { return (le_lf*)p; }                              // plain (non-volatile) float view
+__device__ __forceinline__ unsigned le_add(le_ctl_t* p) {                                              // ds_add_rtn_u32
+    return __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned*)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ le_u64 le_now() { return __builtin_amdgcn_s_memrealtime(); }               // 100 MHz
+
+__device__ __forceinline__ void le_fail(le_ctl_t* ctl, unsigned* err, int op, int what, int cu, int lane) {
+    if (lane == 0) {
+        ctl[C_ABORT] = 1u;
+        __hip_atomic_store((le_gu32*)err, 1u + (unsigned)op + 4096u * (unsigned)what + 65536u * (unsigned)cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// spin until ctl[word] >= target (wave-uniform); false = gave up / aborted
+__device__ __forceinline__ bool le_wait_ge(le_ctl_t* ctl, int word, unsigned target, unsigned* err, int op, int what, int cu, int lane) {
+    unsigned spins = 0;
+    while ((int)(le_ld(ctl + word) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0u) {
+            if (le_ld(ctl + C_ABORT)) return false;
+            if (spins > LE_SPIN_LDS) { le_fail(ctl, err, op, what, cu, lane); return false; }
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ unsigned le_minc(le_ctl_t* ctl, int word) {   // minimum over the consumer waves' words
+    unsigned m = le_ld(ctl + word);
+#pragma unroll
+    for (int i = 1; i < LE_NC; ++i) m = min(m, le_ld(ctl + word + i));
+    return m;
+}
+__device__ __forceinline__ bool le_wait_minc(le_ctl_t* ctl, int word, unsigned target, unsigned* err, int op, int what, int cu, int lane) {
+    unsigned spins = 0;
+    while ((int)(le_minc(ctl, word) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0u) {
+            if (le_ld(ctl + C_ABORT)) return false;
+            if (spins > LE_SPIN_LDS) { le_fail(ctl, err, op, what, cu, lane); return false; }
+        }
+    }
+    return true;
+}
+
+// Four (one) full 1-KiB pieces of a row by LDS-DMA: LDS dst + 1024 j <- sbase[voff + 1024 j .. + 1024), lane l moving 16 bytes at 16 l.  M0 (the
+// LDS destination) is compiler-reserved: saved, advanced and restored inside the statement (cdna_hip_programming.md 5.7); the global address
+// advances through the 32-bit offset register.  Not counted by the compiler: the loader's own vmcnt accounting covers them.
+__device__ __forceinline__ void le_dma4(uint32_t dst, const uint8_t* sbase, unsigned& voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, 0x400, %1\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\t"
+                 "v_add_u32 %1, 0x400, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(voff) : "s"(sbase), "s"(dst) : "memory", "scc");
+}
+__device__ __forceinline__ void le_dma1(uint32_t dst, const uint8_t* sbase, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(dst) : "memory");
+}
+
+// wait until at most n of the wave's vector-memory operations are outstanding, n <= 47 exact (more: 47, stricter)
+__device__ __forceinline__ void le_wait_vm(int n) {
+#define LE_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 47 ? n : 47) {
+        LE_VM(0) LE_VM(1) LE_VM(2) LE_VM(3) LE_VM(4) LE_VM(5) LE_VM(6) LE_VM(7) LE_VM(8) LE_VM(9) LE_VM(10) LE_VM(11) LE_VM(12) LE_VM(13)
+        LE_VM(14) LE_VM(15) LE_VM(16) LE_VM(17) LE_VM(18) LE_VM(19) LE_VM(20) LE_VM(21) LE_VM(22) LE_VM(23) LE_VM(24) LE_VM(25) LE_VM(26)
+        LE_VM(27) LE_VM(28) LE_VM(29) LE_VM(30) LE_VM(31) LE_VM(32) LE_VM(33) LE_VM(34) LE_VM(35) LE_VM(36) LE_VM(37) LE_VM(38) LE_VM(39)
+        LE_VM(40) LE_VM(41) LE_VM(42) LE_VM(43) LE_VM(44) LE_VM(45) LE_VM(46) LE_VM(47)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef LE_VM
+}
+
+__device__ __forceinline__ le_u64 le_gran_ld(const le_u64* p) {
+    return __hip_atomic_load((const le_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // global_load_dwordx2 sc1
+}
+__device__ __forceinline__ void le_gran_st(le_u64* p, unsigned tag, float v) {
+    __hip_atomic_store((le_gu64*)p, ((le_u64)tag << 32) | (le_u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ONE sc1 store
+}
+
+// the activation image: column i of the vector -> float index.  Lane l of a consumer owns columns 64 l .. 64 l + 63 of every 4096-column
+// slice and reads them as 16 b128 chunks; chunk q sits at position q ^ (l & 15), so the 16 lanes of a b128 group hit 16 different bank quads
+__device__ __forceinline__ int le_swz(int i) {
+    const int l = (i >> 6) & 63, q = (i >> 2) & 15;
+    return (i & ~63) | (((q ^ (l & 15)) << 2) | (i & 3));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the loader wave
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void le_loader(LCOp* ops, int nops, int ns, uint32_t ring_lds, le_ctl_t* ctl, int cu, int ncu, int lane,
+                                          unsigned* err, le_u64* dbg) {
+    unsigned g = 0;          // global fill index: fills 0 .. g-1 issued
+    int gslot = 0;           // g % ns
+    // DMA instructions of fills g-1 / g-2 / g-3 while those are not yet published as landed.  A fill is published when the fill THREE behind it
+    // has been issued: by then it has long landed and the counted wait does not stall (waiting for the fill before last cost 340 cycles
+    // of idle queue per fill); the 6-bit vmcnt holds 4 x 15 instructions.
+    int c1 = 0, c2 = 0, c3 = 0;
+    unsigned seen_done = 0;  // lower bound of min(done words) from the last poll: the six-word poll only when it does not suffice
+    auto publish = [&](unsigned n) { if (lane == 0) ctl[C_FILLED] = n; };
+    const unsigned lane16 = 16u * (unsigned)lane;
+    for (int k = 0; k < nops; ++k) {
+        LCOp& op = ops[k];
+        if (op.kind != LE_GEMV) continue;
+        int r0, r1;
+        le_rows(op.rows_total, ncu, cu, r0, r1);
+        const int n = r1 - r0;
+        if (n <= 0) continue;
+        const int rpf = op.rpf;
+        const unsigned row_bytes = op.row_bytes;
+        const int nfull = (int)(row_bytes >> 10), tail = (int)(row_bytes & 1023u), ipr = nfull + (tail ? 1 : 0);
+        const bool pair = (op.flags & LF_SILU) != 0;
+        const int nrf = (n + rpf - 1) / rpf, nf = pair ? 2 * nrf : nrf;
+        // the operator's matrices, out of the table once (a scalar load per row costs its latency per row)
+        const uint8_t* W0 = op.seg[0].W;
+        const uint8_t* W1 = op.seg[1].W;
+        const uint8_t* W2 = op.seg[2].W;
+        const int n0 = op.seg[0].rows, n1 = op.seg[1].rows;
+        // row cursor of the plain form: (segment, row inside it) of the CU's first row, then advanced row by row
+        int seg = 0, rr = r0;
+        if (!pair) {
+            if (op.nseg > 1 && rr >= n0) { rr -= n0; seg = 1; if (op.nseg > 2 && rr >= n1) { rr -= n1; seg = 2; } }
+        }
+        const uint8_t* src = (seg == 0 ? W0 : seg == 1 ? W1 : W2) + (size_t)rr * row_bytes;
+        int seg_left = (seg == 0 ? n0 : seg == 1 ? n1 : 0x7fffffff) - rr;   // rows left in the segment, this one included
+        if (dbg && lane == 0) dbg[((size_t)cu * nops + k) * LE_DBG + 4] = le_now();
+        le_u64 t_slot = 0, t_vm = 0, t_issue = 0;   // shader cycles (debug launches only: dbg != nullptr)
+        for (int f = 0; f < nf; ++f) {
+            le_u64 ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+            const int first = r0 + (pair ? (f >> 1) : f) * rpf;
+            const int cnt = min(rpf, r1 - first);
+            if (g >= (unsigned)ns) {   // the slot's previous fill (g - ns) must have been passed by every consumer wave
+                const unsigned need = g - (unsigned)ns + 1u;
+                if ((int)(seen_done - need) < 0) {
+                    seen_done = le_minc(ctl, C_DONE);
+                    if ((int)(seen_done - need) < 0) {
+                        // nothing can be issued: publish everything in flight first (the consumers may be waiting for exactly that)
+                        if (c1 | c2 | c3) { le_wait_vm(0); publish(g); }
+                        c1 = c2 = c3 = 0;
+                        if (!le_wait_minc(ctl, C_DONE, need, err, k, LW_SLOT, cu, lane)) return;
+                        seen_done = need;
+                    }
+                }
+            }
+            le_u64 tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
+            t_slot += tb - ta;
+            uint32_t dst = ring_lds + (uint32_t)gslot * (uint32_t)LE_SLOT;
+            for (int r = 0; r < cnt; ++r) {
+                const uint8_t* row = pair ? ((f & 1) ? W1 : W0) + (size_t)(first + r) * row_bytes : src;
+                unsigned voff = lane16;
+                uint32_t d = dst;
+                int i = 0;
+                for (; i + 4 <= nfull; i += 4) { le_dma4((uint32_t)le_uni((int)d), row, voff); d += 4096u; }
+                for (; i < nfull; ++i) { le_dma1((uint32_t)le_uni((int)d), row, voff); voff += 1024u; d += 1024u; }
+                if (tail && (int)lane16 < tail) le_dma1((uint32_t)le_uni((int)d), row, voff);   // (lane 0 is always active: the piece is issued)
+                dst += row_bytes;
+                if (!pair) {   // next row of the operator
+                    src += row_bytes;
+                    if (--seg_left == 0) { ++seg; src = seg == 1 ? W1 : W2; seg_left = seg == 1 ? n1 : 0x7fffffff; }
+                }
+            }
+            const int c0 = cnt * ipr;
+            le_u64 tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
+            t_issue += tc - tb;
+            if (c3) { le_wait_vm(c2 + c1 + c0); publish(g - 2u); }   // fill g-3 has landed: fills 0 .. g-3 readable
+            if (dbg) t_vm += __builtin_amdgcn_s_memtime() - tc;
+            c3 = c2; c2 = c1; c1 = c0; ++g;
+            if (++gslot == ns) gslot = 0;
+        }
+        if (dbg && lane == 0) {
+            le_u64* d = dbg + ((size_t)cu * nops + k) * LE_DBG;
+            d[5] = le_now(); d[8] = t_slot; d[9] = t_issue; d[10] = t_vm; d[11] = (le_u64)nf;
+        }
+    }
+    if (c3) { le_wait_vm(c2 + c1); publish(g - 2u); }
+    if (c2) { le_wait_vm(c1); publish(g - 1u); }
+    if (c1 | c2 | c3) { le_wait_vm(0); publish(g); }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// consumer side: gathering the activations of an operator into the CU's LDS image
+// ------------------------------------------------------------------------------------------------------------------
+// The consumer waves share the sweep (2048-granule chunks round the waves).  Returns false if a bounded wait gave up.  On return
+// the image holds the vector and ctl[C_SSQ + w] the waves' partial sums of squares.
+template <int GPL>   // granules per lane and pass: 16 (vectors <= 6144: one pass of <= 6 waves) or 40 (<= 15360: one pass of all six)
+__device__ __forceinline__ bool le_gather(LCOp& op, float* xs, le_ctl_t* ctl, int c, int lane, unsigned xseq, unsigned* err, int k, int cu) {
+    // the previous operator's image has been copied into registers by every wave of this CU
+    if (!le_wait_minc(ctl, C_XLOADED, xseq - 1u, err, k, LW_XFREE, cu, lane)) return false;
+    const int n = op.in, nchunks = (n + 64 * GPL - 1) / (64 * GPL);
+    const bool plain = (op.flags & LF_XPLAIN) != 0;
+    float ssq = 0.0f;
+    for (int chunk = c; chunk < nchunks; chunk += LE_NC) {
+        const int base = chunk * 64 * GPL + lane;
+        le_u64 gr[GPL];   // {tag, value} (plain vectors: the value only)
+        if (plain) {
+#pragma unroll
+            for (int j = 0; j < GPL; ++j) gr[j] = base + 64 * j < n ? (le_u64)__float_as_uint(op.xp[base + 64 * j]) : 0ull;
+        } else {
+            const unsigned want = op.xtag;
+            unsigned spins = 0;
+            for (;;) {
+#pragma unroll
+                for (int j = 0; j < GPL; ++j) gr[j] = le_gran_ld(op.xg + min(base + 64 * j, n - 1));
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < GPL; ++j) ok = ok && (unsigned)(gr[j] >> 32) == want;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 15u) == 0u) {
+                    if (le_ld(ctl + C_ABORT)) return false;
+                    if (spins > LE_SPIN_GRAN) { le_fail(ctl, err, k, LW_GRAN, cu, lane); return false; }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GPL; ++j) {
+            const int i = base + 64 * j;
+            if (i < n) {
+                const float v = __uint_as_float((unsigned)gr[j]);
+                xs[le_swz(i)] = v;
+                ssq = fmaf(v, v, ssq);
+            }
+        }
+    }
+    ssq = wave_sum(ssq);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();   // the wave's image stores precede (DS operations of a wave execute in order) the word that publishes them
+    if (lane == 0) {
+        ctl[C_SSQ + c] = __float_as_uint(ssq);
+        ctl[C_XDONE + c] = xseq;
+    }
+    return le_wait_minc(ctl, C_XDONE, xseq, err, k, LW_XDONE, cu, lane);
+}
+
+// the lane's 64 activations of slice s out of the image (x * rms_inv * w when NORM: the reference's association, rmsnorm.cu:68; the norm
+// weights were requested before the gather and are in registers by now)
+template <bool NORM>
+__device__ __forceinline__ void le_load_x(f32x2 (&x2)[32], const float* xs, int s, int lane, int ncols, const f32x4* nw, float rms_inv) {
+    if (ncols <= 0) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) x2[j] = f32x2{0.0f, 0.0f};
+        return;
+    }
+    const float* row = xs + s * LE_SLICE + 64 * lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * (q ^ (lane & 15)));
+        if constexpr (NORM) {
+            v.x = v.x * rms_inv * nw[q].x; v.y = v.y * rms_inv * nw[q].y; v.z = v.z * rms_inv * nw[q].z; v.w = v.w * rms_inv * nw[q].w;
+        }
+        x2[2 * q] = f32x2{v.x, v.y};
+        x2[2 * q + 1] = f32x2{v.z, v.w};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// consumer side: RoPE + KV store + single-pass attention of ONE head by the CU's three consumer waves
+// (reference rotary.cu:46-60, attention.cu:108-202, 316-342; the arithmetic of attention.hip's fused decode kernel)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void le_unpack8(const u32x4 r, float (&f)[8]) {
+    f[0] = h2f((uint16_t)(r.x & 0xFFFF)); f[1] = h2f((uint16_t)(r.x >> 16));
+    f[2] = h2f((uint16_t)(r.y & 0xFFFF)); f[3] = h2f((uint16_t)(r.y >> 16));
+    f[4] = h2f((uint16_t)(r.z & 0xFFFF)); f[5] = h2f((uint16_t)(r.z >> 16));
+    f[6] = h2f((uint16_t)(r.w & 0xFFFF)); f[7] = h2f((uint16_t)(r.w >> 16));
+}
+
+template <int LPR>
+__device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int lane, int pos, int head, unsigned attseq,
+                                             unsigned* err, int k, int cu) {
+    constexpr int HD = 8 * LPR, HALF = HD / 2, PPW = 64 / LPR, G = LE_NC * PPW;   // HD <= 128
+    const int n_kv = op.n_kv_heads, group = op.n_heads / n_kv, kvh = head / group;
+    const int sub = lane / LPR, pi = lane % LPR, g = c * PPW + sub;
+    le_lf* rope = le_f(ctl + C_ROPE) + c * 128;   // this wave's [cos 64][sin 64]
+    for (int i = lane; i < HALF; i += 64) {
+        // reference rotary.cu:46-60; inv_freq holds 1/powf(theta, 2i/hd) computed once on the host
+        const float freq = op.inv_freq ? op.inv_freq[i] : 1.0f / (float)pow((double)op.theta, (double)((2.0f * i) / HD));
+        const float angle = pos * freq * op.fscale;
+        rope[i] = cosf(angle);
+        rope[64 + i] = sinf(angle);
+    }
+    // this lane's 8 dimensions of q, k, v and their RoPE partners, as granules of the Q|K|V operator
+    le_u64 gq[8], gqp[8], gk[8], gkp[8], gv[8];
+    {
+        const le_u64* qb = op.qg + (size_t)head * HD;
+        const le_u64* kb = op.kg + (size_t)kvh * HD;
+        const le_u64* vb = op.vg + (size_t)kvh * HD;
+        const unsigned want = op.xtag;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = 8 * pi + j, pd = d ^ HALF;
+                gq[j] = le_gran_ld(qb + d); gqp[j] = le_gran_ld(qb + pd);
+                gk[j] = le_gran_ld(kb + d); gkp[j] = le_gran_ld(kb + pd);
+                gv[j] = le_gran_ld(vb + d);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                ok = ok && (unsigned)(gq[j] >> 32) == want && (unsigned)(gqp[j] >> 32) == want && (unsigned)(gk[j] >> 32) == want &&
+                     (unsigned)(gkp[j] >> 32) == want && (unsigned)(gv[j] >> 32) == want;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 15u) == 0u) {
+                if (le_ld(ctl + C_ABORT)) return false;
+                if (spins > LE_SPIN_GRAN) { le_fail(ctl, err, k, LW_ATTG, cu, lane); return false; }
+            }
+        }
+    }
+    float qreg[8], kx[8], vx[8];
+    uint16_t hk[8], hv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = 8 * pi + j, i = d & (HALF - 1);
+        const bool lo = d < HALF;
+        const float cs = rope[i], sn = rope[64 + i];
+        const float qa = __uint_as_float((unsigned)(lo ? gq[j] : gqp[j])), qb2 = __uint_as_float((unsigned)(lo ? gqp[j] : gq[j]));
+        const float ka = __uint_as_float((unsigned)(lo ? gk[j] : gkp[j])), kb2 = __uint_as_float((unsigned)(lo ? gkp[j] : gk[j]));
+        float ra, rb;
+        rope_rotate(qa, qb2, cs, sn, ra, rb);
+        qreg[j] = lo ? ra : rb;
+        rope_rotate(ka, kb2, cs, sn, ra, rb);
+        hk[j] = f2h(lo ? ra : rb);                                   // attention.cu:338 (__float2half, RNE)
+        hv[j] = f2h(__uint_as_float((unsigned)gv[j]));
+        kx[j] = h2f(hk[j]);
+        vx[j] = h2f(hv[j]);
+    }
+    const size_t stride = (size_t)n_kv * HD;
+    if (head % group == 0 && c == 0 && sub == 0 && pos < op.max_seq) {   // the token's cache row (read by later launches only)
+        const size_t at = (size_t)pos * stride + (size_t)kvh * HD + 8 * pi;
+        u32x4 pk, pv;
+        pk.x = hk[0] | ((uint32_t)hk[1] << 16); pk.y = hk[2] | ((uint32_t)hk[3] << 16); pk.z = hk[4] | ((uint32_t)hk[5] << 16); pk.w = hk[6] | ((uint32_t)hk[7] << 16);
+        pv.x = hv[0] | ((uint32_t)hv[1] << 16); pv.y = hv[2] | ((uint32_t)hv[3] << 16); pv.z = hv[4] | ((uint32_t)hv[5] << 16); pv.w = hv[6] | ((uint32_t)hv[7] << 16);
+        *reinterpret_cast<u32x4*>(op.kc + at) = pk;
+        *reinterpret_cast<u32x4*>(op.vc + at) = pv;
+    }
+    const uint16_t* kbase = op.kc + (size_t)kvh * HD + 8 * pi;
+    const uint16_t* vbase = op.vc + (size_t)kvh * HD + 8 * pi;
+    int p = g;
+    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
+    if (p < pos) {
+        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
+        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
+    }
+    float m = -INFINITY, l = 0.0f, acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (; p <= pos; p += G) {
+        float kf[8], vf[8];
+        if (p < pos) {
+            le_unpack8(kraw, kf);
+            le_unpack8(vraw, vf);
+        } else {   // the token being decoded
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kf[j] = kx[j]; vf[j] = vx[j]; }
+        }
+        const int pn = p + G;
+        if (pn < pos) {
+            kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)pn * stride);
+            vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)pn * stride);
+        }
+        float sc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sc = fmaf(qreg[j], kf[j], sc);
+        sc = group_sum<LPR>(sc);
+        sc *= op.scale;
+        const float mn = fmaxf(m, sc);
+        const float a = expf(m - mn), pw = expf(sc - mn);
+        l = fmaf(l, a, pw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], a, pw * vf[j]);
+        m = mn;
+    }
+    // merge the wave's PPW position groups: (m, l, acc) -> max-rescaled sums
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+        const float mo = __shfl_xor(m, off, 64), lo2 = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, mo);
+        const float wa = (m == -INFINITY) ? 0.0f : expf(m - mn), wb = (mo == -INFINITY) ? 0.0f : expf(mo - mn);
+        l = fmaf(l, wa, lo2 * wb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaf(acc[j], wa, __shfl_xor(acc[j], off, 64) * wb);
+        m = mn;
+    }
+    le_lf* ms = le_f(ctl + C_ATTM);
+    le_lf* ls = le_f(ctl + C_ATTL);
+    le_lf* accs = le_f(ctl + C_ATTACC);
+    if (lane == 0) { ms[c] = m; ls[c] = l; }
+    if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accs[c * 128 + 8 * pi + j] = acc[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    if (lane == 0) le_add(ctl + C_ATT);
+    if (c != 0) return true;
+    if (!le_wait_ge(ctl, C_ATT, LE_NC * attseq, err, k, LW_ATTM, cu, lane)) return false;
+    asm volatile("" ::: "memory");
+    for (int d = lane; d < HD; d += 64) {
+        float M = ms[0];
+        for (int i = 1; i < LE_NC; ++i) M = fmaxf(M, ms[i]);
+        float L = 0.0f, o = 0.0f;
+        for (int i = 0; i < LE_NC; ++i) {
+            const float w = (ms[i] == -INFINITY) ? 0.0f : expf(ms[i] - M);   // waves that saw no position
+            L = fmaf(w, ls[i], L);
+            o = fmaf(w, accs[i * 128 + d], o);
+        }
+        le_gran_st(op.og + (size_t)head * HD + d, op.tag, o / L);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// consumer side: one GEMV operator
+// ------------------------------------------------------------------------------------------------------------------
+// row R of the operator -> (segment, row inside it)
+__device__ __forceinline__ void le_locate(LCOp& op, int R, int& s, int& rr) {
+    s = 0; rr = R;
+    while (s + 1 < op.nseg && rr >= op.seg[s].rows) { rr -= op.seg[s].rows; ++s; }
+}
+__device__ __forceinline__ void le_store(LCOp& op, int s, int rr, float v) {
+    if (op.seg[s].yg) le_gran_st(op.seg[s].yg + rr, op.tag, v);
+    if (op.seg[s].yp) op.seg[s].yp[rr] = v;
+}
+
+// SPLIT = false: a wave owns whole rows (in <= 4096: the row's activations are the lane's 64 registers); a fill holds up to 3 rows, one per
+// wave of the group that owns the fill.  SPLIT = true: rows of 2 .. 6 slices; a fill holds one row, wave m of the owning group decodes
+// slices m and m + 3 and the three partial sums meet in LDS.  Fills (pairs of fills for gate | up) alternate between the two groups, so a
+// consumer wave has two fill periods per row; every wave walks ALL fills and marks the ones of the other group as passed at once.
+template <bool SPLIT>
+__device__ __forceinline__ bool le_gemv(LCOp* ops, int k, const uint8_t* ring, int ns, float* xs, le_ctl_t* ctl, int c, int lane,
+                                        int cu, int ncu, unsigned& g, int& gslot, unsigned xseq, unsigned* err, le_u64* dbg, int nops) {
+    LCOp& op = ops[k];
+    constexpr int NS2 = SPLIT ? 2 : 1;
+    const int grp = c / LE_GW, mem = c % LE_GW;
+    int r0, r1;
+    le_rows(op.rows_total, ncu, cu, r0, r1);
+    const int n = r1 - r0;
+    const int rpf = op.rpf;
+    const unsigned row_bytes = op.row_bytes;
+    const bool pair = (op.flags & LF_SILU) != 0, norm = (op.flags & LF_NORM) != 0, resid = (op.flags & LF_RESID) != 0;
+    const int nrf = (n + rpf - 1) / rpf, nf = pair ? 2 * nrf : nrf;
+    le_lf* hid = le_f(ctl + C_HID);
+    auto stamp = [&](int i) { if (dbg && c == 0 && lane == 0) dbg[((size_t)cu * nops + k) * LE_DBG + i] = le_now(); };
+    stamp(0);
+    // layer 0: the residual of the CU's rows comes from the vector the previous kernel wrote (afterwards it never leaves this LDS)
+    if ((op.flags & LF_RESID_PLAIN) && c == 0 && lane < n) hid[lane] = op.resid_plain[r0 + lane];
+    // the lane's RMSNorm weights (whole-row form: the lane's 64 columns), requested now, landed long before the gather is over
+    f32x4 nwr[SPLIT ? 1 : 16];
+    if constexpr (!SPLIT) {
+        if (norm && 64 * lane < op.in) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) nwr[q] = *reinterpret_cast<const f32x4*>(op.norm_w + 64 * lane + 4 * q);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) nwr[q] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        }
+    }
+    if (!(SPLIT ? le_gather<40>(op, xs, ctl, c, lane, xseq, err, k, cu) : le_gather<16>(op, xs, ctl, c, lane, xseq, err, k, cu))) return false;
+    stamp(1);
+    float rms_inv = 1.0f;
+    if (norm) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < LE_NC; ++i) tot += __uint_as_float(le_ld(ctl + C_SSQ + i));
+        rms_inv = 1.0f / sqrtf(tot / (float)op.in + op.eps);   // rsqrtf(mean + eps), rmsnorm.cu:60-61
+    }
+    f32x2 x2[NS2][32];
+    int ncols[NS2];
+#pragma unroll
+    for (int u = 0; u < NS2; ++u) {
+        const int s = SPLIT ? mem + LE_GW * u : 0;
+        const int cols = s < op.nsl ? min(LE_SLICE, op.in - s * LE_SLICE) : 0;
+        ncols[u] = min(64, max(0, cols - 64 * lane));
+        if constexpr (!SPLIT) {
+            if (norm) le_load_x<true>(x2[u], xs, s, lane, ncols[u], nwr, rms_inv);
+            else le_load_x<false>(x2[u], xs, s, lane, ncols[u], nwr, rms_inv);
+        } else {
+            le_load_x<false>(x2[u], xs, s, lane, ncols[u], nwr, 1.0f);   // (nwr unused)
+        }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) ctl[C_XLOADED + c] = xseq;
+    stamp(2);
+    const float zz4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zz2[2] = {0.0f, 0.0f};
+    float gate_carry = 0.0f;
+    bool alive = true;
+    le_u64 t_fill = 0, t_dot = 0;   // shader cycles waiting for fills / decoding (debug launches only)
+    for (int f = 0; f < nf; ++f, ++g) {
+        const int unit = pair ? (f >> 1) : f;
+        if ((unit & 1) == grp) {
+            const le_u64 ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+            le_u64 tb = ta;
+            const int first = r0 + unit * rpf;
+            const int cnt = min(rpf, r1 - first);
+            const uint8_t* slot = ring + (size_t)gslot * LE_SLOT;
+            if (!SPLIT) {
+                if (mem < cnt && alive) {
+                    alive = le_wait_ge(ctl, C_FILLED, g + 1u, err, k, LW_FILL, cu, lane);
+                    asm volatile("" ::: "memory");
+                    if (dbg) tb = __builtin_amdgcn_s_memtime();
+                    const float acc = Dot<NTK_DT_Q8_0, false>::run(slot + (size_t)mem * row_bytes, 0, lane, ncols[0], x2[0], zz4, zz2);
+                    const float tot = wave_sum_lane63(acc);
+                    if (lane == 63 && alive) {
+                        const int R = first + mem;
+                        if (pair) {
+                            if ((f & 1) == 0) gate_carry = tot;
+                            else le_store(op, 0, R, gate_carry / (1.0f + expf(-gate_carry)) * tot);   // gemm.cu:719-724
+                        } else {
+                            int s, rr;
+                            le_locate(op, R, s, rr);
+                            float v = tot;
+                            if (resid && s == 0) { v = hid[R - r0] + v; hid[R - r0] = v; }           // elementwise.cu:23-32
+                            le_store(op, s, rr, v);
+                        }
+                    }
+                }
+            } else {
+                if (alive) alive = le_wait_ge(ctl, C_FILLED, g + 1u, err, k, LW_FILL, cu, lane);
+                asm volatile("" ::: "memory");
+                if (dbg) tb = __builtin_amdgcn_s_memtime();
+                float acc = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NS2; ++u) {
+                    const int s = mem + LE_GW * u;
+                    if (s < op.nsl) acc += Dot<NTK_DT_Q8_0, false>::run(slot + (size_t)s * LE_SLICE_BYTES, 0, lane, ncols[u], x2[u], zz4, zz2);
+                }
+                const float tot = wave_sum_lane63(acc);
+                if (lane == 63 && alive) {
+                    const int w = (int)(g & 7u);
+                    le_lf* part = le_f(ctl + C_RPART) + 3 * w;
+                    part[mem] = tot;
+                    asm volatile("" ::: "memory");
+                    const unsigned old = le_add(ctl + C_RCNT + w);
+                    if (old == LE_GW - 1) {   // the last of the three partial sums: add them in wave order, epilogue, store
+                        asm volatile("" ::: "memory");
+                        float v = (part[0] + part[1]) + part[2];
+                        ctl[C_RCNT + w] = 0u;
+                        const int R = first;
+                        int s, rr;
+                        le_locate(op, R, s, rr);
+                        if (resid && s == 0) { v = hid[R - r0] + v; hid[R - r0] = v; }
+                        le_store(op, s, rr, v);
+                    }
+                }
+            }
+            if (dbg) { const le_u64 te = __builtin_amdgcn_s_memtime(); t_fill += tb - ta; t_dot += te - tb; }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();   // every read of the slot precedes the word that lets the loader refill it
+        if (lane == 0) ctl[C_DONE + c] = g + 1u;
+        if (++gslot == ns) gslot = 0;
+    }
+    stamp(3);
+    if (dbg && c == 0 && lane == 0) { le_u64* d = dbg + ((size_t)cu * nops + k) * LE_DBG; d[12] = t_fill; d[13] = t_dot; }
+    return alive;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------------------------
+// dbg (optional): per (CU, operator) LE_DBG words.  Stamps of the 100 MHz clock: [0] consumer 0 reaches the operator, [1] activations gathered,
+// [2] in registers, [3] rows done; [4] loader issues the operator's first fill, [5] its last; [6] attention done.  Shader cycles summed over
+// the operator's fills: loader [8] waiting for a free slot, [9] issuing, [10] waiting for the fill before last to land, [11] fills;
+// consumer 0 [12] waiting for fills, [13] decoding
+__global__ __launch_bounds__(LE_T) void layer_engine_kernel(const LeOp* __restrict__ ops_arg, int nops, int ns, int xbytes, unsigned* err,
+                                                            const int* __restrict__ d_pos, le_u64* dbg) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t le_smem[];
+    LCOp* ops = (LCOp*)ops_arg;
+    const int lane = threadIdx.x & 63;
+    const int wave = le_uni((int)(threadIdx.x >> 6));
+    const int cu = blockIdx.x, ncu = gridDim.x;
+    uint8_t* ring = le_smem;
+    float* xs = reinterpret_cast<float*>(le_smem + (size_t)ns * LE_SLOT);
+    le_ctl_t* ctl = (le_ctl_t*)(le_smem + (size_t)ns * LE_SLOT + xbytes);
+    if (threadIdx.x < 160) ctl[threadIdx.x] = 0u;
+    __syncthreads();   // the only barrier of the launch
+    if (wave == 0) {
+        le_loader(ops, nops, ns, (uint32_t)(uintptr_t)le_smem, ctl, cu, ncu, lane, err, dbg);
+        return;
+    }
+    if (wave > LE_NC) return;   // (the eighth wave: spare)
+    const int c = wave - 1;
+    const int pos = *d_pos;
+    unsigned g = 0, xseq = 0, attseq = 0;
+    int gslot = 0;
+    const int lane0 = lane;
+    for (int k = 0; k < nops; ++k) {
+        LCOp& op = ops[k];
+        if (le_ld(ctl + C_ABORT)) return;
+        // Re-derive the lane index behind an opaque barrier every operator: otherwise every lane-dependent address of every operator form is
+        // loop-invariant, gets hoisted out of this loop and stays live (spilled) for the whole token (decode_persistent.hip found the same)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        if (op.kind == LE_ATTN) {
+            if (cu < op.n_heads) {
+                ++attseq;
+                bool ok;
+                if (op.hd == 128) ok = le_attention<16>(op, ctl, c, lane, pos, cu, attseq, err, k, cu);
+                else ok = le_attention<8>(op, ctl, c, lane, pos, cu, attseq, err, k, cu);
+                if (dbg && c == 0 && lane == 0) dbg[((size_t)cu * nops + k) * LE_DBG + 6] = le_now();
+                if (!ok) return;
+            }
+            continue;
+        }
+        int r0, r1;
+        le_rows(op.rows_total, ncu, cu, r0, r1);
+        if (r1 <= r0) continue;   // (no rows here: the CU needs neither the activations nor a turn in the ring)
+        ++xseq;
+        bool ok;
+        if (op.flags & LF_SPLIT) ok = le_gemv<true>(ops, k, ring, ns, xs, ctl, c, lane, cu, ncu, g, gslot, xseq, err, dbg, nops);
+        else ok = le_gemv<false>(ops, k, ring, ns, xs, ctl, c, lane, cu, ncu, g, gslot, xseq, err, dbg, nops);
+        if (!ok) return;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+struct LayerEnginePlan {
+    LeOp* d_ops = nullptr;
+    le_u64* d_gran = nullptr;
+    size_t gran_bytes = 0;
+    unsigned* d_err = nullptr;
+    le_u64* d_dbg = nullptr;
+    int nops = 0, grid = 0, ns = 0, xbytes = 0, lds = 0;
+};
+
+struct LeRegion { uintptr_t lo, hi; size_t base; };
+
+}  // namespace ntk
+
+extern "C" {
+
+using namespace ntk;
+
+int ntk_layer_engine_plan_create(const ntk_pop* ops, int nops, void** plan_out) {
+    if (!ops || !plan_out || nops <= 0) return NTK_E_NULL;
+    *plan_out = nullptr;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NTK_E_NODEVICE;
+    int grid = prop.multiProcessorCount;   // one workgroup per CU (the LDS request admits exactly one): every workgroup is resident
+#ifdef NTK_TUNE
+    if (const char* e = getenv("NTK_LAYER_ENGINE_GRID")) grid = std::max(1, std::min(grid, atoi(e)));
+#endif
+    // ---- vectors that cross CUs inside the launch: every non-plain GEMV output and the attention outputs get granules ----
+    std::vector<LeRegion> iv;
+    auto add_iv = [&](const void* p, size_t floats) {
+        if (p && floats) iv.push_back({reinterpret_cast<uintptr_t>(p), reinterpret_cast<uintptr_t>(p) + 4 * floats, 0});
+    };
+    int max_in = 0;
+    for (int i = 0; i < nops; ++i) {
+        const ntk_pop& a = ops[i];
+        if (a.kind == NTK_POP_ATTENTION) {
+            if (a.n_heads <= 0 || a.n_kv_heads <= 0 || a.n_heads % a.n_kv_heads != 0 || a.n_heads > grid) return NTK_E_SHAPE;
+            if (a.head_dim != 64 && a.head_dim != 128) return NTK_E_SHAPE;
+            if (!a.q || !a.k || !a.v || !a.out || !a.k_cache || !a.v_cache) return NTK_E_NULL;
+            if ((reinterpret_cast<uintptr_t>(a.k_cache) & 15) || (reinterpret_cast<uintptr_t>(a.v_cache) & 15)) return NTK_E_ALIGN;
+            add_iv(a.out, (size_t)a.n_heads * a.head_dim);
+            continue;
+        }
+        if (a.kind != NTK_POP_GEMV || a.nseg < 1 || a.nseg > 3 || !a.x) return NTK_E_SHAPE;
+        if (a.in_features <= 0 || a.in_features % 64 != 0) return NTK_E_SHAPE;   // (a lane owns whole runs of 64 columns)
+        max_in = std::max(max_in, a.in_features);
+        for (int s = 0; s < a.nseg; ++s) {
+            if (a.segs[s].dtype != NTK_DT_Q8_0) return NTK_E_DTYPE;
+            if (a.segs[s].rows <= 0 || !a.segs[s].W || !a.segs[s].y) return NTK_E_NULL;
+            if (reinterpret_cast<uintptr_t>(a.segs[s].W) & 15) return NTK_E_ALIGN;
+            if (!a.plain_store && !(a.silu_pair && s == 1)) add_iv(a.segs[s].y, (size_t)a.segs[s].rows);
+        }
+    }
+    std::sort(iv.begin(), iv.end(), [](const LeRegion& x, const LeRegion& y) { return x.lo < y.lo; });
+    std::vector<LeRegion> reg;
+    size_t total = 0;
+    for (const LeRegion& r : iv) {
+        if (!reg.empty() && r.lo <= reg.back().hi) { reg.back().hi = std::max(reg.back().hi, r.hi); continue; }
+        reg.push_back(r);
+    }
+    for (LeRegion& r : reg) { r.base = total; total += (r.hi - r.lo) / 4; }
+    if (total == 0) return NTK_E_SHAPE;
+    LayerEnginePlan* p = new LayerEnginePlan();
+    p->nops = nops;
+    p->grid = grid;
+    p->gran_bytes = total * sizeof(le_u64);
+    auto fail = [&](int code) {
+        if (p->d_ops) (void)hipFree(p->d_ops);
+        if (p->d_gran) (void)hipFree(p->d_gran);
+        if (p->d_err) (void)hipFree(p->d_err);
+        delete p;
+        return code;
+    };
+    if (hipMalloc(reinterpret_cast<void**>(&p->d_gran), p->gran_bytes) != hipSuccess) return fail(NTK_E_NOMEM);
+    auto gran_of = [&](const void* ptr) -> le_u64* {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+        for (const LeRegion& r : reg)
+            if (a >= r.lo && a < r.hi) return p->d_gran + r.base + (a - r.lo) / 4;
+        return nullptr;
+    };
+    // ---- LDS: ring | activation image | control words ----
+    const int xbytes = ((4 * max_in + 255) / 256) * 256;
+    int ns = (160 * 1024 - LE_CTL_BYTES - xbytes) / LE_SLOT;
+    ns = std::min(ns, 8);
+#ifdef NTK_TUNE
+    if (const char* e = getenv("NTK_LAYER_ENGINE_SLOTS")) ns = std::max(3, std::min(ns, atoi(e)));
+#endif
+    if (ns < 3) return fail(NTK_E_SHAPE);
+    p->ns = ns; p->xbytes = xbytes; p->lds = ns * LE_SLOT + xbytes + LE_CTL_BYTES;
+    // ---- the device table ----
+    std::vector<LeOp> dv((size_t)nops);
+    std::map<const void*, unsigned> last_tag;     // vector (by its first element) -> tag of the operator that wrote it last
+    std::map<const void*, int> last_rows;
+    for (int i = 0; i < nops; ++i) {
+        const ntk_pop& a = ops[i];
+        LeOp& o = dv[i];
+        memset(&o, 0, sizeof o);
+        o.tag = (unsigned)i + 1u;
+        if (a.kind == NTK_POP_ATTENTION) {
+            o.kind = LE_ATTN;
+            const auto tq = last_tag.find(a.q), tk = last_tag.find(a.k), tv = last_tag.find(a.v);
+            if (tq == last_tag.end() || tk == last_tag.end() || tv == last_tag.end() || tq->second != tk->second || tq->second != tv->second)
+                return fail(NTK_E_SHAPE);   // q, k, v must come from ONE operator of this launch
+            o.xtag = tq->second;
+            o.qg = gran_of(a.q); o.kg = gran_of(a.k); o.vg = gran_of(a.v); o.og = gran_of(a.out);
+            if (!o.qg || !o.kg || !o.vg || !o.og) return fail(NTK_E_SHAPE);
+            o.kc = static_cast<uint16_t*>(a.k_cache); o.vc = static_cast<uint16_t*>(a.v_cache);
+            o.inv_freq = a.inv_freq;
+            o.n_heads = a.n_heads; o.n_kv_heads = a.n_kv_heads; o.hd = a.head_dim; o.max_seq = a.max_seq;
+            o.scale = a.scale; o.theta = a.theta_base; o.fscale = a.freq_scale;
+            last_tag[a.out] = o.tag;
+            continue;
+        }
+        o.kind = LE_GEMV;
+        const int in = a.in_features;
+        o.in = in; o.nseg = a.nseg; o.eps = a.eps;
+        o.row_bytes = (unsigned)(in / 32 * 34);
+        o.nsl = (in + LE_SLICE - 1) / LE_SLICE;
+        if (o.row_bytes > (unsigned)LE_SLOT || o.nsl > 2 * LE_NC) return fail(NTK_E_SHAPE);
+        if (o.row_bytes % 16 != 0) return fail(NTK_E_ALIGN);   // rows inside a slot start 16-byte aligned (in % 256 == 0 for Q8_0)
+        if (o.nsl > 1) o.flags |= LF_SPLIT;
+        o.ipr = (int)((o.row_bytes + 1023u) / 1024u);
+        o.rpf = o.nsl > 1 ? 1 : std::min(LE_GW, (int)(LE_SLOT / o.row_bytes));
+        if (o.rpf * o.ipr > 15) o.rpf = std::max(1, 15 / o.ipr);   // four fills in flight stay inside the 6-bit vmcnt
+        long total_rows = 0;
+        for (int s = 0; s < a.nseg; ++s) {
+            o.seg[s].W = static_cast<const uint8_t*>(a.segs[s].W);
+            o.seg[s].rows = a.segs[s].rows;
+            if (a.plain_store) o.seg[s].yp = a.segs[s].y;
+            else if (!(a.silu_pair && s == 1)) { o.seg[s].yg = gran_of(a.segs[s].y); if (!o.seg[s].yg) return fail(NTK_E_SHAPE); }
+            total_rows += a.segs[s].rows;
+        }
+        if (a.silu_pair) {
+            if (a.nseg != 2 || a.segs[0].rows != a.segs[1].rows || a.resid || o.nsl > 1) return fail(NTK_E_SHAPE);
+            total_rows = a.segs[0].rows;
+            o.flags |= LF_SILU;
+        }
+        o.rows_total = (int)total_rows;
+        if (a.norm_w) {
+            if ((reinterpret_cast<uintptr_t>(a.norm_w) & 15) || o.nsl > 1) return fail(NTK_E_SHAPE);
+            o.flags |= LF_NORM;
+            o.norm_w = a.norm_w;
+        }
+        const auto tx = last_tag.find(a.x);
+        if (tx != last_tag.end()) {
+            o.xg = gran_of(a.x); o.xtag = tx->second;
+            if (!o.xg) return fail(NTK_E_SHAPE);
+        } else {
+            o.flags |= LF_XPLAIN; o.xp = a.x;
+        }
+        if (a.resid) {
+            if (a.resid != a.segs[0].y || (total_rows + grid - 1) / grid > 64) return fail(NTK_E_SHAPE);   // in place: the CU's rows stay in its LDS
+            o.flags |= LF_RESID;
+            const auto tr = last_tag.find(a.resid);
+            if (tr == last_tag.end()) { o.flags |= LF_RESID_PLAIN; o.resid_plain = a.resid; }
+            else if (last_rows[a.resid] != (int)total_rows) return fail(NTK_E_SHAPE);   // (same rows -> same CU: le_rows)
+        }
+        for (int s = 0; s < a.nseg; ++s)
+            if (!a.plain_store && !(a.silu_pair && s == 1)) last_tag[a.segs[s].y] = o.tag;
+        if (a.resid || !a.plain_store) last_rows[a.segs[0].y] = (int)total_rows;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(layer_engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, p->lds) != hipSuccess)
+        return fail(NTK_E_LAUNCH);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, layer_engine_kernel, LE_T, p->lds) != hipSuccess || per_cu < 1) return fail(NTK_E_LAUNCH);
+    if (hipMalloc(reinterpret_cast<void**>(&p->d_ops), sizeof(LeOp) * (size_t)nops) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&p->d_err), 256) != hipSuccess ||
+        hipMemcpy(p->d_ops, dv.data(), sizeof(LeOp) * (size_t)nops, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(p->d_err, 0, 256) != hipSuccess || hipMemset(p->d_gran, 0, p->gran_bytes) != hipSuccess)
+        return fail(NTK_E_NOMEM);
+    *plan_out = p;
+    return NTK_OK;
+}
+
+void ntk_layer_engine_plan_destroy(void* plan) {
+    LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
+    if (!p) return;
+    if (p->d_ops) (void)hipFree(p->d_ops);
+    if (p->d_gran) (void)hipFree(p->d_gran);
+    if (p->d_err) (void)hipFree(p->d_err);
+    if (p->d_dbg) (void)hipFree(p->d_dbg);
+    delete p;
+}
+
+int ntk_layer_engine_launch(void* plan, const int* d_pos, void* stream) {
+    LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
+    if (!p || !d_pos) return NTK_E_NULL;
+    hipStream_t st = resolve_stream(stream);
+    // every granule is zeroed in front of every launch (a memset node when captured): tags count operators WITHIN the launch
+    if (hipMemsetAsync(p->d_gran, 0, p->gran_bytes, st) != hipSuccess) return NTK_E_LAUNCH;
+    hipLaunchKernelGGL(layer_engine_kernel, dim3(p->grid), dim3(LE_T), p->lds, st, (const LeOp*)p->d_ops, p->nops, p->ns, p->xbytes, p->d_err,
+                       d_pos, p->d_dbg);
+    return last_launch_status();
+}
+
+int ntk_layer_engine_error(void* plan, unsigned* code_out) {
+    LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
+    if (!p) return NTK_E_NULL;
+    unsigned e = 0;
+    if (hipMemcpy(&e, p->d_err, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
+    if (code_out) *code_out = e;
+    if (e) {
+        (void)hipMemset(p->d_err, 0, sizeof(unsigned));
+        return NTK_E_LAUNCH;
+    }
+    return NTK_OK;
+}
+
+// geometry[0..3] = grid, ring slots, LDS bytes, operators.  Debug stamps: enable for launches made AFTER the call (captured graphs keep
+// their argument); out = [grid][nops][8] ticks of the 100 MHz clock.
+int ntk_layer_engine_info(void* plan, int* geometry4) {
+    LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
+    if (!p || !geometry4) return NTK_E_NULL;
+    geometry4[0] = p->grid; geometry4[1] = p->ns; geometry4[2] = p->lds; geometry4[3] = p->nops;
+    return NTK_OK;
+}
+int ntk_layer_engine_debug(void* plan, int enable, unsigned long long* out) {
+    LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
+    if (!p) return NTK_E_NULL;
+    const size_t n = sizeof(le_u64) * LE_DBG * (size_t)p->grid * (size_t)p->nops;
+    if (enable && !p->d_dbg) {
+        if (hipMalloc(reinterpret_cast<void**>(&p->d_dbg), n) != hipSuccess) return NTK_E_NOMEM;
+        (void)hipMemset(p->d_dbg, 0, n);
+    }
+    if (out && p->d_dbg && hipMemcpy(out, p->d_dbg, n, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
+    return p->nops;
+}
+
+}  // extern "C"

@@ -45,6 +45,61 @@ def persistent(name, shape, mix, tmp_path):
     return "ok"
 
 
+def layer_engine(name, shape, mix, tmp_path):
+    """Round 5: the same token as ONE launch on the loader / consumer engine (csrc/layer_engine.hip, "persistent" = 2: an LDS-DMA loader wave per
+    CU that runs ahead across operator edges, six consumer waves, activations between CUs as {tag, value} granules) against the launch path on
+    the same KV cache; eager and hipGraph replay; Q8_0 models only (others must refuse the plan and keep decoding with launches)."""
+    path, z = golden_model(name, shape, mix, tmp_path)
+    prompt = [int(t) for t in z["prompt"]]
+    fed = [int(t) for t in z["fed"][1:]][:6] + [5, 9, 300 % 256, 17]
+    outs = {}
+    for mode in ("launches", "engine", "engine_graph"):
+        eng = E.Engine()
+        eng.load(path, int(z["ctx"]))
+        eng.set_option("persistent", 0 if mode == "launches" else 2)
+        if mode != "launches" and "layer engine" not in eng.decode_path():
+            eng.close()
+            assert mix != "Q8_0", (name, "a Q8_0 model must qualify for the layer engine")
+            return "skipped (not a Q8_0 model: the plan is refused and the launch path stays)"
+        lg = [eng.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in fed:
+            lg.append(eng.decode_fused(t, pos, mode == "engine_graph"))
+            pos += 1
+        toks = eng.decode_greedy_steps(fed[-1], pos, 8)
+        outs[mode] = (np.stack(lg), toks)
+        eng.close()
+    for mode in ("engine", "engine_graph"):
+        err = np.abs(outs[mode][0] - outs["launches"][0]).max()
+        assert np.isfinite(outs[mode][0]).all() and err <= 5e-4, (name, mode, err)   # summation order differs; the logits bar is 1e-3
+    assert outs["engine"][1] == outs["engine_graph"][1]
+    return "ok"
+
+
+def layer_engine_wide():
+    """... and a shape the golden models do not have: FFN rows of three column slices (the split form: one row per fill, the three slice owners'
+    partial sums meet in LDS), synthetic weights."""
+    spec = E.SynthSpec(1024, 9216, 3, 8, 2, 2048, 2048, 1e-5, 500000.0, 256, 257, b"Q8_0", 20260925)
+    prompt = [256, 5, 77, 1000, 31, 8]
+    outs = {}
+    for mode, level in (("launches", 0), ("engine", 2)):
+        eng = E.Engine()
+        eng.load_synthetic(spec, 512)
+        eng.set_option("persistent", level)
+        assert level == 0 or "layer engine" in eng.decode_path()
+        lg = [eng.forward(prompt, 0)]
+        pos = len(prompt)
+        for t in (9, 300, 4, 2000, 17, 17, 250):
+            lg.append(eng.decode_fused(t, pos, level == 2))
+            pos += 1
+        outs[mode] = (np.stack(lg), eng.decode_greedy_steps(17, pos, 12))
+        eng.close()
+    err = np.abs(outs["engine"][0] - outs["launches"][0]).max()
+    assert np.isfinite(outs["engine"][0]).all() and err <= 5e-4, err
+    assert outs["engine"][1] == outs["launches"][1]
+    return "ok"
+
+
 def attention_in_wo(name, shape, mix, tmp_path):
     """Short contexts: RoPE + KV store + attention run as extra workgroups IN FRONT of the Wo projection's grid
     (ntk_attention_gemv_fused: the GEMV workgroups request their first weight rows, then wait for the heads), one launch
@@ -82,6 +137,9 @@ def main():
             print("persistent", name, persistent(name, shape, mix, Path(d)), flush=True)
         for name, shape, mix in [c for c in CASES if c[0] in ("tiny_q8_0", "tiny_q4_k_m", "small_q8_0", "small_q6_k")]:
             print("attention_in_wo", name, attention_in_wo(name, shape, mix, Path(d)), flush=True)
+        for name, shape, mix in [c for c in CASES if c[0] in ("tiny_q8_0", "small_q8_0", "small_q4_k_m")]:
+            print("layer_engine", name, layer_engine(name, shape, mix, Path(d)), flush=True)
+    print("layer_engine wide", layer_engine_wide(), flush=True)
     print("experiments ok")
 
 

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Bring-up probe of the loader / consumer layer engine (csrc/layer_engine.hip; EXPERIMENTS=1 library, "persistent" = 2).
+  1. parity on the committed golden Q8_0 models: logits of the engine (eager and hipGraph) against the 5-launches-per-layer path;
+  2. the 8B Q8_0 synthetic model: same greedy tokens as the launch path, logits difference, tokens/s of both, and
+  3. the per-operator timeline of one token (ntk_layer_engine_debug), summarised per operator kind.
+usage (GPU box): NTK_LIB_PATH=$PWD/ntransformer_amd/libntransformer_hip_exp.so python tools/layer_engine_probe.py [--no-8b] [--steps N]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from ntransformer_amd import engine as E   # noqa: E402
+from ntransformer_amd import _lib   # noqa: E402
+
+
+def small_parity():
+    from test_oracle_golden import golden_model
+    from ntransformer_amd import gguf as G
+    with tempfile.TemporaryDirectory() as d:
+        for name, shape in (("tiny_q8_0", G.TINY), ("small_q8_0", G.SMALL)):
+            path, z = golden_model(name, shape, "Q8_0", Path(d))
+            prompt = [int(t) for t in z["prompt"]]
+            fed = [int(t) for t in z["fed"][1:]][:6] + [5, 9, 44, 17]
+            outs = {}
+            for mode in ("launches", "engine", "engine_graph"):
+                eng = E.Engine()
+                eng.load(path, int(z["ctx"]))
+                eng.set_option("persistent", 0 if mode == "launches" else 2)
+                if mode != "launches" and "layer engine" not in eng.decode_path():
+                    print(name, "does not qualify:", eng.decode_path(), flush=True)
+                    eng.close()
+                    break
+                lg = [eng.forward(prompt, 0)]
+                pos = len(prompt)
+                try:
+                    for t in fed:
+                        lg.append(eng.decode_fused(t, pos, mode == "engine_graph"))
+                        pos += 1
+                    toks = eng.decode_greedy_steps(fed[-1], pos, 8)
+                except Exception as e:   # a bounded wait that gave up surfaces here
+                    print(name, mode, "FAILED:", repr(e), "|", eng.last_error() if hasattr(eng, "last_error") else "", flush=True)
+                    eng.close()
+                    break
+                outs[mode] = (np.stack(lg), toks)
+                eng.close()
+            for mode in ("engine", "engine_graph"):
+                if mode in outs:
+                    err = np.abs(outs[mode][0] - outs["launches"][0])
+                    print("%s %-12s max |dlogit| vs launches %.3g (finite %s), per step %s, greedy tokens equal %s" % (
+                        name, mode, err.max(), bool(np.isfinite(outs[mode][0]).all()), np.array2string(err.max(axis=1), precision=2),
+                        outs[mode][1] == outs["launches"][1]), flush=True)
+
+
+def wide_parity():
+    """A shape the golden models do not have: FFN rows of three column slices (the split form: one row per fill, partial sums through LDS)."""
+    spec = E.SynthSpec(1024, 9216, 3, 8, 2, 2048, 2048, 1e-5, 500000.0, 256, 257, b"Q8_0", 20260925)
+    prompt = [256, 5, 77, 1000, 31, 8]
+    outs = {}
+    for mode, level in (("launches", 0), ("engine", 2), ("engine_graph", 2)):
+        eng = E.Engine()
+        eng.load_synthetic(spec, 512)
+        eng.set_option("persistent", level)
+        lg = [eng.forward(prompt, 0)]
+        pos = len(prompt)
+        try:
+            for t in (9, 300, 4, 2000, 17, 17, 250):
+                lg.append(eng.decode_fused(t, pos, mode == "engine_graph"))
+                pos += 1
+            toks = eng.decode_greedy_steps(17, pos, 12)
+        except Exception as e:
+            print("wide", mode, "FAILED:", repr(e), flush=True)
+            eng.close()
+            return
+        outs[mode] = (np.stack(lg), toks, eng.decode_path())
+        eng.close()
+    for mode in ("engine", "engine_graph"):
+        err = np.abs(outs[mode][0] - outs["launches"][0])
+        print("wide(1024x9216) %-12s [%s] max |dlogit| vs launches %.3g, per step %s, greedy tokens equal %s" % (
+            mode, outs[mode][2][:22], err.max(), np.array2string(err.max(axis=1), precision=2), outs[mode][1] == outs["launches"][1]), flush=True)
+
+
+def big(args):
+    spec = E.synth_spec("8b", "Q8_0")
+    eng = E.Engine()
+    eng.load_synthetic(spec, 4096)
+    rng = np.random.Generator(np.random.Philox(key=[20260925, 99]))
+    prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, 15)]
+    res = {}
+    for mode, level in (("launches", 0), ("engine", 2), ("launches", 0), ("engine", 2)):
+        eng.set_option("persistent", level)
+        first = eng.generate_tokens(prompt, 1, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False)
+        tok, pos = first[0], len(prompt)
+        lg = eng.decode_fused(tok, pos, True)
+        try:
+            warm = eng.decode_greedy_steps(tok, pos, 8)
+            t0 = time.perf_counter()
+            out = eng.decode_greedy_steps(warm[-1], pos + 8, args.steps)
+            dt = time.perf_counter() - t0
+        except Exception as e:
+            print("8b", mode, "FAILED:", repr(e), flush=True)
+            break
+        print("8b Q8_0 %-9s %-40.40s %7.1f tok/s (%.3f ms/token)  first tokens %s" % (mode, eng.decode_path(), args.steps / dt, dt / args.steps * 1e3, out[:6]), flush=True)
+        res.setdefault(mode, (lg, warm + out))
+    if "engine" in res:
+        print("8b: max |dlogit| engine vs launches at the first decode step %.3g; greedy streams equal: %s" % (
+            np.abs(res["engine"][0] - res["launches"][0]).max(), res["engine"][1] == res["launches"][1]), flush=True)
+        timeline(eng, spec)
+    eng.close()
+
+
+def timeline(eng, spec):
+    L = _lib.lib()
+    L.nt_engine_persistent_plan.restype = C.c_void_p; L.nt_engine_persistent_plan.argtypes = [C.c_void_p]
+    L.ntk_layer_engine_debug.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.ntk_layer_engine_info.argtypes = [C.c_void_p, C.c_void_p]
+    eng.set_option("persistent", 2)
+    plan = L.nt_engine_persistent_plan(eng.h)
+    if not plan:
+        return
+    geo = (C.c_int * 4)()
+    L.ntk_layer_engine_info(plan, geo)
+    grid, ns, lds, nops = geo[0], geo[1], geo[2], geo[3]
+    L.ntk_layer_engine_debug(plan, 1, None)
+    tok = 5
+    for i in range(3):
+        eng.decode_fused(tok, 40 + i, False)   # eager: the debug pointer is an argument of the launch
+    raw = np.zeros((grid, nops, 16), dtype=np.uint64)
+    L.ntk_layer_engine_debug(plan, 1, raw.ctypes.data_as(C.c_void_p))
+    t = raw.astype(np.float64) / 100.0   # us
+    t0 = t[:, :, 0][t[:, :, 0] > 0].min()
+    print("layer engine: grid %d, ring slots %d, LDS %d B, %d operators; timeline of one token (us from the first stamp; per operator: median over CUs)" % (grid, ns, lds, nops))
+    names = ["qkv", "attn", "wo", "gate|up", "down"]
+    def med(a):
+        a = a[a > 0]
+        return float(np.median(a)) - t0 if a.size else float("nan")
+    def mx(a):
+        a = a[a > 0]
+        return float(a.max()) - t0 if a.size else float("nan")
+    rows = []
+    for k in range(nops):
+        nm = names[k % 5] if k < nops - 1 else "lm_head"
+        rows.append((k, nm, med(t[:, k, 0]), med(t[:, k, 1]), mx(t[:, k, 1]), med(t[:, k, 2]), med(t[:, k, 3]), mx(t[:, k, 3]), med(t[:, k, 4]), med(t[:, k, 5]), mx(t[:, k, 6])))
+    print("  op kind      reach    x-gathered(med/max)  in-regs  rows-done(med/max)   loader first..last fill   attention done(max)")
+    for r in rows[:12] + rows[-7:]:
+        print("  %3d %-8s %8.2f %9.2f %8.2f %8.2f %9.2f %8.2f   %8.2f %8.2f   %8.2f" % r)
+    # per-kind averages over the steady layers (2 .. L-2): edge = x gathered (max over CUs) - producer rows done (max over CUs)
+    L_ = (nops - 1) // 5
+    acc = {n: [] for n in names}
+    for layer in range(2, L_ - 1):
+        for j, nm in enumerate(names):
+            k = 5 * layer + j
+            if nm == "attn":
+                acc[nm].append(mx(t[:, k, 6]) - mx(t[:, k - 1, 3]))
+            else:
+                prev_done = mx(t[:, k - 1, 6]) if names[(j - 1) % 5] == "attn" else mx(t[:, k - 1, 3])
+                acc[nm].append((mx(t[:, k, 1]) - prev_done, mx(t[:, k, 3]) - mx(t[:, k, 1]), med(t[:, k, 2]) - med(t[:, k, 1])))
+    print("steady layers, us: per operator  edge (producer's last row -> activations gathered on the slowest CU) | rows (gathered -> last row done) | image -> registers")
+    for nm in names:
+        a = np.array(acc[nm], dtype=np.float64)
+        if nm == "attn":
+            print("  %-8s qkv rows done -> attention output stored: %6.2f" % (nm, np.nanmean(a)))
+        else:
+            print("  %-8s edge %6.2f | rows %6.2f | regs %5.2f" % (nm, np.nanmean(a[:, 0]), np.nanmean(a[:, 1]), np.nanmean(a[:, 2])))
+    # where the row phases go (shader cycles, median over CUs): loader = waiting for a free slot | issuing | waiting for the fill before last to land;
+    # consumer 0 = waiting for fills | decoding + epilogue
+    print("row phases, cycles per FILL (median over CUs): loader slot-wait / issue / landed-wait | consumer 0 fill-wait / decode")
+    for j, nm in enumerate(names + ["lm_head"]):
+        if nm == "attn":
+            continue
+        k = 5 * 5 + j if nm != "lm_head" else nops - 1
+        nf = np.median(raw[:, k, 11][raw[:, k, 11] > 0])
+        m = lambda i: float(np.median(raw[:, k, i][raw[:, k, 11] > 0])) / nf
+        print("  %-8s fills %4d | loader %7.0f %7.0f %7.0f | consumer %7.0f %7.0f" % (nm, nf, m(8), m(9), m(10), m(12), m(13)))
+    layer_t = [mx(t[:, 5 * (l + 1) + 0, 3]) - mx(t[:, 5 * l + 0, 3]) for l in range(2, L_ - 2)]
+    print("  layer period (qkv rows done -> next layer's): %.2f us; token %.1f us" % (float(np.mean(layer_t)), mx(t[:, nops - 1, 3])))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--no-8b", action="store_true")
+    ap.add_argument("--no-small", action="store_true")
+    ap.add_argument("--steps", type=int, default=64)
+    a = ap.parse_args()
+    if not a.no_small:
+        small_parity()
+        wide_parity()
+    if not a.no_8b:
+        big(a)
