@@ -51,11 +51,12 @@ def parse():
     ap.add_argument("--prompt-len", type=int, default=16)
     ap.add_argument("--no-fuse", action="store_true", help="the reference's 15-launch/layer sequence")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--persistent", action="store_true", help="the persistent one-launch-per-token kernel instead of fused launches")
+    ap.add_argument("--persistent", type=int, nargs="?", const=1, default=0,
+                    help="EXPERIMENTS=1 library only: 1 = the round-2 persistent token kernel, 2 = the round-5 loader / consumer layer engine, instead of fused launches")
     ap.add_argument("--no-repack", action="store_true", help="K-quant decode GEMVs from the raw GGUF blocks (csrc/gemv.hip) instead of the engine's load-time repack (csrc/gemv_rp.hip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=128, help="-n of the reference CLI run that is the CPU baseline (BASELINE config 1: 128)")
-    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (8B Q4_K_M, 70B Q4_K_M, 70B Q6_K, 3.9K-context 8B Q8_0)")
+    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (8B Q4_K_M, 70B Q4_K_M, 70B Q6_K, 8B Q8_0 behind 3900- and 32768-token prompts)")
     ap.add_argument("--no-pmc-note", action="store_true")
     ap.add_argument("--prompt-bench", type=int, default=1024, help="also time one prompt pass of this many tokens (0 = skip); reported under config.prompt_pass")
     return ap.parse_args()
@@ -109,24 +110,34 @@ def cpu_baseline_reference_cli(args, spec):
     E.synth_write_gguf(path, spec)
     t_write = time.perf_counter() - t0
     try:
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false", OMP_WAIT_POLICY="passive")
+        # threads pinned to the first `threads` CPUs of the affinity mask (one per core), two runs, the better one reported with both and the
+        # host's load average before and after (the boxes are shared: a 256-thread host has been seen at loadavg 39 with our 16-thread quota)
+        cpus = sorted(os.sched_getaffinity(0))[:max(1, threads)] if hasattr(os, "sched_getaffinity") else []
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_WAIT_POLICY="passive")
+        pin = (lambda: os.sched_setaffinity(0, cpus)) if cpus else None
         # 15 ASCII bytes = BOS + 15 byte-level tokens in the synthetic vocabulary (GPT-2 byte alphabet, no merges): the 16-token prompt
         # length of the GPU run, greedy, -n 128 = BASELINE config 1 / SURVEY 8(d)
         cpu_prompt = "abcdefghijklmno"[:max(1, args.prompt_len - 1)]
         cmd = [exe, "-m", path, "-p", cpu_prompt, "-n", str(args.cpu_tokens), "-t", "0", "--repeat-penalty", "1.0", "-c", str(args.ctx)]
-        t0 = time.perf_counter()
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
-        wall = time.perf_counter() - t0
-        txt = r.stderr + r.stdout
-        m = re.search(r"Decode:\s+(\d+) tokens,\s+([0-9.]+) ms \(([0-9.]+) tok/s\)", txt)
-        mp = re.search(r"Prompt:\s+(\d+) tokens,\s+([0-9.]+) ms", txt)
-        if r.returncode != 0 or not m:
-            raise RuntimeError("reference CLI failed (rc %d): %s" % (r.returncode, txt[-400:]))
-        n_dec, ms_dec = int(m.group(1)), float(m.group(2))
+        load0 = os.getloadavg()[0]
+        runs, wall = [], 0.0
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, preexec_fn=pin)
+            wall += time.perf_counter() - t0
+            txt = r.stderr + r.stdout
+            m = re.search(r"Decode:\s+(\d+) tokens,\s+([0-9.]+) ms \(([0-9.]+) tok/s\)", txt)
+            if r.returncode != 0 or not m:
+                raise RuntimeError("reference CLI failed (rc %d): %s" % (r.returncode, txt[-400:]))
+            runs.append((int(m.group(1)), float(m.group(2))))
+        load1 = os.getloadavg()[0]
+        n_dec, ms_dec = min(runs, key=lambda t: t[1] / t[0])
         return {"value": round(n_dec / (ms_dec * 1e-3), 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+                "runs_tok_s": [round(n / (ms * 1e-3), 4) for n, ms in runs], "loadavg_1m_before_after": [round(load0, 1), round(load1, 1)],
+                "pinned_cpus": cpus[:4] + (["..."] if len(cpus) > 4 else []),
                 "sample": "reference CLI (oracle/_ref/ntransformer_cpu: the reference's unmodified host code over the CPU restatement of its "
-                          "kernels) on the full %s %s GGUF (%.1f GB), -p <%d tokens> -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Decode: line, "
-                          "%d tokens in %.0f ms; run %.0f s + %.0f s writing the file"
+                          "kernels) on the full %s %s GGUF (%.1f GB), -p <%d tokens> -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Decode: line "
+                          "(engine.cpp:595-600), best of two runs, threads pinned: %d tokens in %.0f ms; runs %.0f s + %.0f s writing the file"
                           % (args.model, args.mix, os.path.getsize(path) / 1e9, len(cpu_prompt) + 1, args.cpu_tokens, args.ctx, n_dec, ms_dec, wall, t_write),
                 "host": _cpu_model(), "host_cpus": info}
     finally:
@@ -168,7 +179,7 @@ def activation_form(mix, repack=True):
     return "f32" if (mix in ("Q8_0", "Q4_0", "F16", "F32") or not repack) else "int24-block"
 
 
-def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
+def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None, ctx=None):
     """Load `model`:`mix` resident, prompt + first token untimed, `warmup` tokens untimed, exactly `steps` greedy decode
     tokens timed by `timed` (replica.timed_steps partial).  Returns the measurements (rank-local roofline included)."""
     import numpy as np
@@ -178,11 +189,12 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     eng.set_option("fused", not args.no_fuse)
     eng.set_option("graph", not args.no_graph)
     if args.persistent:
-        eng.set_option("persistent", 1)
+        eng.set_option("persistent", args.persistent)
     if args.no_repack:
         eng.set_option("repack", 0)
+    ctx = ctx or args.ctx
     t_load = time.perf_counter()
-    eng.load_synthetic(spec, args.ctx)
+    eng.load_synthetic(spec, ctx)
     t_load = time.perf_counter() - t_load
     rng = np.random.Generator(np.random.Philox(key=[20260925, 99]))
     prompt_len = prompt_len or args.prompt_len
@@ -204,15 +216,16 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
                     or "rocprof" in os.environ.get("LD_PRELOAD", ""))   # rocprofv3 serialises kernels: nothing can run BESIDE the steps
         if profiled:
             sclk = round(_ops.sclk_mhz(), 1)       # ... so there: one wave spinning for 50 us right behind the timed region
-        elif pos_end + 32 <= args.ctx and out:
+        elif pos_end + 32 <= ctx and out:
             with _ops.SclkSpan() as c:
                 eng.decode_greedy_steps(out[-1], pos_end, 32)
                 sync()
             sclk = round(c.mhz, 1) if c.mhz else None
     except Exception:
         sclk = None
-    res = {"spec": spec, "elapsed": elapsed, "pos": pos, "pos_end": pos_end, "t_load": t_load, "sclk_mhz": sclk,
-           "b_tok": eng.bytes_per_token(pos + steps // 2), "path": eng.decode_path() if hasattr(eng, "decode_path") else None}
+    res = {"spec": spec, "prompt_len": prompt_len, "elapsed": elapsed, "pos": pos, "pos_end": pos_end, "t_load": t_load, "sclk_mhz": sclk,
+           "b_tok": eng.bytes_per_token(pos + steps // 2), "path": eng.decode_path() if hasattr(eng, "decode_path") else None,
+           "resident_bytes": eng.resident_weight_bytes() if hasattr(eng, "resident_weight_bytes") else None, "ctx": ctx}
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the compute stream over a few eagerly
     # launched tokens (the fused launch sequence: the persistent token kernel has no per-operator boundaries to put
@@ -222,7 +235,7 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     def prof(coarse, n_prof=4):
         ms, calls = [0.0] * 4, [0] * 4
         for i in range(n_prof):
-            m_, c_ = eng.profile_token(out[-1] if out else tok, min(pos_end + i, args.ctx - 1), coarse)
+            m_, c_ = eng.profile_token(out[-1] if out else tok, min(pos_end + i, ctx - 1), coarse)
             ms = [a + b for a, b in zip(ms, m_)]
             calls = [a + b for a, b in zip(calls, c_)]
         return [m / n_prof for m in ms], [c / n_prof for c in calls]
@@ -232,7 +245,7 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None):
     # ---- prompt pass, outside the timed decode region: one 1024-token prompt through the batched
     # projections (FP16 matrix cores) and the matrix-core prompt attention; second of two runs, host-timed around the sync
     res["prompt"] = None
-    if getattr(args, "prompt_bench", 0) and args.ctx >= args.prompt_bench:
+    if getattr(args, "prompt_bench", 0) and ctx >= args.prompt_bench:
         try:
             long_prompt = [spec.bos] + [int(t) for t in rng.integers(0, spec.vocab, args.prompt_bench - 1)]
             eng.forward(long_prompt, 0)
@@ -251,10 +264,15 @@ def roofline_block(args, model, mix, r):
     avg_launch_ms = r["ms"][0] / max(r["calls"][0], 1)
     achieved = (r["gemv_bytes_tok"] / max(launches_tok, 1)) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     traffic, traffic_src = _pmc_traffic(model, mix)
+    tr = _trace_gemv(model, mix, r.get("prompt_len"))
     kern = "gemv_quant_kernel" if activation_form(mix, not args.no_repack) == "f32" else "rp_gemv_kernel"
     return {"bound": "hbm", "kernel": "ntk::%s, %s (all projection launches of a token pooled)" % (kern, mix),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_events": round(achieved / HBM_PEAK_GBS, 4),
+            # the same quantity from the committed rocprofv3 --kernel-trace of this workload (tools/prof_summary.py --json -> profiles/trace_gemv.json):
+            # bytes per launch / average GEMV kernel duration.  frac (= frac_events) carries the cost of the HIP events, frac_trace does not.
+            "frac_trace": tr.get("frac"), "avg_launch_us_trace": tr.get("avg_us"), "trace_source": tr.get("source"),
+            "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": int(r["gemv_bytes_tok"] / max(launches_tok, 1)), "launches_per_token": launches_tok,
             "avg_launch_us": round(avg_launch_ms * 1e3, 2),
             "avg_launch_us_event_pair_per_launch": round(r["ms_fine"][0] / max(r["calls_fine"][0], 1) * 1e3, 2),
@@ -333,16 +351,23 @@ def main():
             rb = roofline_block(args, model, mix, a)
             e = {"k": key, "value": round(a_tok_s, 2), "ms": round(1e3 * a["elapsed"] / steps, 4), "steps": steps,
                  "frac": round(a["b_tok"] * a_tok_s / nrep / (HBM_PEAK_GBS * 1e9), 4), "gemv_frac": rb["frac"], "gemv_us": rb["avg_launch_us"],
-                 "pos": [a["pos"], a["pos_end"]], "form": activation_form(mix, not args.no_repack), "sclk_mhz": a["sclk_mhz"]}
+                 "roofline": {"frac_events": rb["frac_events"], "frac_trace": rb["frac_trace"], "us_trace": rb["avg_launch_us_trace"],
+                              "traffic": rb["traffic"], "bytes_per_launch": rb["bytes_per_launch"]},
+                 "pos": [a["pos"], a["pos_end"]], "form": activation_form(mix, not args.no_repack), "sclk_mhz": a["sclk_mhz"],
+                 "resident_GB": round(a["resident_bytes"] / 1e9, 2) if a.get("resident_bytes") else None}
+            if a.get("kv_frac") is not None:
+                e["kv_frac"] = a["kv_frac"]
             if a.get("prompt") and "tokens_per_s" in a["prompt"]:
                 e["prompt_tok_s"] = a["prompt"]["tokens_per_s"]
             return e
         line["config"]["also_legend"] = ("k = model_mix[_ctx<prompt tokens>], synthetic, resident, greedy; value tokens/s (whole job); ms per step; frac = "
-                                         "algorithmic bytes/token x tokens/s / 8 TB/s (per GPU); gemv_frac / gemv_us = GEMV launches, live HIP events; "
-                                         "prompt_tok_s = one 1024-token prompt pass")
+                                         "algorithmic bytes/token x tokens/s / 8 TB/s (per GPU); gemv_frac / gemv_us = GEMV launches, live HIP events; roofline = the GEMV launches: "
+                                         "frac_events (= gemv_frac), frac_trace / us_trace (committed rocprofv3 kernel trace of the workload, profiles/trace_gemv.json), "
+                                         "traffic (PMC bytes per launch, profiles/pmc_traffic.json); resident_GB = weights in HBM; prompt_tok_s = one 1024-token prompt pass")
         if headline and not args.no_also:
             also = []
-            plan = ((("8b", "Q4_K_M", 128, None), ("70b", "Q4_K_M", 64, None), ("70b", "Q6_K", 64, None), ("8b", "Q8_0", 64, 3900))
+            # (the last one: decode behind a 32768-token prompt -- 4.3 GB of KV cache per token, a third of the bytes: contexts beyond 4096)
+            plan = ((("8b", "Q4_K_M", 128, None), ("70b", "Q4_K_M", 64, None), ("70b", "Q6_K", 64, None), ("8b", "Q8_0", 64, 3900), ("8b", "Q8_0", 32, 32768))
                     if world == 1 else (("70b", "Q6_K", 64, None),))   # N > 1: BASELINE config 5, one whole-model replica per GPU
             for model, mix, steps, plen in plan:
                 key = "%s_%s%s" % (model, mix.lower(), "_ctx%d" % plen if plen else "")
@@ -350,7 +375,8 @@ def main():
                     keep_pb = args.prompt_bench
                     if plen or world > 1:
                         args.prompt_bench = 0
-                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local if world == 1 else timed_all_ranks, sync, prompt_len=plen)
+                    a = run_workload(args, model, mix, steps, min(args.warmup, 8), timed_local if world == 1 else timed_all_ranks, sync, prompt_len=plen,
+                                     ctx=(plen + 256 if plen and plen + 256 > args.ctx else None))
                     args.prompt_bench = keep_pb
                     also.append(also_entry(key, model, mix, steps, a, world))
                 except Exception as e:   # the headline must survive a problem in an extra workload
@@ -365,6 +391,17 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _trace_gemv(model, mix, prompt_len=None):
+    """GEMV launches of the workload in the committed rocprofv3 kernel trace (evidence pass of the round, tools/gpu_round_final.sh ->
+    tools/prof_summary.py --json): average duration and bytes / duration / 8 TB/s.  Read back like the PMC traffic."""
+    key = "%s_%s%s" % (model, mix.lower(), "_ctx%d" % prompt_len if prompt_len and prompt_len > 64 else "")
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "trace_gemv.json")))[key]
+        return {"frac": d["frac"], "avg_us": d["avg_us"], "source": "profiles/trace_gemv.json[%s] (%s)" % (key, d.get("file", ""))}
+    except Exception:
+        return {}
 
 
 def _pmc_traffic(model, mix):

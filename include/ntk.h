@@ -173,10 +173,14 @@ int ntk_gemv_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_fe
  *   ntk_rp_bytes        size of the repacked form (0: unsupported dtype / shape)
  *   ntk_rp_pack         raw GGUF [rows][in] -> dst (16-byte aligned, ntk_rp_bytes); stream ordered
  *   ntk_rp_dequant      parity instrumentation: the weights as F32 [rows][in] from the repacked form
+ *   ntk_rp_unpack       the raw GGUF bytes back (exact inverse of ntk_rp_pack)
  *   ntk_gemv_rp(_fused) = ntk_gemv / ntk_gemv_fused with segs[i].W pointing at REPACKED tensors (same epilogues; one or two formats) */
 size_t ntk_rp_bytes(int dtype, int rows, int in_features);
 int ntk_rp_pack(void* dst, const void* raw, int rows, int in_features, int dtype, void* stream);
 int ntk_rp_dequant(float* out, const void* rp, int rows, int in_features, int dtype, void* stream);
+/* the raw GGUF blocks [rows][in] back from the repacked form, byte for byte (the engine keeps ONE resident copy of a K-quant matrix and unpacks into
+ * a scratch in front of the launches that read raw blocks); raw: 4-byte aligned (Q6_K: 2); stream ordered */
+int ntk_rp_unpack(void* raw, const void* rp, int rows, int in_features, int dtype, void* stream);
 int ntk_gemv_rp(float* y, const void* rp, const float* x, int out_features, int in_features, int weight_dtype, void* stream);
 int ntk_gemv_rp_fused(const ntk_gemv_seg* segs, int nseg, const float* x, int in_features, const float* norm_w, float eps,
                       const float* resid, int silu_pair, void* stream);

@@ -65,7 +65,9 @@ typedef struct nt_synth_spec { /* seeded synthetic Llama-shaped model (no checkp
 int  nt_engine_load_ex(nt_engine_t e, const char* model_path, int max_context);
 int  nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_context);
 /* "fused" / "graph" / "device_sampling" / "batched_prefill" / "f16_prefill" (alias "bf16_prefill") = "0" | "1"; "persistent" / "fuse_attention" are accepted
- * everywhere and take effect only in EXPERIMENTS=1 builds (include/ntk_experiments.h) */
+ * everywhere and take effect only in EXPERIMENTS=1 builds (include/ntk_experiments.h); "repack" = "0" raw-GGUF decode GEMVs | "1" load-time repack with the GGUF
+ * bytes kept resident (K-quant weights twice in HBM) | "2" (default) one resident copy: the GGUF bytes of a repacked matrix are freed and unpacked into a scratch
+ * for the launches that read raw blocks (prompt GEMM, 1:1 sequence) */
 int  nt_engine_set_option(nt_engine_t e, const char* key, const char* value);
 const char* nt_engine_last_error(nt_engine_t e);
 void nt_gen_params_default(nt_gen_params* p);
@@ -87,7 +89,8 @@ int  nt_engine_profile_token(nt_engine_t e, int token, int pos, int coarse, floa
 int  nt_engine_tokenize(nt_engine_t e, const char* text, int add_bos, int* out, int out_cap);   /* returns count */
 int  nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int out_cap);       /* returns bytes */
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos);   /* algorithmic HBM bytes of one decode token */
-uint64_t nt_engine_weight_bytes(nt_engine_t e);
+uint64_t nt_engine_weight_bytes(nt_engine_t e);            /* the model's tensors in their GGUF encoding */
+uint64_t nt_engine_resident_weight_bytes(nt_engine_t e);   /* what they occupy in HBM now: GGUF bytes still resident + the decode repack + the unpack scratch */
 int  nt_engine_max_context(nt_engine_t e);
 /* which form the fused decode step takes at the current position: "fused (5 launches/layer)", or (EXPERIMENTS=1 builds with the
  * "persistent" option on) "persistent (...)" */

@@ -5,15 +5,65 @@
 // src/cuda/{gemm,attention,rmsnorm,rotary,elementwise,softmax}.cu; every caller in src/model/*.cpp and
 // tests/test_gemm.cpp stays untouched.  Error behaviour is the reference's: launches are fire-and-forget, an
 // unsupported GEMV dtype only prints (src/cuda/gemm.cu:801-803, :866-868).
+//
+// Round 5: the matrix-core decode GEMV of the K-quant formats (csrc/gemv_rp.hip) reads an ENGINE-OWNED repack of the tensor, not the raw GGUF
+// blocks (SURVEY 8(b) "Ownership": launchers never allocate) -- so the repack belongs to this binding.  nt_hip_repack.h declares
+// nt::cuda::hip_register_resident_weight(): ONE call per resident K-quant matrix where the reference hands its weights to the layers
+// (Attention::set_weights, src/model/attention.cpp:80-95; FFN::init, src/model/ffn.cpp:7-29) packs it (ntk_rp_pack, once, on the device) and
+// from then on launch_gemv() on that pointer runs ntk_gemv_rp.  For the reference's UNMODIFIED binaries the same registration happens lazily at
+// the first launch_gemv() of a pointer when NT_HIP_AUTO_REPACK=1 is set -- valid for resident weights only (the streaming / tiered modes
+// rewrite their weight buffers in place; those are out of scope and must leave the switch off).
 #include "cuda/kernels.h"   // the reference's own header (include path: <reference>/src)
+#include "nt_hip_repack.h"
 #include "ntk.h"
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace nt {
 namespace cuda {
 
 static void report(const char* what, int st) {
     if (st != NTK_OK) fprintf(stderr, "%s: %s\n", what, ntk_status_string(st));
+}
+
+namespace {
+struct Packed { void* rp; int out_f, in_f, dt; };
+std::unordered_map<const void*, Packed>& registry() { static std::unordered_map<const void*, Packed> r; return r; }
+std::mutex g_mu;
+unsigned long g_rp_launches = 0, g_raw_launches = 0;
+bool auto_repack() {
+    static const bool on = [] { const char* e = getenv("NT_HIP_AUTO_REPACK"); return e && atoi(e) != 0; }();
+    return on;
+}
+void print_stats() {
+    if (const char* e = getenv("NT_HIP_REPACK_STATS")) {
+        if (atoi(e)) fprintf(stderr, "nt_hip_repack: %zu tensors repacked, launch_gemv: %lu on ntk_gemv_rp (matrix cores), %lu on ntk_gemv (raw GGUF blocks)\n",
+                             registry().size(), g_rp_launches, g_raw_launches);
+    }
+}
+}  // namespace
+
+bool hip_register_resident_weight(const void* W, int out_f, int in_f, DType dt, void* stream) {
+    if (!W) return false;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = registry().find(W);
+    if (it != registry().end()) return it->second.out_f == out_f && it->second.in_f == in_f && it->second.dt == (int)dt;
+    const size_t n = ntk_rp_bytes((int)dt, out_f, in_f);
+    if (n == 0) return false;                                    // not a K-quant matrix / a shape the repack does not take: stays on ntk_gemv
+    void* rp = nt_hip_malloc(n + 256);
+    if (!rp) return false;
+    if (ntk_rp_pack(rp, W, out_f, in_f, (int)dt, stream) != NTK_OK) { nt_hip_free(rp); return false; }
+    if (registry().empty()) atexit(print_stats);
+    registry()[W] = Packed{rp, out_f, in_f, (int)dt};
+    return true;
+}
+void hip_release_resident_weights() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)ntk_device_synchronize();
+    for (auto& kv : registry()) nt_hip_free(kv.second.rp);
+    registry().clear();
 }
 
 void launch_rmsnorm(float* o, const float* in, const float* w, int batch, int hidden, float eps, void* s) {
@@ -31,6 +81,24 @@ void launch_masked_softmax(float* o, const float* in, const bool* mask, int rows
     report("launch_masked_softmax", ntk_masked_softmax(o, in, reinterpret_cast<const uint8_t*>(mask), rows, cols, s));
 }
 void launch_gemv(float* y, const void* W, const float* x, int out_f, int in_f, DType dt, void* s) {
+    if (dt == DType::Q4_K_M || dt == DType::Q5_K || dt == DType::Q6_K) {   // a registered (resident, repacked) matrix: the matrix-core GEMV
+        const void* rp = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            auto it = registry().find(W);
+            if (it != registry().end() && it->second.out_f == out_f && it->second.in_f == in_f && it->second.dt == (int)dt) rp = it->second.rp;
+        }
+        if (!rp && auto_repack() && hip_register_resident_weight(W, out_f, in_f, dt, s)) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            rp = registry()[W].rp;
+        }
+        if (rp) {
+            const int st = ntk_gemv_rp(y, rp, x, out_f, in_f, (int)dt, s);
+            if (st == NTK_OK) { ++g_rp_launches; return; }
+            if (st != NTK_E_SHAPE && st != NTK_E_ALIGN && st != NTK_E_DTYPE) { report("launch_gemv (repacked)", st); return; }
+        }
+    }
+    ++g_raw_launches;
     const int st = ntk_gemv(y, W, x, out_f, in_f, (int)dt, s);
     if (st == NTK_E_DTYPE) fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dtype_name(dt));
     else report("launch_gemv", st);

@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         "ntk_rp_bytes": (sz, [i, i, i]),
         "ntk_rp_pack": (i, [vp, vp, i, i, i, vp]),
         "ntk_rp_dequant": (i, [vp, vp, i, i, i, vp]),
+        "ntk_rp_unpack": (i, [vp, vp, i, i, i, vp]),
         "ntk_gemv_rp": (i, [vp, vp, vp, i, i, i, vp]),
         "ntk_gemv_rp_fused": (i, [C.POINTER(GemvSeg), i, vp, i, vp, f, vp, i, vp]),
         "ntk_debug_rp_prologue": (i, [vp, vp, vp, f, i, i, i, vp]),

@@ -55,7 +55,7 @@ int nt_engine_set_option(nt_engine_t e, const char* key, const char* value) {
     else if (k == "device_sampling") E(e)->options().device_sampling = on;
     else if (k == "f16_prefill" || k == "bf16_prefill") E(e)->model().set_bf16_prefill(on);   // (the round-2 name stays accepted)
     else if (k == "fuse_attention") E(e)->model().set_fuse_attention(on);
-    else if (k == "repack") E(e)->model().set_repack(on);
+    else if (k == "repack") return E(e)->model().set_repack(atoi(value));   // 0 raw path, 1 repack + GGUF bytes resident, 2 (default) one resident copy
     else if (k == "persistent") { E(e)->options().persistent = on; E(e)->model().set_persistent(atoi(value)); }   // 1: decode_persistent.hip, 2: layer_engine.hip
     else if (k == "synth_threads") E(e)->options().synth_threads = atoi(value);
     else return NTK_E_SHAPE;
@@ -205,6 +205,7 @@ int nt_engine_detokenize(nt_engine_t e, const int* ids, int n, char* out, int ca
 
 uint64_t nt_engine_bytes_per_token(nt_engine_t e, int pos) { return e && E(e)->loaded() ? E(e)->model().bytes_per_token(pos) : 0; }
 uint64_t nt_engine_weight_bytes(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().weight_bytes() : 0; }
+uint64_t nt_engine_resident_weight_bytes(nt_engine_t e) { return e && E(e)->loaded() ? E(e)->model().resident_weight_bytes() : 0; }
 
 int nt_synth_write_gguf(const char* path, const nt_synth_spec* spec, int nthreads) {
     if (!path || !spec) return NTK_E_NULL;

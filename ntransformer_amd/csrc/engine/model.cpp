@@ -67,6 +67,9 @@ void Model::free_all() {
     token_embd_ = output_norm_ = output_ = DevTensor();
     weight_bytes_ = 0;
     repack_bytes_ = 0;
+    raw_freed_bytes_ = 0;
+    raw_scratch_ = nullptr; raw_scratch_bytes_ = raw_cursor_ = 0; raw_err_ = 0;
+    repack_done_ = false;
     output_tied_ = false;
     host_pos_ = 0;
     attn_regime_ = 0;
@@ -305,12 +308,24 @@ int Model::finish_load(int /*max_context*/) {
     }
     if (!stream_) { err_ = "no compute stream"; return NTK_E_NODEVICE; }
     NT_TRY(alloc_buffers());
-    if (repack_) NT_TRY(repack_all());
+    if (repack_) {
+        // ADVICE (round 4): a repack that does not fit must not fail the load -- the raw path decodes every tensor that has no repacked form
+        const int st = repack_all();
+        if (st == NTK_E_NOMEM) {
+            int kept = 0;
+            for (auto& L : layers_) for (DevTensor* t : {&L.wq, &L.wk, &L.wv, &L.wo, &L.w_gate, &L.w_up, &L.w_down}) kept += t->rp ? 0 : 1;
+            fprintf(stderr, "warning: not enough device memory for the decode repack of every matrix: %d projection tensors stay on the raw-GGUF path\n", kept);
+            err_.clear();
+        } else if (st != NTK_OK) {
+            return st;
+        }
+        if (repack_ == 2) NT_TRY(drop_raw_all());
+    }
     if (persistent_wanted_) set_persistent(persistent_wanted_);
     size_t fr = 0, tot = 0;
     ntk_device_mem_info(&fr, &tot);
     fprintf(stderr, "Model loaded successfully! (resident on MI355X: %.2f GB of weights%s)\nFree VRAM: %.1f GB\n",
-            weight_bytes_ / 1073741824.0, repack_bytes_ ? (" + " + std::to_string(repack_bytes_ / 1073741824.0).substr(0, 5) + " GB repacked for decode").c_str() : "",
+            (weight_bytes_ - raw_freed_bytes_) / 1073741824.0, repack_bytes_ ? (" + " + std::to_string(repack_bytes_ / 1073741824.0).substr(0, 5) + " GB repacked for decode").c_str() : "",
             fr / 1073741824.0);
     return NTK_OK;
 }
@@ -323,7 +338,7 @@ int Model::repack_one(DevTensor& t) {
     const size_t n = ntk_rp_bytes(t.dtype, (int)t.out_f, (int)t.in_f);
     if (n == 0 || n > 0xFFFFFFF0ull) return NTK_OK;   // formats / shapes the matrix-core GEMV does not take keep the raw path
     void* d = nt_hip_malloc(n + 256);
-    if (!d) { err_ = "out of device memory (decode repack)"; return NTK_E_NOMEM; }
+    if (!d) return NTK_E_NOMEM;   // (the caller keeps the tensors that did fit and lets the raw path take the rest)
     allocs_.push_back(d);
     const int st = ntk_rp_pack(d, t.ptr, (int)t.out_f, (int)t.in_f, t.dtype, stream_);
     if (st != NTK_OK) { err_ = std::string("decode repack failed: ") + ntk_status_string(st); return st; }
@@ -334,20 +349,97 @@ int Model::repack_one(DevTensor& t) {
 }
 
 int Model::repack_all() {
+    int rc = NTK_OK;
+    auto one = [&](DevTensor& t) { const int st = repack_one(t); if (st != NTK_OK && rc == NTK_OK) rc = st; return st; };
     for (auto& L : layers_) {
-        NT_TRY(repack_one(L.wq)); NT_TRY(repack_one(L.wk)); NT_TRY(repack_one(L.wv)); NT_TRY(repack_one(L.wo));
-        NT_TRY(repack_one(L.w_gate)); NT_TRY(repack_one(L.w_up)); NT_TRY(repack_one(L.w_down));
+        if (one(L.wq) == NTK_E_NOMEM) break;
+        one(L.wk); one(L.wv); one(L.wo); one(L.w_gate); one(L.w_up); one(L.w_down);
+        if (rc == NTK_E_NOMEM) break;
     }
-    NT_TRY(repack_one(output_));
-    return ntk_stream_synchronize(stream_);
+    if (rc != NTK_E_NOMEM) one(output_);
+    repack_done_ = true;
+    const int sy = ntk_stream_synchronize(stream_);
+    return rc != NTK_OK ? rc : sy;
 }
 
-void Model::set_repack(bool on) {
-    if (on == repack_ && (!on || layers_.empty() || repack_bytes_ > 0)) { repack_ = on; return; }
-    repack_ = on;
-    if (layers_.empty()) return;   // before the load: finish_load() decides
+// ---- one resident copy (level 2): the uploaded GGUF bytes of every repacked matrix go; raw_of() unpacks on demand ----
+int Model::drop_raw_all() {
+    size_t need = 0, group = 0;
+    auto grp = [&](std::initializer_list<DevTensor*> ts) {
+        size_t g = 0;
+        for (DevTensor* t : ts) if (t->rp && !(output_tied_ && t->ptr == token_embd_.ptr)) g += (t->nbytes + 255) / 256 * 256 + 256;
+        need = std::max(need, g);
+    };
+    for (auto& L : layers_) { grp({&L.wq, &L.wk, &L.wv}); grp({&L.wo}); grp({&L.w_gate, &L.w_up}); grp({&L.w_down}); }
+    grp({&output_});
+    (void)group;
+    if (need == 0) return NTK_OK;
+    if (!raw_scratch_ || raw_scratch_bytes_ < need) {
+        void* d = nt_hip_malloc(need);
+        if (!d) { fprintf(stderr, "warning: no device memory for the unpack scratch: the GGUF bytes stay resident beside the repack\n"); repack_ = 1; return NTK_OK; }
+        allocs_.push_back(d);
+        raw_scratch_ = d; raw_scratch_bytes_ = need;
+    }
+    auto drop = [&](DevTensor& t) {
+        if (!t.rp || !t.ptr || (output_tied_ && t.ptr == token_embd_.ptr)) return;
+        auto it = std::find(allocs_.begin(), allocs_.end(), t.ptr);
+        if (it != allocs_.end()) allocs_.erase(it);
+        nt_hip_free(t.ptr);
+        t.ptr = nullptr;
+        raw_freed_bytes_ += t.nbytes;
+    };
+    NT_TRY(ntk_stream_synchronize(stream_));
+    for (auto& L : layers_) { drop(L.wq); drop(L.wk); drop(L.wv); drop(L.wo); drop(L.w_gate); drop(L.w_up); drop(L.w_down); }
+    drop(output_);
+    return NTK_OK;
+}
+
+int Model::restore_raw_all() {
+    int rc = NTK_OK;
+    auto back = [&](DevTensor& t) {
+        if (t.ptr || !t.rp || rc != NTK_OK) return;
+        void* d = nt_hip_malloc((t.nbytes + 255) / 256 * 256 + 256);
+        if (!d) { rc = NTK_E_NOMEM; return; }
+        const int st = ntk_rp_unpack(d, t.rp, (int)t.out_f, (int)t.in_f, t.dtype, stream_);
+        if (st != NTK_OK) { nt_hip_free(d); rc = st; return; }
+        allocs_.push_back(d);
+        t.ptr = d;
+        raw_freed_bytes_ -= t.nbytes;
+    };
+    for (auto& L : layers_) { back(L.wq); back(L.wk); back(L.wv); back(L.wo); back(L.w_gate); back(L.w_up); back(L.w_down); }
+    back(output_);
+    const int sy = ntk_stream_synchronize(stream_);
+    return rc != NTK_OK ? rc : sy;
+}
+
+const void* Model::raw_of(const DevTensor& t) {
+    if (t.ptr) return t.ptr;
+    if (!t.rp || !raw_scratch_) { raw_err_ = NTK_E_NULL; return nullptr; }
+    const size_t n = (t.nbytes + 255) / 256 * 256 + 256;
+    if (raw_cursor_ + n > raw_scratch_bytes_) raw_cursor_ = 0;   // (a group never exceeds the scratch: sized for the largest in drop_raw_all)
+    void* d = static_cast<uint8_t*>(raw_scratch_) + raw_cursor_;
+    raw_cursor_ += n;
+    const int st = ntk_rp_unpack(d, t.rp, (int)t.out_f, (int)t.in_f, t.dtype, stream_);
+    if (st != NTK_OK) { raw_err_ = st; return nullptr; }
+    return d;
+}
+
+int Model::set_repack(int level) {
+    level = level < 0 ? 0 : level > 2 ? 2 : level;
+    if (layers_.empty()) { repack_ = level; return NTK_OK; }   // before the load: finish_load() decides
+    if (level == repack_) return NTK_OK;
+    NT_TRY(sync());
     for (auto& row : graphs_) for (auto& gx : row) { if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx)); gx = nullptr; }
-    if (on && repack_all() != NTK_OK) repack_ = false;
+    int rc = NTK_OK;
+    if (level < 2 && raw_freed_bytes_ > 0) rc = restore_raw_all();           // the GGUF bytes come back first (levels 0 and 1 read them)
+    if (rc == NTK_OK && level > 0 && !repack_done_) {
+        rc = repack_all();
+        if (rc == NTK_E_NOMEM) { fprintf(stderr, "warning: decode repack incomplete (device memory): the rest stays on the raw path\n"); rc = NTK_OK; err_.clear(); }
+    }
+    if (rc != NTK_OK) { err_ = std::string("set_repack: ") + ntk_status_string(rc); return rc; }
+    repack_ = level;
+    if (level == 2) rc = drop_raw_all();
+    return rc;
 }
 
 int Model::alloc_buffers() {   // transformer.cpp:330-391
@@ -358,6 +450,9 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
         if (p) { allocs_.push_back(p); if (zero) nt_hip_memset(p, 0, bytes); }
         return p;
     };
+    // the attention kernels address a layer's cache rows with 32-bit byte offsets (attention.hip): a context whose per-layer cache reaches
+    // 3.75 GiB is refused here, at load, rather than as NTK_E_SHAPE from the first decode step (8 KV heads of 128: 1.9 M positions)
+    if (S * per * sizeof(uint16_t) >= 0xF0000000ull) { err_ = "context too long: one layer's K cache must stay below 3.75 GiB (32-bit row offsets)"; return NTK_E_SHAPE; }
     const size_t kvb = L * S * per * sizeof(uint16_t);
     k_cache_ = (uint16_t*)dev(kvb, true);
     v_cache_ = (uint16_t*)dev(kvb, true);
@@ -374,7 +469,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_token_ = (int*)dev(64, true);
     argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
-    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, 32), false);
+    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, kMaxAttnSplits), false);
     h_token_ = (int*)nt_hip_malloc_host(64);
     h_ring_ = (unsigned long long*)nt_hip_malloc_host(64);
     if (h_ring_) memset(h_ring_, 0, 64);
@@ -449,7 +544,8 @@ float* Model::forward(const int* tokens, int T, int start_pos) {
     float* last = hidden_ + (size_t)(T - 1) * H;
     ok(ntk_rmsnorm(last, last, (const float*)output_norm_.ptr, 1, H, cfg_.norm_eps, s));   // in place, :658-659
     {
-        const int st = ntk_gemv(logits_, output_.ptr, last, (int)output_.out_f, (int)output_.in_f, output_.dtype, s);
+        raw_begin();
+        const int st = ntk_gemv(logits_, raw_of(output_), last, (int)output_.out_f, (int)output_.in_f, output_.dtype, s);
         if (st == NTK_E_DTYPE) fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dtype_name(output_.dtype));   // gemm.cu:801-803
         else ok(st);
     }
@@ -475,8 +571,9 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
     float* up_buf = gate_buf + (size_t)T * I;
     int rc = NTK_OK;
     auto ok = [&](int st) { if (st != NTK_OK && rc == NTK_OK) rc = st; };
-    auto gemv = [&](float* y, const DevTensor& w, const float* x) {
-        const int st = ntk_gemv(y, w.ptr, x, (int)w.out_f, (int)w.in_f, w.dtype, s);
+    // (wp: the tensor's raw GGUF blocks -- resident, or unpacked from the repack by raw_of() once per projection, not per token)
+    auto gemv = [&](float* y, const DevTensor& w, const void* wp, const float* x) {
+        const int st = ntk_gemv(y, wp, x, (int)w.out_f, (int)w.in_f, w.dtype, s);
         if (st == NTK_E_DTYPE) fprintf(stderr, "Unsupported dtype for GEMV: %s\n", dtype_name(w.dtype));   // gemm.cu:801-803
         else ok(st);
     };
@@ -486,17 +583,19 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
     const bool bf16_now = bf16_prefill_ && gemm_ws_ && T > 16;
     const float* planes_of = nullptr;   // the x whose FP16 planes sit in gemm_ws_ (Q, K, V and gate, up share one x)
     auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
+        raw_begin();
+        const void* wp = raw_of(w);
         if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
             if (bf16_now)   // FP16 matrix cores, up to 1024 tokens per pass (Q8_0 / Q4_K / Q5_K / Q6_K)
-                st = ntk_gemm_quant_ws(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
+                st = ntk_gemm_quant_ws(Y, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
                                        X == planes_of ? 1 : 0, s);
             if (st == NTK_OK) planes_of = X;
             if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)
-                st = ntk_gemm_quant(Y, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s);
+                st = ntk_gemm_quant(Y, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s);
             if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }   // those two: shapes only the per-token loop takes
         }
-        for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, X + (size_t)t * xstride);
+        for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, wp, X + (size_t)t * xstride);
     };
     // matrices that share X (Q | K | V, gate | up): those of one format go out as ONE launch of the FP16 GEMM, the rest one by one
     auto project_many = [&](float* const* Ys, const DevTensor* const* Ws, int n, const float* X) {
@@ -507,8 +606,10 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
                 ntk_gemv_seg segs[3];
                 int idx[3], m = 0;
                 for (int b = a; b < n; ++b)
-                    if (!done[b] && Ws[b]->dtype == Ws[a]->dtype && Ws[b]->in_f == Ws[a]->in_f) { segs[m] = {Ws[b]->ptr, Ys[b], (int)Ws[b]->out_f, Ws[b]->dtype}; idx[m++] = b; }
+                    if (!done[b] && Ws[b]->dtype == Ws[a]->dtype && Ws[b]->in_f == Ws[a]->in_f) idx[m++] = b;
                 if (m < 2) continue;
+                raw_begin();   // (the group's tensors side by side in the unpack scratch when their GGUF bytes are not resident)
+                for (int k = 0; k < m; ++k) segs[k] = {raw_of(*Ws[idx[k]]), Ys[idx[k]], (int)Ws[idx[k]]->out_f, Ws[idx[k]]->dtype};
                 const int st = ntk_gemm_quant_ws_multi(segs, m, X, T, (int)Ws[a]->in_f, gemm_ws_, gemm_ws_bytes_, X == planes_of ? 1 : 0, s);
                 if (st == NTK_OK) { planes_of = X; for (int k = 0; k < m; ++k) done[idx[k]] = true; }
                 else if (st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) { ok(st); return; }
@@ -528,11 +629,13 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
         }
         if (batched && is_quant(w.dtype) && (size_t)w.out_f == (size_t)H && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
+            raw_begin();
+            const void* wp = raw_of(w);
             if (bf16_now)
-                st = ntk_gemm_quant_ws(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, s);
+                st = ntk_gemm_quant_ws(hidden_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, s);
             planes_of = nullptr;   // (this projection rewrites hidden_, and the next group has a new x)
             if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)
-                st = ntk_gemm_quant(hidden_, w.ptr, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s);
+                st = ntk_gemm_quant(hidden_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s);
             if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }
         }
         project(residual_, w, X, H, xstride);
@@ -664,7 +767,6 @@ int Model::enqueue_token(bool greedy) {
     {
         const DevTensor& w = output_;
         if (is_quant(w.dtype)) {
-            ntk_gemv_seg seg = {w.ptr, logits_, (int)w.out_f, w.dtype};
             prof_mark(0, true);
             int st = NTK_E_DTYPE;
             if (repack_ && w.rp && (rp_mask() & 16)) {
@@ -672,7 +774,11 @@ int Model::enqueue_token(bool greedy) {
                 st = ntk_gemv_rp_fused(&rs, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s);
                 if (st != NTK_OK && st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) return st;
             }
-            if (st != NTK_OK) NT_TRY(ntk_gemv_fused(&seg, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s));
+            if (st != NTK_OK) {
+                raw_begin();
+                ntk_gemv_seg seg = {raw_of(w), logits_, (int)w.out_f, w.dtype};
+                NT_TRY(ntk_gemv_fused(&seg, 1, hidden_, (int)w.in_f, (const float*)output_norm_.ptr, cfg_.norm_eps, nullptr, 0, s));
+            }
             prof_mark(0, false);
         } else {
             NT_TRY(ntk_rmsnorm(residual_ + H, hidden_, (const float*)output_norm_.ptr, 1, (int)w.in_f, cfg_.norm_eps, s));
@@ -758,7 +864,8 @@ int Model::enqueue_layers(int first, int last_layer) {
             for (int a = 0; a < n; ++a) { all_quant = all_quant && is_quant(ws[a]->dtype); mixed = mixed || ws[a]->dtype != ws[0]->dtype; }
             if (all_quant && mixed) {
                 ntk_gemv_seg segs[3];
-                for (int a = 0; a < n; ++a) segs[a] = {ws[a]->ptr, ys[a], (int)ws[a]->out_f, ws[a]->dtype};
+                raw_begin();
+                for (int a = 0; a < n; ++a) segs[a] = {raw_of(*ws[a]), ys[a], (int)ws[a]->out_f, ws[a]->dtype};
                 mark(0, true);
                 const int st = ntk_gemv_fused(segs, n, x, (int)ws[0]->in_f, nw, cfg_.norm_eps, nullptr, 0, s);
                 mark(0, false);
@@ -778,16 +885,18 @@ int Model::enqueue_layers(int first, int last_layer) {
                     xin = residual_ + H;
                 }
                 float* y = resid ? residual_ : ys[a];
-                NT_TRY(ntk_gemv(y, w.ptr, xin, (int)w.out_f, (int)w.in_f, w.dtype, s));
+                raw_begin();
+                NT_TRY(ntk_gemv(y, raw_of(w), xin, (int)w.out_f, (int)w.in_f, w.dtype, s));
                 if (resid) NT_TRY(ntk_add(ys[a], resid, residual_, (int)w.out_f, s));
                 done[a] = true;
                 continue;
             }
             ntk_gemv_seg segs[3];
             int m = 0;
+            raw_begin();
             for (int b = a; b < n; ++b) {
                 if (done[b] || ws[b]->dtype != w.dtype) continue;
-                segs[m++] = {ws[b]->ptr, ys[b], (int)ws[b]->out_f, ws[b]->dtype};
+                segs[m++] = {raw_of(*ws[b]), ys[b], (int)ws[b]->out_f, ws[b]->dtype};
                 done[b] = true;
             }
             mark(0, true);
@@ -814,7 +923,8 @@ int Model::enqueue_layers(int first, int last_layer) {
 #ifdef NTK_EXPERIMENTS
         if (attn_regime_ == 0 && fuse_attention_ && attn_sync_ && is_quant(L.wo.dtype) && tp_world_ == 1) {
             // attention producers inside the Wo launch: one launch, one boundary and one first-byte latency less per layer
-            ntk_gemv_seg wo = {L.wo.ptr, hidden_, (int)L.wo.out_f, L.wo.dtype};
+            raw_begin();
+            ntk_gemv_seg wo = {raw_of(L.wo), hidden_, (int)L.wo.out_f, L.wo.dtype};
             mark(0, true);
             const int st = ntk_attention_gemv_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
                                                     cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale, &wo, hidden_,
@@ -843,7 +953,6 @@ int Model::enqueue_layers(int first, int last_layer) {
     ffn:
 #endif
         if (is_quant(L.w_gate.dtype) && L.w_gate.dtype == L.w_up.dtype) {
-            ntk_gemv_seg segs[2] = {{L.w_gate.ptr, gate_buf, I, L.w_gate.dtype}, {L.w_up.ptr, up_buf, I, L.w_up.dtype}};
             mark(0, true);
             int st = NTK_E_DTYPE;
             if (repack_ && L.w_gate.rp && L.w_up.rp && (rp_mask() & 4)) {
@@ -851,7 +960,11 @@ int Model::enqueue_layers(int first, int last_layer) {
                 st = ntk_gemv_rp_fused(rs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s);
                 if (st != NTK_OK && st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) return st;
             }
-            if (st != NTK_OK) NT_TRY(ntk_gemv_fused(segs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s));
+            if (st != NTK_OK) {
+                raw_begin();
+                ntk_gemv_seg segs[2] = {{raw_of(L.w_gate), gate_buf, I, L.w_gate.dtype}, {raw_of(L.w_up), up_buf, I, L.w_up.dtype}};
+                NT_TRY(ntk_gemv_fused(segs, 2, hidden_, H, (const float*)L.ffn_norm.ptr, cfg_.norm_eps, nullptr, 1, s));
+            }
             mark(0, false);
         } else {
             const DevTensor* ws[2] = {&L.w_gate, &L.w_up};
@@ -958,12 +1071,13 @@ void Model::set_persistent(int level) {   // 0 off, 1 the round-2 token kernel (
 #else
     if (persistent_plan_ && persistent_kind_ != (level == 2 ? 2 : 1)) {   // the other kernel's plan: drop it and its captured graphs
         (void)sync();
-        for (auto& row : graphs_) { if (row[3]) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(row[3])); row[3] = nullptr; }
+        for (auto& row : graphs_) { if (row[kPersistentSlot]) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(row[kPersistentSlot])); row[kPersistentSlot] = nullptr; }
         if (persistent_kind_ == 2) ntk_layer_engine_plan_destroy(persistent_plan_); else ntk_persistent_plan_destroy(persistent_plan_);
         persistent_plan_ = nullptr;
     }
 #endif
     if (!on || tp_world_ != 1 || layers_.empty()) return;
+    if (raw_freed_bytes_ > 0) (void)set_repack(1);   // the persistent kernels stream the GGUF bytes themselves: those must be resident
     if (!persistent_plan_) (void)build_persistent_plan(level == 2 ? 2 : 1);   // built on first use (EXPERIMENTS=1 builds only): it allocates device memory
     persistent_on_ = persistent_plan_ != nullptr;
 }
@@ -1127,7 +1241,7 @@ void Model::pick_attention_regime() {
 int Model::decode_step_fused(bool greedy, bool use_graph) {
     pick_attention_regime();
     if (!use_graph) return enqueue_token(greedy);
-    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? 3 : attn_regime_];
+    ihipGraphExec_t*& slot = graphs_[greedy ? 1 : 0][use_persistent_now() ? kPersistentSlot : attn_regime_];
     hipStream_t st = static_cast<hipStream_t>(stream_);
     if (!slot) {   // capture once: every per-token quantity (token id, position) lives in device memory
         hipGraph_t g = nullptr;

@@ -58,11 +58,19 @@ public:
     //    once, one 32-row chunk per wave up to 4096 positions (12.75 us at 4095; 70B geometry 13.5 vs 16.5; decode behind a 3900-token
     //    prompt 467 -> 482 tokens/s; with 16 splits the two forms tie between 2300 and 3300 positions:
     //    profiles/r04_attention_kvhead_form.txt); other head sizes: the walk with 16 splits from 16384 positions.
+    //    Contexts beyond 4096 (round 5; the reference's -c / --ctx-size, main.cpp:74-75): 32 splits STAY the best count however long the context --
+    //    8B geometry, us per layer incl. the combine launch, caches past the Infinity Cache (tools/attn_bench.py --max-seq,
+    //    profiles/r05_attention_long_context.txt): 8191 positions 17.2 / 14.6 / 19.1 / 27.2 with 16 / 32 / 64 / 128 splits; 32767: 30.1 /
+    //    35.8 / 42.8 / 59.4 with 32 / 64 / 128 / 256 (4.45 TB/s of cache bytes at 32); 131071: 103 / 108 / 118 with 64 / 128 / 256 (5.2
+    //    TB/s): one workgroup per CU (8 KV heads x 32), the chunks of 32 rows go round ALL waves of the launch, and every further split
+    //    costs a redundant RoPE prologue and a longer serial walk in the combine launch.
+    static constexpr int kAttnRegimes = 3;
     static int attention_regime(int pos, int head_dim) {
         if (pos < 544) return 0;
         return pos < (head_dim == 128 ? 3072 : 16384) ? 1 : 2;
     }
     static int attention_splits(int regime, int head_dim) { return regime <= 1 ? 8 : head_dim == 128 ? 32 : 16; }
+    static constexpr int kMaxAttnSplits = 32;
     void pick_attention_regime();
     int sync();
     int host_token() const;                 // token written by the last device argmax (after sync)
@@ -94,10 +102,17 @@ public:
     int persistent_kind() const { return persistent_plan_ ? persistent_kind_ : 0; }
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
     // Decode GEMVs of the K-quant matrices from the load-time repack (ntk_gemv_rp_fused) instead of the raw GGUF blocks (ntk_gemv_fused).
-    // The repack is made at load unless the option was switched off BEFORE the load; the switch itself works at any time.
-    void set_repack(bool on);
-    bool repack() const { return repack_; }
+    // level 0: no repack (raw path).  1: repack AND the uploaded GGUF bytes stay resident (K-quant weights x 2 in HBM; rounds 4's form).
+    // 2 (default, round 5): ONE resident copy -- the GGUF bytes of every repacked matrix are freed after the repack; the launches that read raw
+    // blocks (prompt GEMM, the 1:1 ntk_gemv sequence, fallbacks) get the tensor unpacked into a scratch right in front of them
+    // (ntk_rp_unpack: byte-exact inverse; + 2 x the tensor's bytes of HBM traffic per prompt pass, ~4 % of a 1024-token chunk).
+    // The repack is made at load unless the option was switched off BEFORE the load; switching after the load works in every direction
+    // (2 -> 0 / 1 re-materialises the GGUF bytes from the repack).  Returns a status (NTK_E_NOMEM: the model keeps running on what it has).
+    int set_repack(int level);
+    bool repack() const { return repack_ != 0; }
+    int repack_level() const { return repack_; }
     uint64_t repack_bytes() const { return repack_bytes_; }
+    uint64_t resident_weight_bytes() const { return weight_bytes_ - raw_freed_bytes_ + repack_bytes_ + raw_scratch_bytes_; }
     void set_bf16_prefill(bool on) { bf16_prefill_ = on; }   // batched prompt: FP16-MFMA (gemm_f16.hip; the option keeps its round-2 name) or the F32-MFMA form (16)
     bool persistent_available() const { return persistent_plan_ != nullptr; }
     void* persistent_plan() const { return persistent_plan_; }
@@ -138,6 +153,12 @@ private:
     int upload_shard(DevTensor& dst, const void* host_full, int dtype, int64_t in_f, int64_t out_f, size_t nbytes_full, Shard how);
     int repack_all();                 // the repacked form of every K-quant projection (after the upload)
     int repack_one(DevTensor& t);
+    int drop_raw_all();               // level 2: free the GGUF bytes of every repacked matrix, size the unpack scratch
+    int restore_raw_all();            // ... and back: the GGUF bytes re-materialised from the repack
+    // the raw GGUF blocks of a projection for a launch that reads them: the resident bytes, or the tensor unpacked into the scratch (stream
+    // ordered; raw_begin() starts a new group of tensors that must be valid together: Q | K | V, gate | up)
+    void raw_begin() { raw_cursor_ = 0; }
+    const void* raw_of(const DevTensor& t);
     int tp_check_shapes();            // the head / FFN / block divisibility the slices need
     int tp_allreduce(float* hidden, int n);   // hidden += sum over ranks of the partial vectors in the current slot
     float* tp_slot() const;           // where the next partial vector goes
@@ -184,9 +205,9 @@ private:
     struct Timed { int cls; void* a; void* b; int n; bool shared_a; };   // n launches between events a and b
     bool prof_coarse_ = false;
     std::vector<Timed>* prof_ = nullptr;   // non-null while profile_token() runs
-    // one captured token per (greedy?, attention regime): regime 0 = single-pass attention, 1 = 8 KV splits, 2 = 16
-    // (the persistent form of regime 0 has its own slot, index 3)
-    ihipGraphExec_t* graphs_[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // [greedy][attention regime 0..2, 3 = persistent]
+    // one captured token per (greedy?, attention regime)
+    static constexpr int kPersistentSlot = kAttnRegimes;   // the persistent forms of regime 0 have their own slot
+    ihipGraphExec_t* graphs_[2][kAttnRegimes + 1] = {};   // [greedy][attention regime 0..2, 3 = persistent]
     int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
     int attn_regime_ = 0;            // regime enqueue_token() emits
     float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention
@@ -194,8 +215,13 @@ private:
     size_t gemm_ws_bytes_ = 0;
     bool bf16_prefill_ = true;
     unsigned* attn_sync_ = nullptr;  // 3 words for ntk_attention_gemv_fused (attention producers inside the Wo launch)
-    bool repack_ = true;             // decode GEMVs read the repacked K-quant tensors
+    int repack_ = 2;                 // 0 raw path, 1 repack + raw resident, 2 repack only (one resident copy)
+    bool repack_done_ = false;       // repack_all() ran on the loaded tensors
     uint64_t repack_bytes_ = 0;
+    uint64_t raw_freed_bytes_ = 0;   // GGUF bytes released after the repack (level 2)
+    void* raw_scratch_ = nullptr;    // where raw_of() unpacks to
+    size_t raw_scratch_bytes_ = 0, raw_cursor_ = 0;
+    int raw_err_ = 0;                // first failure inside raw_of() (it returns a pointer): surfaced by the caller's next status check
     bool fuse_attention_ = false;    // attention + Wo projection as one launch: measured SLOWER than two launches (profiles/r02_*): opt-in
     int tp_rank_ = 0, tp_world_ = 1;
     void* tp_comm_ = nullptr;        // this rank's communication buffer (flags + two slots of max_seq x H floats)

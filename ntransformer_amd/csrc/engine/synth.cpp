@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -114,9 +115,34 @@ bool use_more_bits(int i, int n) { return i < n / 8 || i >= 7 * n / 8 || (i - n 
 
 }  // namespace
 
+// "Q4_K_M@<n>:<i0>,<i1>,..." -- a SAMPLE of the layers of an n-layer Q4_K_M model: layer j of this model gets the tensor types layer i_j has there
+// (tests: the `use_more_bits` borders of the 80-layer 70B mix in an 8-layer file).  Returns false on a malformed list.
+static bool parse_layer_sample(const std::string& mix, int layers, int& of, std::vector<int>& map) {
+    of = 0; map.clear();
+    if (mix.compare(0, 7, "Q4_K_M@") != 0) return true;
+    const size_t colon = mix.find(':');
+    if (colon == std::string::npos) return false;
+    of = atoi(mix.substr(7, colon - 7).c_str());
+    size_t at = colon + 1;
+    while (at <= mix.size()) {
+        const size_t comma = mix.find(',', at);
+        const std::string tok = mix.substr(at, comma == std::string::npos ? std::string::npos : comma - at);
+        if (tok.empty()) return false;
+        map.push_back(atoi(tok.c_str()));
+        if (comma == std::string::npos) break;
+        at = comma + 1;
+    }
+    if (of <= 0 || (int)map.size() != layers) return false;
+    for (int i : map) if (i < 0 || i >= of) return false;
+    return true;
+}
+
 bool synth_plan(const SynthSpec& s, std::vector<SynthTensor>& out) {
     out.clear();
-    const bool km = s.mix == "Q4_K_M";
+    int sample_of = 0;
+    std::vector<int> sample;
+    if (!parse_layer_sample(s.mix, s.layers, sample_of, sample)) return false;
+    const bool km = s.mix == "Q4_K_M" || sample_of > 0;
     const int base = km ? 12 : mix_type(s.mix);
     if (base < 0 || s.heads <= 0 || s.kv_heads <= 0 || s.hidden % s.heads) return false;
     const int hd = s.hidden / s.heads;
@@ -129,7 +155,7 @@ bool synth_plan(const SynthSpec& s, std::vector<SynthTensor>& out) {
     add("token_embd.weight", embd_t, s.hidden, s.vocab, std::sqrt((double)s.hidden));
     for (int i = 0; i < s.layers; ++i) {
         const std::string p = "blk." + std::to_string(i) + ".";
-        const bool more = km && use_more_bits(i, s.layers);
+        const bool more = km && (sample_of > 0 ? use_more_bits(sample[i], sample_of) : use_more_bits(i, s.layers));
         const int v_t = more ? 14 : (km && s.heads / s.kv_heads >= 4 && s.hidden >= 8192 ? 13 : base);
         const int down_t = more ? 14 : base;
         add(p + "attn_norm.weight", 0, s.hidden, 1, 0);

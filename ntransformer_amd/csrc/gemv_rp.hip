@@ -125,6 +125,86 @@ __global__ __launch_bounds__(128) void rp_pack_kernel(uint8_t* __restrict__ dst,
     }
 }
 
+// ---- the raw GGUF blocks back from the repacked form (round 5: ONE resident copy of a K-quant matrix -- the engine frees the uploaded GGUF bytes
+//      after the repack and, for the launches that read raw blocks (the prompt GEMM of gemm_f16.hip, the 1:1 ntk_gemv), unpacks the tensor into
+//      a scratch right in front of them).  Exact inverse of rp_pack_kernel: the repack holds the same integers and the same 6-bit / int8 scales,
+//      so the bytes come back as they were uploaded (tests/test_gemv_rp.py::test_unpack_restores_the_gguf_bytes).  One workgroup per item
+//      (16 rows x one 256-column super-block): the item's planes into LDS, then every thread assembles output words. ----
+template <int DT>
+__device__ __forceinline__ int rp_q_lds(const uint8_t* p1, int i, int c) {   // quant of (row i, column c of the super-block), as rp_dequant_kernel
+    using F = Rp<DT>;
+    const int s = c >> 7, h = (c >> 6) & 1, kg = (c >> 4) & 3, b = c & 15, l = 16 * kg + i;
+    const uint8_t* ps = p1 + (size_t)s * F::S1;
+    const int by = ps[16 * l + b];
+    int q = h ? (by >> 4) : (by & 15);
+    const int v = b >> 2, y = b & 3;
+    if constexpr (DT == NTK_DT_Q5_K) q |= (int)((*reinterpret_cast<const uint32_t*>(ps + 1024 + 4 * l) >> (8 * y + 4 * h + v)) & 1u) << 4;
+    if constexpr (DT == NTK_DT_Q6_K) q |= (int)((*reinterpret_cast<const uint32_t*>(ps + 1024 + 8 * l + 4 * h) >> (8 * y + 2 * v)) & 3u) << 4;
+    return q;
+}
+template <int DT>
+__device__ __forceinline__ uint32_t rp_raw_byte(const uint8_t* p1, const uint8_t* p2, int i, int B) {   // byte B of row i's GGUF block
+    if constexpr (DT == NTK_DT_Q6_K) {   // ql[128] qh[64] scales[16] d   (types.h:132-137)
+        if (B < 128) {
+            const int n = B >> 6, l = B & 31, odd = (B >> 5) & 1;              // ql[64 n + l + 32 odd]: q(128n + 32 odd + l) | q(128n + 64 + 32 odd + l) << 4
+            const int c0 = 128 * n + 32 * odd + l;
+            return (uint32_t)((rp_q_lds<DT>(p1, i, c0) & 15) | ((rp_q_lds<DT>(p1, i, c0 + 64) & 15) << 4));
+        }
+        if (B < 192) {
+            const int n = (B - 128) >> 5, l = (B - 128) & 31;
+            uint32_t v = 0;
+#pragma unroll
+            for (int quarter = 0; quarter < 4; ++quarter) v |= (uint32_t)(rp_q_lds<DT>(p1, i, 128 * n + 32 * quarter + l) >> 4) << (2 * quarter);
+            return v;
+        }
+        if (B < 208) return p2[16 * i + (B - 192)];
+        return p2[256 + 2 * i + (B - 208)];
+    } else {                             // d dmin scales[12] (qh[32]) qs[128]   (types.h:112-128)
+        constexpr int QS0 = DT == NTK_DT_Q5_K ? 48 : 16;
+        if (B < 4) return p2[256 + 4 * i + B];
+        if (B < 16) {                    // the 6-bit (scale, min) pairs, packed as gemm.cu:206-222 unpacks them
+            const int j = (B - 4) & 3, grp = (B - 4) >> 2;
+            const uint32_t sc_lo = p2[16 * i + j], sc_hi = p2[16 * i + 4 + j], mn_lo = p2[16 * i + 8 + j], mn_hi = p2[16 * i + 12 + j];
+            if (grp == 0) return (sc_lo & 63u) | ((sc_hi >> 4) << 6);
+            if (grp == 1) return (mn_lo & 63u) | ((mn_hi >> 4) << 6);
+            return (sc_hi & 15u) | ((mn_hi & 15u) << 4);
+        }
+        if (DT == NTK_DT_Q5_K && B < 48) {
+            const int l = B - 16;
+            uint32_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v |= (uint32_t)((rp_q_lds<DT>(p1, i, 64 * (k >> 1) + 32 * (k & 1) + l) >> 4) & 1) << k;
+            return v;
+        }
+        const int b = B - QS0, chunk = b >> 5, l = b & 31;
+        return (uint32_t)((rp_q_lds<DT>(p1, i, 64 * chunk + l) & 15) | ((rp_q_lds<DT>(p1, i, 64 * chunk + 32 + l) & 15) << 4));
+    }
+}
+template <int DT>
+__global__ __launch_bounds__(256) void rp_unpack_kernel(uint8_t* __restrict__ raw, const uint8_t* __restrict__ rp, int rows, int nsb, size_t p2_off) {
+    using F = Rp<DT>;
+    __shared__ __attribute__((aligned(16))) uint8_t img[2 * F::S1 + F::S2];
+    const int item = blockIdx.x, tile = item / nsb, sb = item - tile * nsb, t = threadIdx.x;
+    const uint8_t* g1 = rp + (size_t)item * (2 * F::S1);
+    const uint8_t* g2 = rp + p2_off + (size_t)item * F::S2;
+    for (int k = t; k < 2 * F::S1 / 16; k += 256) *reinterpret_cast<u4*>(img + 16 * k) = *reinterpret_cast<const u4*>(g1 + 16 * k);
+    for (int k = t; k < F::S2 / 16; k += 256) *reinterpret_cast<u4*>(img + 2 * F::S1 + 16 * k) = *reinterpret_cast<const u4*>(g2 + 16 * k);
+    __syncthreads();
+    const uint8_t* p1 = img;
+    const uint8_t* p2 = img + 2 * F::S1;
+    constexpr int UB = DT == NTK_DT_Q6_K ? 2 : 4, U = F::BB / UB;   // Q6_K blocks are 210 bytes at 2-byte alignment: halfword units
+    for (int k = t; k < 16 * U; k += 256) {
+        const int i = k / U, u = k - i * U, row = 16 * tile + i;
+        if (row >= rows) continue;
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < UB; ++e) w |= rp_raw_byte<DT>(p1, p2, i, UB * u + e) << (8 * e);
+        uint8_t* dst = raw + ((size_t)row * nsb + sb) * F::BB + (size_t)UB * u;
+        if constexpr (UB == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)w;
+        else *reinterpret_cast<uint32_t*>(dst) = w;
+    }
+}
+
 // the weights back as floats from the repacked form, with the block formulas of SURVEY Appendix A evaluated product by product
 // (no contraction): w = (d sc) q - (dmin m)   /   w = (d sc) (q - 32).  out [rows][in].  Test / parity instrumentation.
 template <int DT>
@@ -733,6 +813,24 @@ int ntk_rp_pack(void* dst, const void* raw, int rows, int in_features, int dtype
     if (dtype == NTK_DT_Q4_K) hipLaunchKernelGGL(ntk::rp_pack_kernel<NTK_DT_Q4_K>, g, b, 0, st, d, r, rows, nsb, p2);
     else if (dtype == NTK_DT_Q5_K) hipLaunchKernelGGL(ntk::rp_pack_kernel<NTK_DT_Q5_K>, g, b, 0, st, d, r, rows, nsb, p2);
     else hipLaunchKernelGGL(ntk::rp_pack_kernel<NTK_DT_Q6_K>, g, b, 0, st, d, r, rows, nsb, p2);
+    return ntk::last_launch_status();
+}
+
+int ntk_rp_unpack(void* raw, const void* rp, int rows, int in_features, int dtype, void* stream) {
+    if (!raw || !rp) return NTK_E_NULL;
+    if (!ntk::rp_supported(dtype)) return NTK_E_DTYPE;
+    if (rows <= 0 || in_features <= 0 || in_features % 256 != 0) return NTK_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(rp) & 15) || (reinterpret_cast<uintptr_t>(raw) & (dtype == NTK_DT_Q6_K ? 1 : 3))) return NTK_E_ALIGN;
+    const int tiles = (rows + 15) / 16, nsb = in_features / 256;
+    if ((long)tiles * nsb > 0x7FFFFFFFl) return NTK_E_SHAPE;
+    const size_t p2 = (size_t)tiles * nsb * 2 * ntk::rp_s1(dtype);
+    hipStream_t st = ntk::resolve_stream(stream);
+    const dim3 g((unsigned)(tiles * nsb)), b(256);
+    uint8_t* d = static_cast<uint8_t*>(raw);
+    const uint8_t* r = static_cast<const uint8_t*>(rp);
+    if (dtype == NTK_DT_Q4_K) hipLaunchKernelGGL(ntk::rp_unpack_kernel<NTK_DT_Q4_K>, g, b, 0, st, d, r, rows, nsb, p2);
+    else if (dtype == NTK_DT_Q5_K) hipLaunchKernelGGL(ntk::rp_unpack_kernel<NTK_DT_Q5_K>, g, b, 0, st, d, r, rows, nsb, p2);
+    else hipLaunchKernelGGL(ntk::rp_unpack_kernel<NTK_DT_Q6_K>, g, b, 0, st, d, r, rows, nsb, p2);
     return ntk::last_launch_status();
 }
 

@@ -73,6 +73,8 @@ def _bind():
     L.nt_engine_bytes_per_token.restype = C.c_uint64
     L.nt_engine_weight_bytes.argtypes = [vp]
     L.nt_engine_weight_bytes.restype = C.c_uint64
+    L.nt_engine_resident_weight_bytes.argtypes = [vp]
+    L.nt_engine_resident_weight_bytes.restype = C.c_uint64
     L.nt_engine_decode_path.argtypes = [vp]
     L.nt_engine_decode_path.restype = C.c_char_p
     L.nt_synth_write_gguf.argtypes = [C.c_char_p, C.POINTER(SynthSpec), i]
@@ -243,6 +245,9 @@ class Engine:
 
     def weight_bytes(self) -> int:
         return int(self.L.nt_engine_weight_bytes(self.h))
+
+    def resident_weight_bytes(self) -> int:
+        return int(self.L.nt_engine_resident_weight_bytes(self.h))
 
     def tokenize(self, text: str, add_bos: bool = True) -> List[int]:
         out = (C.c_int * 4096)()

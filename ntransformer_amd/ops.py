@@ -187,6 +187,14 @@ def rp_pack(raw, rows, in_features, dtype, stream=None) -> "DeviceBuffer":
     return dst
 
 
+def rp_unpack(rp, rows, in_features, dtype, nbytes, stream=None) -> "DeviceBuffer":
+    """ntk_rp_unpack: the raw GGUF blocks back from the engine's repacked form (nbytes = rows * row_bytes of the GGUF encoding)."""
+    dst = DeviceBuffer(nbytes + 256)
+    check(_lib.lib().ntk_rp_unpack(_p(dst), _p(rp), rows, in_features, int(dtype), stream), "rp_unpack")
+    synchronize(stream)
+    return dst
+
+
 def gemv_rp_fused(segs: Sequence[tuple], x, in_features, norm_w=None, eps=0.0, resid=None, silu_pair=False, stream=None):
     """ntk_gemv_rp_fused: gemv_fused over REPACKED tensors: segs = [(rp, y, rows, dtype), ...] (<= 3; one or two K-quant formats)."""
     arr = (GemvSeg * len(segs))()

@@ -245,6 +245,51 @@ def test_decode_beyond_3072_positions_runs_the_matrix_core_attention_and_matches
                    "max_abs_err_vs_oracle": observed})
 
 
+def test_decode_at_8k_and_33k_positions_matches_the_oracle(tmp_path):
+    """Contexts beyond 4096 through the ENGINE (reference -c / --ctx-size, main.cpp:74-75): the `small` shape (head_dim 128, GQA 4) with 2 layers and a
+    33 000-token context; the SAME seeded random cache rows are written into the engine (nt_engine_debug_kv_write) and into the oracle's cache
+    for positions [0, start), then both decode four teacher-forced tokens from `start` = 8190 and 32766 (the matrix-core split attention, 32 splits:
+    256 and 1024 rows per split and wave chunk walk) -- fused launches and hipGraph replay against the ORACLE (reference attention.cu:108-202 over tens of
+    thousands of cache rows), at the north-star tolerance.  (The oracle's O(n^2) prompt pass at these lengths would take minutes; a prompt pass does
+    not reach these positions any differently than 3900, which tests above cover end to end.)"""
+    import dataclasses
+    ctx = 33000
+    shape = dataclasses.replace(G.SMALL, name="small33k", layers=2, ctx=ctx)
+    path = str(tmp_path / "small33k_q8_0.gguf")
+    G.make_synthetic_llama(path, shape, "Q8_0", seed=20260927)
+    per = shape.kv_heads * (shape.hidden // shape.heads)
+    observed = {}
+    for start in (8190, 32766):
+        r = np.random.Generator(np.random.Philox(key=[20260927, start]))
+        rows_k = [(0.5 * r.standard_normal((start, per))).astype(np.float16).view(np.uint16) for _ in range(shape.layers)]
+        rows_v = [(0.5 * r.standard_normal((start, per))).astype(np.float16).view(np.uint16) for _ in range(shape.layers)]
+        cont = [int(t) for t in r.integers(0, 256, 4)]
+        m = O.OracleModel(path, ctx)
+        for i in range(shape.layers):
+            m.k_cache[i][: start * per] = rows_k[i].reshape(-1)
+            m.v_cache[i][: start * per] = rows_v[i].reshape(-1)
+        want, pos = [], start
+        for t in cont:
+            want.append(m.forward([t], pos))
+            pos += 1
+        want = np.stack(want)
+        for mode in ("fused", "graph"):
+            eng = E.Engine()
+            eng.load(path, ctx)
+            for i in range(shape.layers):
+                eng.kv_write(i, 0, rows_k[i], rows_v[i])
+            lg, pos = [], start
+            for t in cont:
+                lg.append(eng.decode_fused(t, pos, mode == "graph"))
+                pos += 1
+            eng.close()
+            err = np.abs(np.stack(lg) - want).max(axis=1)
+            observed["%d/%s" % (start, mode)] = float(err.max())
+            assert np.isfinite(np.stack(lg)).all() and err.max() <= TOL, (start, mode, [float(e) for e in err])
+    _log_observed({"test": "decode_at_8k_and_33k_positions_vs_oracle", "model": "small Q8_0, 2 layers, hd 128, GQA 4, context 33000",
+                   "max_abs_err_vs_oracle": observed})
+
+
 # ---------------------------------------------------------------------------------------------------
 # Parity at the BASELINE configs' real width, shallow depth (SURVEY 8(d) "Parity procedure"; reference
 # src/model/transformer.cpp:604-669).  Teacher-forced: the oracle runs free greedy decode, the HIP engine is fed the
@@ -389,6 +434,42 @@ def test_reference_transformer_runs_on_the_hip_library(name, shape, mix, tmp_pat
     assert got.shape == want.shape and np.isfinite(got).all()
     err = float(np.abs(got - want).max())
     _log_observed({"test": "reference_transformer_on_hip_library", "model": name, "max_abs_err": err, "tolerance": TOL})
+    assert err <= TOL, (name, err)
+
+
+@pytest.mark.parametrize("name,shape,mix", [c for c in CASES if c[2] in ("Q4_K_M", "Q6_K", "MIXED")])
+def test_reference_transformer_on_the_matrix_core_gemv(name, shape, mix, tmp_path):
+    """Round 5: the matrix-core K-quant GEMV reached THROUGH THE REFERENCE'S OWN BINDING.  The reference's unmodified nt::Transformer
+    (ref_logits_hip) with NT_HIP_AUTO_REPACK=1: integration/nt_cuda_launchers.cpp packs every K-quant matrix at its first launch_gemv
+    (ntk_rp_pack, owned by the binding -- what hip_register_resident_weight does from Attention::set_weights / FFN::init, attention.cpp:80-95,
+    ffn.cpp:7-29) and serves that pointer from ntk_gemv_rp afterwards; logits against the committed goldens (the same host code over the CPU
+    restatement), and the binding's own count of which kernel served the launches."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(O.__file__), "_ref", "ref_logits_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_logits_hip not built (needs /root/reference at build time)")
+    path, z = golden_model(name, shape, mix, tmp_path)
+    prompt = [int(t) for t in z["prompt"]]
+    fed_all = [int(t) for t in z["fed"][1:]]
+    out_path = str(tmp_path / "hip_rp_logits.bin")
+    cmd = [exe, path, str(int(z["ctx"])), out_path, str(len(prompt)), "0"] + [str(t) for t in prompt + fed_all]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, NT_HIP_AUTO_REPACK="1", NT_HIP_REPACK_STATS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    import re
+    m = re.search(r"nt_hip_repack: (\d+) tensors repacked, launch_gemv: (\d+) on ntk_gemv_rp \(matrix cores\), (\d+) on ntk_gemv", r.stderr)
+    assert m, r.stderr[-2000:]
+    n_packed, n_rp, n_raw = (int(g) for g in m.groups())
+    assert n_packed > 0 and n_rp > 0
+    if mix in ("Q4_K_M", "Q6_K"):
+        assert n_rp >= 7 * shape.layers * len(z["logits"]) // 2   # the projections: K-quant in these mixes (in_features % 256 == 0 at this shape)
+    raw = np.fromfile(out_path, dtype=np.uint8)
+    n_steps, V = np.frombuffer(raw[:8].tobytes(), "<i4")
+    got = raw[8:].reshape(n_steps, 8 + 4 * V)[:, 8:].copy().view("<f4").reshape(n_steps, V)
+    want = z["logits"]
+    assert got.shape == want.shape and np.isfinite(got).all()
+    err = float(np.abs(got - want).max())
+    _log_observed({"test": "reference_transformer_on_matrix_core_gemv", "model": name, "max_abs_err": err, "tolerance": TOL,
+                   "tensors_repacked": n_packed, "launches_rp": n_rp, "launches_raw": n_raw})
     assert err <= TOL, (name, err)
 
 

@@ -114,6 +114,22 @@ def test_repacked_weights_dequantise_to_the_gguf_weights_bit_for_bit(qname, out_
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("qname", sorted(KQ))
+@pytest.mark.parametrize("out_f,in_f", [(1, 256), (16, 512), (37, 1024), (130, 4096), (48, 14336)])
+def test_unpack_restores_the_gguf_bytes(qname, out_f, in_f):
+    """Round 5: one resident copy of a K-quant matrix -- the engine frees the uploaded GGUF bytes after the repack and unpacks a tensor into a
+    scratch in front of the launches that read raw blocks (prompt GEMM, 1:1 ntk_gemv).  ntk_rp_unpack(ntk_rp_pack(W)) must be W, byte for byte
+    (same integers, same 6-bit / int8 scales, same FP16 d / dmin; block layouts of reference src/core/types.h:112-137), ragged tiles included."""
+    gt = KQ[qname]
+    r = rng(out_f * 5 + in_f + gt)
+    W = G.synth_tensor(r, gt, out_f, in_f)
+    dt = G.GGML_TO_DT[gt]
+    rp = packed(W, out_f, in_f, gt)
+    raw = np.frombuffer(W, np.uint8)
+    back = ops.rp_unpack(rp, out_f, in_f, dt, raw.size).numpy(np.uint8)[:raw.size]
+    assert np.array_equal(back, raw), int((back != raw).sum())
+
+
 def test_repack_rejects_what_it_does_not_take():
     L = _lib.lib()
     assert ops.rp_bytes(G.GGML_TO_DT[G.GGML_Q8_0], 16, 256) == 0

@@ -727,6 +727,39 @@ def test_attention_decode_split_equals_oracle_and_single_pass(pos, nh, nkv, hd, 
     assert np.array_equal(caches[0][0], caches[1][0]) and np.array_equal(caches[0][1], caches[1][1])   # identical cache rows
 
 
+@pytest.mark.parametrize("pos,nsplit", [(8191, 32), (8191, 64), (32767, 32), (32767, 128), (131071, 32), (131071, 128)])
+@pytest.mark.parametrize("nh,nkv", [(8, 2), (16, 2)])
+def test_attention_decode_split_beyond_4096_positions(pos, nsplit, nh, nkv):
+    """Contexts beyond 4096 (the reference takes -c / --ctx-size up to the file's 131072: main.cpp:74-75, transformer.cpp:70-73): the split
+    attention at positions 8191 / 32767 / 131071 with the split count the engine uses there (Model::attention_splits: 32 at every context --
+    measured best, profiles/r05_attention_long_context.txt) and a larger one, head_dim 128, both GQA ratios of the target models (4 and 8; two KV heads = a sample of the heads: the workgroups of
+    a KV head share nothing with another's), against the ORACLE's rope + store + attention over the whole cache (reference attention.cu:108-202)."""
+    hd, max_seq = 128, pos + 1
+    r = rng(pos + nh + nsplit)
+    kc, vc = make_cache(r, pos, max_seq, nkv, hd)
+    q = r.standard_normal(nh * hd).astype(np.float32)
+    k = r.standard_normal(nkv * hd).astype(np.float32)
+    v = r.standard_normal(nkv * hd).astype(np.float32)
+    scale, theta = float(1 / np.sqrt(hd)), 500000.0
+    rq, rk = O.rope(q, k, [pos], nh, nkv, hd, theta)
+    kc_ref, vc_ref = kc.copy(), vc.copy()
+    O.copy_to_kv_cache(kc_ref, vc_ref, rk, v, 1, nkv, hd, pos, max_seq)
+    ref = O.attention_decode(rq, kc_ref, vc_ref, pos + 1, nh, nkv, hd, max_seq, scale)
+    kcd, vcd = DB.from_numpy(kc), DB.from_numpy(vc)
+    od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+    ops.attention_decode_split(od, DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v), kcd, vcd, DB.from_numpy(np.array([pos], np.int32)),
+                               nh, nkv, hd, max_seq, scale, theta, nsplit)
+    out = od.numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() <= 3e-5, np.abs(out - ref).max()
+    row = slice(pos * nkv * hd, (pos + 1) * nkv * hd)
+    got_k, got_v = kcd.numpy(np.uint16), vcd.numpy(np.uint16)
+    assert np.array_equal(got_v[row], vc_ref[row])                                                  # V: bit-exact (RNE to half)
+    dk = np.abs(got_k[row].view(np.float16).astype(np.float32) - kc_ref[row].view(np.float16).astype(np.float32))
+    assert dk.max() <= 2e-3                                                                          # K: a half ulp at |k| < 4 (device vs glibc sin / cos at pos 131071)
+    assert np.array_equal(got_k[: pos * nkv * hd], kc[: pos * nkv * hd]) and np.array_equal(got_v[: pos * nkv * hd], vc[: pos * nkv * hd])   # earlier rows untouched
+
+
 @pytest.mark.parametrize("pos", [5, 40, 607, 1500])
 @pytest.mark.parametrize("nh,nkv,nsplit", [(32, 8, 8), (32, 8, 16), (64, 8, 32)])
 def test_attention_decode_split_ignores_rows_past_the_position(pos, nh, nkv, nsplit):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--long", action="store_true")
     ap.add_argument("--cases", default=None, help="pos:nsplit,... instead of the built-in table")
     ap.add_argument("--models", default="8b,70b")
+    ap.add_argument("--max-seq", type=int, default=4096, help="context the caches are allocated for (round 5: 8192 ... 131072; use fewer --layers)")
     a = ap.parse_args()
     ops.init(0)
     L = _lib.lib()
@@ -36,15 +37,20 @@ def main():
     for name, nh, nkv, hd in (("8b", 32, 8, 128), ("70b", 64, 8, 128)):
         if name not in a.models.split(","):
             continue
-        max_seq, nl = 4096, a.layers
+        max_seq, nl = a.max_seq, a.layers
         per = nkv * hd
-        kc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
-        vc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
+        if max_seq <= 4096:
+            kc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
+            vc = [DB.from_numpy(rng.standard_normal(max_seq * per).astype(np.float16)) for _ in range(nl)]
+        else:   # long contexts: one host array, nl device copies (distinct addresses are what defeats the Infinity Cache, not distinct values)
+            hk = rng.standard_normal(max_seq * per, dtype=np.float32).astype(np.float16)
+            kc = [DB.from_numpy(hk) for _ in range(nl)]
+            vc = [DB.from_numpy(hk[::-1].copy()) for _ in range(nl)]
         q = DB.from_numpy(rng.standard_normal(nh * hd).astype(np.float32))
         k = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         v = DB.from_numpy(rng.standard_normal(per).astype(np.float32))
         out = DB.zeros(nh * hd * 4)
-        scratch = DB.zeros(int(L.ntk_attention_split_scratch_bytes(nh, hd, 64)))
+        scratch = DB.zeros(int(L.ntk_attention_split_scratch_bytes(nh, hd, 256)))
         cases = ((16, 1), (128, 1), (128, 2), (255, 1), (255, 2), (255, 4), (320, 1), (320, 2), (320, 4), (320, 8), (320, 16), (320, 32), (512, 1), (512, 2), (512, 4), (512, 8), (512, 32), (1024, 1), (1024, 4), (1024, 8), (1024, 16), (1024, 32), (2048, 8), (2048, 16), (2048, 32), (4095, 1), (4095, 4), (4095, 8), (4095, 16), (4095, 32), (4095, 64))
         if a.long:
             cases = tuple((p_, n_) for p_ in (600, 1023, 2047, 4095) for n_ in (1, 4, 8, 16, 32) if not (n_ == 1 and p_ > 1023))
@@ -52,7 +58,7 @@ def main():
             cases = tuple(tuple(int(t) for t in c.split(":")) for c in a.cases.split(","))
         for pos, nsplit in cases:
             dpos = DB.from_numpy(np.array([pos], np.int32))
-            n = 64
+            n = 64 if max_seq <= 4096 else 16
             def launch(i):
                 if nsplit == 1:
                     ops.attention_decode_fused(out, q, k, v, kc[i % nl], vc[i % nl], dpos, nh, nkv, hd, max_seq, 1.0 / np.sqrt(hd), 500000.0)

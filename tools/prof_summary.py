@@ -13,6 +13,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
     ap.add_argument("--gemv-bytes-per-token", type=float, default=7_973_699_584.0, help="bytes the GEMV launches of one token stream")
+    ap.add_argument("--json", default=None, help="merge {key: GEMV launches of this trace} into this file (profiles/trace_gemv.json, read back by bench.py as frac_trace)")
+    ap.add_argument("--key", default=None, help="workload key of --json: <model>_<mix>[_ctx<prompt tokens>], e.g. 8b_q8_0")
+    ap.add_argument("--file", default="", help="name of the committed summary this trace becomes (recorded beside the numbers)")
     a = ap.parse_args()
     db = sqlite3.connect(a.db)
     rows = db.execute("select name, start, end, grid_x, workgroup_x, vgpr_count, lds_size from kernels order by start").fetchall()
@@ -45,6 +48,14 @@ def main():
         print("\ngemv launches (gemv_quant_* + rp_gemv_kernel) pooled: %.1f launches/token, avg %.2f us, algorithmic %.1f MB/launch -> %.1f GB/s = %.1f%% of 8 TB/s"
               % (c / n_tokens, t / c, per_launch / 1e6, per_launch / (t / c * 1e-6) / 1e9, per_launch / (t / c * 1e-6) / 8e12 * 100))
         print("kernel time per token: %.1f us all kernels, %.1f us GEMV launches" % (busy / n_tokens, t / n_tokens))
+        if a.json and a.key:
+            import json
+            import os
+            d = json.load(open(a.json)) if os.path.exists(a.json) else {}
+            d[a.key] = {"avg_us": round(t / c, 3), "launches_per_token": round(c / n_tokens, 2), "bytes_per_launch": int(per_launch),
+                        "frac": round(per_launch / (t / c * 1e-6) / 8e12, 4), "kernel_us_per_token": round(busy / n_tokens, 1), "tokens": n_tokens,
+                        "file": a.file}
+            json.dump(d, open(a.json, "w"), indent=1, sort_keys=True)
     # per launch geometry of the GEMV (grid in workgroups, block, vgprs, lds): one line per distinct shape
     byshape = collections.defaultdict(lambda: [0, 0.0])
     for name, s, e, gx, wx, vg, lds in dec:
