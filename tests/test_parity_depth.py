@@ -111,7 +111,7 @@ def _teacher_stream(m, prompt, fed, perturb_seed=None, rel=6e-8):
 
 
 def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=None, flip_scale=1.0, abs_scale=1.0, kv_scale=1.0,
-                  layerwise_prompt=True, end_to_end=True, engine_cache=False):
+                  layerwise_prompt=True, end_to_end=True, engine_cache=False, e2e_kv_scale=None):
     """flip_scale: factor on the two bars that contain F16 rounding flips (layer vs oracle, end to end) and abs_scale: on the absolute
     logit bar of the forced arbiter, kv_scale: on the excess of a stored half over rounding -- 1 for the seeded models; a model built
     to amplify (outlier channels) states its factors.  The per-layer bar against the arbiter forced to the engine's roundings (5e-5 of
@@ -121,7 +121,7 @@ def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=N
     only (the float64 arbiter end to end costs several oracle passes over the whole stream).  engine_cache=True: a second layer-wise
     pass over the decode steps in which the cache rows of ALL earlier positions are the ENGINE's own (its batched prompt pass wrote the
     prompt's, its decode steps the rest) and the arbiter is forced to exactly those rows: the layer arithmetic over a long engine-written
-    cache, not over the oracle's."""
+    cache, not over the oracle's.  e2e_kv_scale: kv_scale of parts (b) / (c) only (part (a) keeps kv_scale)."""
     spec = E.synth_spec(preset, mix, layers=layers)
     path = os.path.join(_scratch_dir(), "_depth_%s.gguf" % tag)
     E.synth_write_gguf(path, spec)
@@ -302,7 +302,7 @@ def _depth_parity(tag, preset, mix, layers, n_prompt, n_decode, ctx=256, patch=N
                                                "max_kv_excess_rel": excess}
             rec["c_end_to_end_vs_oracle"][mode] = [float(x) for x in e_e2e]
             assert e_forced.max() <= FORCED_BAR * abs_scale, (tag, mode, "forced arbiter", e_forced)
-            assert excess <= KV_BAR * kv_scale, (tag, mode, "a stored half is further from the exact value than rounding + F32 error allow", excess)
+            assert excess <= KV_BAR * (e2e_kv_scale or kv_scale), (tag, mode, "a stored half is further from the exact value than rounding + F32 error allow", excess)
             assert e_free <= free_bar, (tag, mode, "free arbiter", e_free, free_bar)
             # (flip_scale > 1: an amplifying model -- its end-to-end distance is judged against what separates two valid evaluations of
             # the reference arithmetic there, the oracle and the free arbiter, not against the seeded models' 5e-3)
@@ -427,4 +427,13 @@ def test_depth_8b_q4_k_m_massive_activations():
 
     def patch(path):
         assert _scale_norm_channels(path, factors) >= 13
-    _depth_parity("8b_q4_k_m_massive_activations_6_layers", "8b", "Q4_K_M", 6, 20, 3, patch=patch, flip_scale=40.0)
+    # Measured (round 5, profiles/r05_parity_depth.jsonl): part (a), fused / graph = the matrix-core GEMV: 1.1e-5 of the layer RMS against the forced
+    # arbiter (bar 5e-5; the x 60 model above: 3.0e-5), cache rows 5.6e-6 (bar 2e-5) -- the per-layer bars hold UNLOOSENED.  Parts (b) / (c) carry
+    # absolute logit bars written for logits of RMS 2; this model's have RMS 66 (the x 4000 channel feeds the LM head), the ORACLE itself sits
+    # 5.0e-4 from the arbiter forced to its own roundings and 2.1e-2 from the free one.  abs_scale = 66: the forced-arbiter bar as 1e-4 OF THE LOGIT
+    # RMS (observed: 6.5e-6 of it in the reference's own launch sequence, 5.8e-5 through the fused path = six layers of 1.1e-5 each amplified by
+    # a model built to amplify; the x 60 model above sits at the same 6e-5 of its RMS); flip_scale 40; the end-to-end cache bar x 10: the rows
+    # of the PROMPT come from the two-piece FP16 GEMM (gemm_f16.hip: one power of two per TOKEN, so next to a x 4000 channel the other
+    # activations keep 22 - 12 bits): 1.4e-4 of the row RMS there, 2.9e-5 in the reference's own launch sequence -- the prompt GEMM, not the
+    # decode GEMV, is what massive activations stress most.
+    _depth_parity("8b_q4_k_m_massive_activations_6_layers", "8b", "Q4_K_M", 6, 20, 3, patch=patch, flip_scale=40.0, abs_scale=66.0, e2e_kv_scale=10.0)
