@@ -180,10 +180,16 @@ __device__ __forceinline__ uint32_t rp_raw_byte(const uint8_t* p1, const uint8_t
         return (uint32_t)((rp_q_lds<DT>(p1, i, 64 * chunk + l) & 15) | ((rp_q_lds<DT>(p1, i, 64 * chunk + 32 + l) & 15) << 4));
     }
 }
+// Word-wise: the repack pairs the columns (c, c + 64) of a 128-column step in one byte, Q6_K's ql pairs the same columns (a 16-byte chunk of a
+// lane IS 16 bytes of the row's ql), Q4_K / Q5_K pair (c, c + 32): two masks and a shift per output dword; the fifth / sixth bits come out of the
+// lanes' bit planes four bytes at a time.  The rows are assembled in LDS and written out in one coalesced pass (first form: a byte at a time
+// through rp_raw_byte, 1 TB/s -- a 1024-token prompt pass of a 70B Q6_K model lost 11 % to it; this one: profiles/r05_repack_one_resident_copy.txt).
 template <int DT>
 __global__ __launch_bounds__(256) void rp_unpack_kernel(uint8_t* __restrict__ raw, const uint8_t* __restrict__ rp, int rows, int nsb, size_t p2_off) {
     using F = Rp<DT>;
+    constexpr int PITCH = (F::BB + 15) & ~15;   // (16-byte row starts: the ql chunks go in as b128 stores)
     __shared__ __attribute__((aligned(16))) uint8_t img[2 * F::S1 + F::S2];
+    __shared__ __attribute__((aligned(16))) uint8_t outb[16 * PITCH];
     const int item = blockIdx.x, tile = item / nsb, sb = item - tile * nsb, t = threadIdx.x;
     const uint8_t* g1 = rp + (size_t)item * (2 * F::S1);
     const uint8_t* g2 = rp + p2_off + (size_t)item * F::S2;
@@ -192,16 +198,67 @@ __global__ __launch_bounds__(256) void rp_unpack_kernel(uint8_t* __restrict__ ra
     __syncthreads();
     const uint8_t* p1 = img;
     const uint8_t* p2 = img + 2 * F::S1;
-    constexpr int UB = DT == NTK_DT_Q6_K ? 2 : 4, U = F::BB / UB;   // Q6_K blocks are 210 bytes at 2-byte alignment: halfword units
-    for (int k = t; k < 16 * U; k += 256) {
-        const int i = k / U, u = k - i * U, row = 16 * tile + i;
-        if (row >= rows) continue;
-        uint32_t w = 0;
+    const int i = t & 15;
+    uint8_t* row = outb + i * PITCH;
+    auto ld32 = [&](const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); };
+    if constexpr (DT == NTK_DT_Q6_K) {   // ql[128] qh[64] scales[16] d   (types.h:132-137)
+        if (t < 128) {                   // ql[64 s + 16 kg ..]: the lane's 16-byte chunk of step s
+            const int kg = (t >> 4) & 3, s = t >> 6;
+            *reinterpret_cast<u4*>(row + 64 * s + 16 * kg) = *reinterpret_cast<const u4*>(p1 + (size_t)s * F::S1 + 16 * (16 * kg + i));
+        }
+        {                                // qh[32 s + 16 half + 4 w ..+3]: two bits of each of the four 32-column quarters
+            const int w = (t >> 4) & 3, half = (t >> 6) & 1, s = t >> 7;
+            const uint8_t* hp = p1 + (size_t)s * F::S1 + 1024;
+            uint32_t v = 0;
 #pragma unroll
-        for (int e = 0; e < UB; ++e) w |= rp_raw_byte<DT>(p1, p2, i, UB * u + e) << (8 * e);
-        uint8_t* dst = raw + ((size_t)row * nsb + sb) * F::BB + (size_t)UB * u;
-        if constexpr (UB == 2) *reinterpret_cast<uint16_t*>(dst) = (uint16_t)w;
-        else *reinterpret_cast<uint32_t*>(dst) = w;
+            for (int j = 0; j < 4; ++j) {   // quarter j: lanes kg = 2 (j & 1) + half, plane j >> 1 (columns c / c + 64)
+                const uint32_t src = ld32(hp + 8 * (16 * (2 * (j & 1) + half) + i) + 4 * (j >> 1));
+                v |= ((src >> (2 * w)) & 0x03030303u) << (2 * j);
+            }
+            *reinterpret_cast<uint32_t*>(row + 128 + 32 * s + 16 * half + 4 * w) = v;
+        }
+        if (t < 64) *reinterpret_cast<uint32_t*>(row + 192 + 4 * (t >> 4)) = ld32(p2 + 16 * i + 4 * (t >> 4));
+        if (t < 16) *reinterpret_cast<uint16_t*>(row + 208) = *reinterpret_cast<const uint16_t*>(p2 + 256 + 2 * i);
+    } else {                             // d dmin scales[12] (qh[32]) qs[128]   (types.h:112-128)
+        constexpr int QS0 = DT == NTK_DT_Q5_K ? 48 : 16;
+        {                                // qs[32 (2 s + h) + 4 g ..+3], h = 0 / 1: low / high nibbles of lanes kg = g >> 2 and 2 + (g >> 2)
+            const int g = (t >> 4) & 7, s = t >> 7;
+            const uint8_t* sp = p1 + (size_t)s * F::S1 + 4 * (g & 3);
+            const uint32_t A = ld32(sp + 16 * (16 * (g >> 2) + i)), B = ld32(sp + 16 * (16 * (2 + (g >> 2)) + i));
+            *reinterpret_cast<uint32_t*>(row + QS0 + 64 * s + 4 * g) = (A & 0x0F0F0F0Fu) | ((B & 0x0F0F0F0Fu) << 4);
+            *reinterpret_cast<uint32_t*>(row + QS0 + 64 * s + 32 + 4 * g) = ((A >> 4) & 0x0F0F0F0Fu) | (B & 0xF0F0F0F0u);
+        }
+        if constexpr (DT == NTK_DT_Q5_K) {
+            if (t < 128) {               // qh[4 g ..+3]: bit 2 (2 s + h) + hi of byte l' <- bit 8 y + 4 h + w of lane kg = 2 hi + (g >> 2), step s
+                const int g = t >> 4, w = g & 3;
+                uint32_t v = 0;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int hi = 0; hi < 2; ++hi) {
+                        const uint32_t H = ld32(p1 + (size_t)s * F::S1 + 1024 + 4 * (16 * (2 * hi + (g >> 2)) + i));
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) v |= ((H >> (4 * h + w)) & 0x01010101u) << (2 * (2 * s + h) + hi);
+                    }
+                *reinterpret_cast<uint32_t*>(row + 16 + 4 * g) = v;
+            }
+        }
+        if (t < 64) {                    // d, dmin and the 12 packed scale bytes (gemm.cu:206-222 unpacks them)
+            const int u = t >> 4;
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w |= rp_raw_byte<DT>(p1, p2, i, 4 * u + e) << (8 * e);
+            *reinterpret_cast<uint32_t*>(row + 4 * u) = w;
+        }
+    }
+    __syncthreads();
+    constexpr int UB = DT == NTK_DT_Q6_K ? 2 : 4, U = F::BB / UB;   // Q6_K blocks are 210 bytes at 2-byte alignment: halfword stores
+    for (int k = t; k < 16 * U; k += 256) {
+        const int r = k / U, u = k - r * U, grow = 16 * tile + r;
+        if (grow >= rows) continue;
+        uint8_t* dst = raw + ((size_t)grow * nsb + sb) * F::BB + (size_t)UB * u;
+        if constexpr (UB == 2) *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(outb + r * PITCH + 2 * u);
+        else *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(outb + r * PITCH + 4 * u);
     }
 }
 

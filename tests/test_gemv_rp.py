@@ -145,7 +145,8 @@ def test_repack_rejects_what_it_does_not_take():
 
 
 # ------------------------------------------------------------------------------- GEMV vs oracle
-SHAPES = [(3, 256), (64, 512), (257, 1024), (129, 2048), (512, 4096), (1024, 4096), (96, 8192), (515, 14336), (130, 28672), (4096, 4096)]
+# (the last: in_features = 32768, the stated limit of ntk_gemv_rp_fused -- 128 super-blocks per row, a 140 KB activation image)
+SHAPES = [(3, 256), (64, 512), (257, 1024), (129, 2048), (512, 4096), (1024, 4096), (96, 8192), (515, 14336), (130, 28672), (4096, 4096), (70, 32768)]
 
 
 @pytest.mark.parametrize("qname", sorted(KQ))
@@ -185,6 +186,35 @@ def test_gemv_rp_outlier_channels_and_scaled_inputs(qname):
         ops.synchronize()
         y = yd.numpy(np.float32)
         assert np.abs(y - ref).max() <= 4e-6 * np.sqrt(in_f) * float(np.abs(ref).max()), (scale, np.abs(y - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("qname", sorted(KQ))
+def test_gemv_rp_fused_at_the_in_features_limit(qname):
+    """in_features = 32768 (the limit include/ntk.h states for ntk_gemv_rp_fused; the raw path sees it through the reference KAT
+    tests/test_gemm.cpp:339-368): RMSNorm prologue + residual epilogue + plain rows, against the oracle; 32769+ is refused."""
+    gt = KQ[qname]
+    dt = G.GGML_TO_DT[gt]
+    out_f, in_f = 48, 32768
+    r = rng(32768 + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    x = r.standard_normal(in_f).astype(np.float32)
+    nw = (1.0 + 0.1 * r.standard_normal(in_f)).astype(np.float32)
+    res = r.standard_normal(out_f).astype(np.float32)
+    rp = packed(W, out_f, in_f, gt)
+    xn = O.rmsnorm(x, nw, 1e-5).reshape(-1)
+    ref = O.gemv(W, xn, out_f, in_f, dt)
+    yd = DB.from_numpy(np.full(out_f, np.nan, np.float32))
+    ops.gemv_rp_fused([(rp, yd, out_f, dt)], DB.from_numpy(x), in_f, norm_w=DB.from_numpy(nw), eps=1e-5)
+    y = yd.numpy(np.float32)
+    assert np.isfinite(y).all() and np.abs(y - ref).max() <= tol_for(ref, in_f), np.abs(y - ref).max()
+    ref2 = res + O.gemv(W, x, out_f, in_f, dt)
+    yd = DB.from_numpy(res.copy())
+    ops.gemv_rp_fused([(rp, yd, out_f, dt)], DB.from_numpy(x), in_f, resid=yd)
+    y = yd.numpy(np.float32)
+    assert np.isfinite(y).all() and np.abs(y - ref2).max() <= tol_for(ref2, in_f), np.abs(y - ref2).max()
+    arr = (ops.GemvSeg * 1)()
+    arr[0].W, arr[0].y, arr[0].rows, arr[0].dtype = rp.ptr, yd.ptr, out_f, int(dt)
+    assert _lib.lib().ntk_gemv_rp_fused(arr, 1, DB.zeros(4 * 33024).ptr, 33024, None, 0.0, None, 0, None) == -2   # NTK_E_SHAPE
 
 
 def test_gemv_rp_zero_and_tiny_inputs():
