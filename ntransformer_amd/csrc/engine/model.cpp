@@ -319,6 +319,7 @@ int Model::finish_load(int /*max_context*/) {
         } else if (st != NTK_OK) {
             return st;
         }
+        if (repack_ == 3) repack_ = keep_both_copies() ? 1 : 2;
         if (repack_ == 2) NT_TRY(drop_raw_all());
     }
     if (persistent_wanted_) set_persistent(persistent_wanted_);
@@ -424,9 +425,18 @@ const void* Model::raw_of(const DevTensor& t) {
     return d;
 }
 
+// level 3: both copies stay while that leaves at least a fifth of the device's memory free (everything else of the model -- caches, workspaces --
+// is allocated by now: finish_load() asks after alloc_buffers() and the repack)
+bool Model::keep_both_copies() const {
+    size_t fr = 0, tot = 0;
+    if (ntk_device_mem_info(&fr, &tot) != NTK_OK || tot == 0) return true;
+    return fr >= tot / 5;
+}
+
 int Model::set_repack(int level) {
-    level = level < 0 ? 0 : level > 2 ? 2 : level;
+    level = level < 0 ? 0 : level > 3 ? 3 : level;
     if (layers_.empty()) { repack_ = level; return NTK_OK; }   // before the load: finish_load() decides
+    if (level == 3) level = raw_freed_bytes_ > 0 ? 2 : (keep_both_copies() ? 1 : 2);   // after the load: what is gone stays gone; what is resident stays unless memory is short
     if (level == repack_) return NTK_OK;
     NT_TRY(sync());
     for (auto& row : graphs_) for (auto& gx : row) { if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx)); gx = nullptr; }

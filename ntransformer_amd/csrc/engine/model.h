@@ -102,10 +102,13 @@ public:
     int persistent_kind() const { return persistent_plan_ ? persistent_kind_ : 0; }
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
     // Decode GEMVs of the K-quant matrices from the load-time repack (ntk_gemv_rp_fused) instead of the raw GGUF blocks (ntk_gemv_fused).
-    // level 0: no repack (raw path).  1: repack AND the uploaded GGUF bytes stay resident (K-quant weights x 2 in HBM; rounds 4's form).
-    // 2 (default, round 5): ONE resident copy -- the GGUF bytes of every repacked matrix are freed after the repack; the launches that read raw
-    // blocks (prompt GEMM, the 1:1 ntk_gemv sequence, fallbacks) get the tensor unpacked into a scratch right in front of them
-    // (ntk_rp_unpack: byte-exact inverse; + 2 x the tensor's bytes of HBM traffic per prompt pass, ~4 % of a 1024-token chunk).
+    // level 0: no repack (raw path).  1: repack AND the uploaded GGUF bytes stay resident (K-quant weights x 2 in HBM; round 4's form).
+    // 2: ONE resident copy (round 5) -- the GGUF bytes of every repacked matrix are freed after the repack; the launches that read raw blocks
+    // (prompt GEMM, the 1:1 ntk_gemv sequence, fallbacks) get the tensor unpacked into a scratch right in front of them (ntk_rp_unpack:
+    // byte-exact inverse; + 2 x the model's bytes of HBM traffic per PROMPT PASS whatever its length: 8B Q4_K_M +4 ms = -30 % on a 64-token
+    // prompt, -6 % on 1024 tokens; 70B -7 %; decode unchanged).  3 (default): 2 when keeping both copies would leave less than a fifth of
+    // the device's memory free after the load, else 1 -- on a 288 GB MI355X every target model keeps both and prompts pay nothing; a model
+    // that needs the room gets it instead of failing to load.
     // The repack is made at load unless the option was switched off BEFORE the load; switching after the load works in every direction
     // (2 -> 0 / 1 re-materialises the GGUF bytes from the repack).  Returns a status (NTK_E_NOMEM: the model keeps running on what it has).
     int set_repack(int level);
@@ -155,6 +158,7 @@ private:
     int repack_one(DevTensor& t);
     int drop_raw_all();               // level 2: free the GGUF bytes of every repacked matrix, size the unpack scratch
     int restore_raw_all();            // ... and back: the GGUF bytes re-materialised from the repack
+    bool keep_both_copies() const;    // level 3's rule
     // the raw GGUF blocks of a projection for a launch that reads them: the resident bytes, or the tensor unpacked into the scratch (stream
     // ordered; raw_begin() starts a new group of tensors that must be valid together: Q | K | V, gate | up)
     void raw_begin() { raw_cursor_ = 0; }
@@ -215,7 +219,7 @@ private:
     size_t gemm_ws_bytes_ = 0;
     bool bf16_prefill_ = true;
     unsigned* attn_sync_ = nullptr;  // 3 words for ntk_attention_gemv_fused (attention producers inside the Wo launch)
-    int repack_ = 2;                 // 0 raw path, 1 repack + raw resident, 2 repack only (one resident copy)
+    int repack_ = 3;                 // 0 raw path, 1 repack + raw resident, 2 repack only (one resident copy), 3 = 2 if memory is short else 1
     bool repack_done_ = false;       // repack_all() ran on the loaded tensors
     uint64_t repack_bytes_ = 0;
     uint64_t raw_freed_bytes_ = 0;   // GGUF bytes released after the repack (level 2)

@@ -473,6 +473,77 @@ def test_reference_transformer_on_the_matrix_core_gemv(name, shape, mix, tmp_pat
     assert err <= TOL, (name, err)
 
 
+@pytest.mark.parametrize("name,shape,mix", [c for c in CASES if c[2] in ("Q4_K_M", "Q6_K", "MIXED")])
+def test_one_resident_copy_gives_the_same_bits_as_two(name, shape, mix, tmp_path):
+    """`repack` = 2 (the GGUF bytes of every repacked K-quant matrix freed after the load-time repack; prompt GEMM, the reference's 1:1 launch sequence
+    and the fallbacks read the tensor from a scratch that ntk_rp_unpack fills in front of them) against `repack` = 1 (both copies resident): the
+    unpack is the byte-exact inverse of the pack, so EVERY logit of a batched prompt, of the per-token reference sequence and of fused / graph decode
+    steps is bit-identical, and the weights occupy about half.  Switching 2 -> 1 -> 2 on a loaded model goes through the same bytes."""
+    path, z = golden_model(name, shape, mix, tmp_path)
+    prompt = [int(t) for t in z["prompt"]]
+    fed = [int(t) for t in z["fed"][1:]][:5]
+    outs, resident = {}, {}
+    for level in (1, 2):
+        for batched in (1, 0):
+            eng = E.Engine()
+            eng.set_option("repack", level)
+            eng.load(path, int(z["ctx"]))
+            eng.set_option("batched_prefill", batched)
+            lg = [eng.forward(prompt, 0)]
+            pos = len(prompt)
+            for i, t in enumerate(fed):
+                lg.append(eng.decode_fused(t, pos, i % 2 == 1) if batched else eng.forward([t], pos))
+                pos += 1
+            outs[(level, batched)] = np.stack(lg)
+            resident[level] = eng.resident_weight_bytes()
+            if level == 2 and batched:
+                eng.set_option("repack", 1)               # the GGUF bytes come back from the repack ...
+                again = eng.forward(prompt, 0)
+                eng.set_option("repack", 2)               # ... and go again
+                again2 = eng.forward(prompt, 0)
+                assert np.array_equal(again, lg[0]) and np.array_equal(again2, lg[0])
+            eng.close()
+    for batched in (1, 0):
+        assert np.isfinite(outs[(2, batched)]).all()
+        assert np.array_equal(outs[(1, batched)], outs[(2, batched)]), (name, batched, np.abs(outs[(1, batched)] - outs[(2, batched)]).max())
+    if mix != "MIXED":
+        assert resident[2] < 0.7 * resident[1], resident
+
+
+def test_decoding_again_after_a_pipelined_run_rebases_the_device_position(tmp_path):
+    """The greedy loops keep one step queued ahead of the token the host waits for (Engine::run, decode_greedy_steps: reference engine.cpp:100-136 is
+    the loop they replace) and stop the decode clock before a discarded run-ahead step drains -- so after a run the DEVICE position, token and pinned
+    ring may be ahead of what the host saw.  Every entry point that decodes afterwards must re-base them (Model::set_device_pos): a second run from an
+    EARLIER position, a teacher-forced step, and a generate on the same engine must give what a fresh engine gives."""
+    path, z = golden_model("small_q8_0", G.SMALL, "Q8_0", tmp_path)
+    prompt = [int(t) for t in z["prompt"]]
+    P = len(prompt)
+
+    def fresh():
+        e = E.Engine()
+        e.load(path, 256)
+        e.forward(prompt, 0)
+        return e
+    a = fresh()
+    first = a.decode_greedy_steps(7, P, 9)              # pipelined: the device has run ahead of the host inside this call
+    again = a.decode_greedy_steps(7, P, 5)              # back to position P on the SAME engine
+    lg_a = a.decode_fused(first[2], P + 3, True)        # a teacher-forced step in the middle of what the cache now holds
+    gen_a = a.generate_tokens(prompt, 6, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False)
+    a.close()
+    b = fresh()
+    assert b.decode_greedy_steps(7, P, 9) == first
+    b.close()
+    b = fresh()
+    assert b.decode_greedy_steps(7, P, 5) == again == first[:5]
+    lg_b = b.decode_fused(first[2], P + 3, True)
+    b.close()
+    assert np.array_equal(lg_a, lg_b)
+    b = E.Engine()
+    b.load(path, 256)
+    assert b.generate_tokens(prompt, 6, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False) == gen_a
+    b.close()
+
+
 def test_reference_cli_runs_on_the_hip_library():
     """The reference's unmodified src/main.cpp + Engine (engine.cpp:40-145) over the HIP library: greedy generation must
     complete and print the reference's own statistics block (engine.cpp:595-600)."""
