@@ -135,9 +135,9 @@ def cpu_baseline_reference_cli(args, spec):
         return {"value": round(n_dec / (ms_dec * 1e-3), 4), "unit": "tokens/s", "cores": threads, "kind": "port",
                 "runs_tok_s": [round(n / (ms * 1e-3), 4) for n, ms in runs], "loadavg_1m_before_after": [round(load0, 1), round(load1, 1)],
                 "pinned_cpus": cpus[:4] + (["..."] if len(cpus) > 4 else []),
-                "sample": "reference CLI (oracle/_ref/ntransformer_cpu: the reference's unmodified host code over the CPU restatement of its "
-                          "kernels) on the full %s %s GGUF (%.1f GB), -p <%d tokens> -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Decode: line "
-                          "(engine.cpp:595-600), best of two runs, threads pinned: %d tokens in %.0f ms; runs %.0f s + %.0f s writing the file"
+                "sample": "oracle/_ref/ntransformer_cpu (the reference's unmodified CLI / Engine / Transformer over the CPU restatement of its kernels) on the full "
+                          "%s %s GGUF (%.1f GB), -p <%d tokens> -n %d -t 0 --repeat-penalty 1.0 -c %d: its own Decode: line, best of two pinned runs: %d tokens in "
+                          "%.0f ms (%.0f s of runs + %.0f s writing the file)"
                           % (args.model, args.mix, os.path.getsize(path) / 1e9, len(cpu_prompt) + 1, args.cpu_tokens, args.ctx, n_dec, ms_dec, wall, t_write),
                 "host": _cpu_model(), "host_cpus": info}
     finally:
@@ -169,9 +169,8 @@ def _gemv_bytes_per_token(spec, mix):
 
 ACTIVATION_FORMS = {
     "f32": "F32 activations x integer weights, F32 accumulate (csrc/gemv.hip)",
-    "int24-block": "K-quant launches of the fused decode path: x as three int8 digit planes of rint(x 2^(22-e)), e per 256-column super-block "
-                   "(<= 2^-22 of the block's largest |x| per term), exact integer dot products on v_mfma_i32_16x16x64_i8 over the engine's "
-                   "load-time repack (csrc/gemv_rp.hip); scales, minima and summation in F32",
+    "int24-block": "K-quant decode launches: x as three int8 digit planes of rint(x 2^(22-e)), e per 256-column super-block, exact integer dot products on "
+                   "v_mfma_i32_16x16x64_i8 over the load-time repack (csrc/gemv_rp.hip; DESIGN 3.1)",
 }
 
 
@@ -350,7 +349,7 @@ def main():
             a_tok_s = nrep * steps / a["elapsed"]
             rb = roofline_block(args, model, mix, a)
             e = {"k": key, "value": round(a_tok_s, 2), "ms": round(1e3 * a["elapsed"] / steps, 4), "steps": steps,
-                 "frac": round(a["b_tok"] * a_tok_s / nrep / (HBM_PEAK_GBS * 1e9), 4), "gemv_frac": rb["frac"], "gemv_us": rb["avg_launch_us"],
+                 "frac": round(a["b_tok"] * a_tok_s / nrep / (HBM_PEAK_GBS * 1e9), 4), "gemv_us": rb["avg_launch_us"],
                  "roofline": {"frac_events": rb["frac_events"], "frac_trace": rb["frac_trace"], "us_trace": rb["avg_launch_us_trace"],
                               "traffic": rb["traffic"], "bytes_per_launch": rb["bytes_per_launch"]},
                  "pos": [a["pos"], a["pos_end"]], "form": activation_form(mix, not args.no_repack), "sclk_mhz": a["sclk_mhz"],
@@ -360,10 +359,9 @@ def main():
             if a.get("prompt") and "tokens_per_s" in a["prompt"]:
                 e["prompt_tok_s"] = a["prompt"]["tokens_per_s"]
             return e
-        line["config"]["also_legend"] = ("k = model_mix[_ctx<prompt tokens>], synthetic, resident, greedy; value tokens/s (whole job); ms per step; frac = "
-                                         "algorithmic bytes/token x tokens/s / 8 TB/s (per GPU); gemv_frac / gemv_us = GEMV launches, live HIP events; roofline = the GEMV launches: "
-                                         "frac_events (= gemv_frac), frac_trace / us_trace (committed rocprofv3 kernel trace of the workload, profiles/trace_gemv.json), "
-                                         "traffic (PMC bytes per launch, profiles/pmc_traffic.json); resident_GB = weights in HBM; prompt_tok_s = one 1024-token prompt pass")
+        line["config"]["also_legend"] = ("k = model_mix[_ctx<prompt tokens>]; value tokens/s; frac = algorithmic bytes/token x tokens/s / 8 TB/s; roofline = GEMV launches: "
+                                         "frac_events (live HIP events), frac_trace / us_trace (committed rocprofv3 trace, profiles/trace_gemv.json), traffic (PMC bytes per "
+                                         "launch, profiles/pmc_traffic.json); resident_GB = weights in HBM; prompt_tok_s = a 1024-token prompt pass")
         if headline and not args.no_also:
             also = []
             # (the last one: decode behind a 32768-token prompt -- 4.3 GB of KV cache per token, a third of the bytes: contexts beyond 4096)

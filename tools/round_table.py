@@ -35,7 +35,7 @@ def main():
             extra = "; driver-style %d steps: %.1f" % (drv["steps"], drv["value"]) if drv else ""
         else:
             a = also[k]
-            v0, ms0, st0, fr0, gf0 = a["value"], a["ms"], a["steps"], a["frac"], a["gemv_frac"]
+            v0, ms0, st0, fr0, gf0 = a["value"], a["ms"], a["steps"], a["frac"], a.get("gemv_frac", a.get("roofline", {}).get("frac_events"))
             extra = ""
         tr = ""
         busy = ""
