@@ -365,7 +365,7 @@ int Model::repack_all() {
 
 // ---- one resident copy (level 2): the uploaded GGUF bytes of every repacked matrix go; raw_of() unpacks on demand ----
 int Model::drop_raw_all() {
-    size_t need = 0, group = 0;
+    size_t need = 0;
     auto grp = [&](std::initializer_list<DevTensor*> ts) {
         size_t g = 0;
         for (DevTensor* t : ts) if (t->rp && !(output_tied_ && t->ptr == token_embd_.ptr)) g += (t->nbytes + 255) / 256 * 256 + 256;
@@ -373,7 +373,6 @@ int Model::drop_raw_all() {
     };
     for (auto& L : layers_) { grp({&L.wq, &L.wk, &L.wv}); grp({&L.wo}); grp({&L.w_gate, &L.w_up}); grp({&L.w_down}); }
     grp({&output_});
-    (void)group;
     if (need == 0) return NTK_OK;
     if (!raw_scratch_ || raw_scratch_bytes_ < need) {
         void* d = nt_hip_malloc(need);
