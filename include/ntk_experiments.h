@@ -79,7 +79,8 @@ void ntk_layer_engine_plan_destroy(void* plan);
 int  ntk_layer_engine_launch(void* plan, const int* d_pos, void* stream);          /* memset of the granules + the kernel; capturable */
 int  ntk_layer_engine_error(void* plan, unsigned* code_out);                        /* after a synchronise; code = 1 + op + 4096 what + 65536 cu */
 int  ntk_layer_engine_info(void* plan, int* geometry4);                             /* grid, ring slots, LDS bytes, operators */
-int  ntk_layer_engine_debug(void* plan, int enable, unsigned long long* out);       /* out [grid][nops][8] stamps of the 100 MHz clock */
+int  ntk_layer_engine_debug(void* plan, int enable, unsigned long long* out);       /* out [grid][nops][16] stamps of the 100 MHz clock / cycle sums */
+unsigned ntk_layer_engine_slow_sweeps(void* plan);                                  /* attention sweeps that ran 16 failed passes (reads and clears) */
 
 #ifdef __cplusplus
 }

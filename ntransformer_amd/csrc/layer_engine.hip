@@ -44,12 +44,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef volatile __attribute__((address_space(3))) unsigned le_ctl_t;   // control words: explicit LDS address space (a volatile GENERIC access
                                                                           // compiles to flat_load ... sc0 sc1, which also counts in vmcnt behind the DMA)
 
-constexpr int LE_T = 512;                 // 8 waves: the loader, 6 consumers (two groups of 3: a fill belongs to ONE group), one spare
+constexpr int LE_T = 512;                 // 8 waves: two loaders (even / odd fills), 6 consumers (two groups of 3: a fill belongs to ONE group)
 constexpr int LE_NC = 6;                  // consumer waves
 constexpr int LE_GW = 3;                  // waves per group = rows per fill (whole-row form) = slice owners (split form)
 constexpr int LE_SLOT = 16384;            // one ring slot = one fill = <= 16 DMA instructions
 constexpr int LE_CTL_BYTES = 8192;
 constexpr int LE_GPL = 32;                // granules per lane and gather pass (2048 per wave-pass = 16 KB in flight)
+#ifndef NTK_LE_GSTRIDE
+#define NTK_LE_GSTRIDE 1
+#endif
+constexpr int LE_GS = NTK_LE_GSTRIDE;     // granule stride in 8-byte units (experiment: 16 = every granule on its own 128-byte line)
 constexpr int LE_DBG = 16;                // debug words per (CU, operator)
 constexpr int LE_SLICE = 4096;            // columns per slice (64 lanes x 64 columns)
 constexpr int LE_SLICE_BYTES = LE_SLICE / 32 * 34;
@@ -57,7 +61,7 @@ constexpr unsigned LE_SPIN_LDS = 1u << 18, LE_SPIN_GRAN = 1u << 14;
 enum { LE_GEMV = 0, LE_ATTN = 1 };
 enum { LF_NORM = 1, LF_SILU = 2, LF_RESID = 4, LF_RESID_PLAIN = 8, LF_XPLAIN = 16, LF_SPLIT = 32 };
 // control words (LDS, behind the ring and the activation image)
-enum { C_FILLED = 0, C_ABORT = 1, C_ATT = 2, C_DONE = 8, C_XDONE = 16, C_XLOADED = 24, C_SSQ = 32, C_HID = 40, C_RCNT = 104, C_RPART = 112,
+enum { C_FILLED = 0 /* [2]: fills landed, per loader wave (even / odd global fill index) */, C_ABORT = 2, C_ATT = 3, C_DONE = 8, C_XDONE = 16, C_XLOADED = 24, C_SSQ = 32, C_HID = 40, C_RCNT = 104, C_RPART = 112,
        C_ATTM = 136, C_ATTL = 144, C_ATTACC = 152, C_ROPE = 920, C_WORDS = 1688 };   // ATTACC [6][128], ROPE [6][cos 64 | sin 64]
 static_assert(C_WORDS * 4 <= LE_CTL_BYTES, "control block");
 // what gave up (error word = 1 + op + 4096 * what + 65536 * cu)
@@ -111,22 +115,38 @@ __device__ __forceinline__ unsigned le_add(le_ctl_t* p) {                       
 }
 __device__ __forceinline__ le_u64 le_now() { return __builtin_amdgcn_s_memrealtime(); }               // 100 MHz
 
-__device__ __forceinline__ void le_fail(le_ctl_t* ctl, unsigned* err, int op, int what, int cu, int lane) {
+__device__ __forceinline__ void le_fail(le_ctl_t* ctl, unsigned* err, int op, int what, int cu, int lane, unsigned a = 0, unsigned b = 0) {
     if (lane == 0) {
         ctl[C_ABORT] = 1u;
-        __hip_atomic_store((le_gu32*)err, 1u + (unsigned)op + 4096u * (unsigned)what + 65536u * (unsigned)cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned code = 1u + (unsigned)op + 4096u * (unsigned)what + 65536u * (unsigned)cu;
+        unsigned expect = 0u;   // the FIRST wait that gave up stays in word 0 (later ones are its consequences) ...
+        __hip_atomic_compare_exchange_strong((le_gu32*)err, &expect, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ... and the first 15 are logged behind it: {code, wave, a, b} (what a / b mean depends on the wait: target and observed counters)
+        const unsigned nk = __hip_atomic_fetch_add((le_gu32*)err + 56 + (what & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at most 2 per kind of wait
+        if (nk < 2u) {
+            const unsigned n = __hip_atomic_fetch_add((le_gu32*)err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n < 13u) {
+                unsigned* r = err + 4 + 4 * n;
+                r[0] = code; r[1] = threadIdx.x >> 6; r[2] = a; r[3] = b;
+            }
+        }
     }
 }
 // spin until ctl[word] >= target (wave-uniform); false = gave up / aborted
+// (Every wait ends in a compiler barrier: what the waiter reads next -- ring rows, the activation image, the attention scratch -- are ORDINARY LDS
+//  loads, and nothing in the language orders those behind the volatile polls; without the barrier whether they are hoisted above the loop is the
+//  scheduler's choice, build by build.)
 __device__ __forceinline__ bool le_wait_ge(le_ctl_t* ctl, int word, unsigned target, unsigned* err, int op, int what, int cu, int lane) {
     unsigned spins = 0;
     while ((int)(le_ld(ctl + word) - target) < 0) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 63u) == 0u) {
             if (le_ld(ctl + C_ABORT)) return false;
-            if (spins > LE_SPIN_LDS) { le_fail(ctl, err, op, what, cu, lane); return false; }
+            if (spins > LE_SPIN_LDS) { le_fail(ctl, err, op, what, cu, lane, target, le_ld(ctl + word)); return false; }
         }
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     return true;
 }
 __device__ __forceinline__ unsigned le_minc(le_ctl_t* ctl, int word) {   // minimum over the consumer waves' words
@@ -141,9 +161,11 @@ __device__ __forceinline__ bool le_wait_minc(le_ctl_t* ctl, int word, unsigned t
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 63u) == 0u) {
             if (le_ld(ctl + C_ABORT)) return false;
-            if (spins > LE_SPIN_LDS) { le_fail(ctl, err, op, what, cu, lane); return false; }
+            if (spins > LE_SPIN_LDS) { le_fail(ctl, err, op, what, cu, lane, target, le_minc(ctl, word)); return false; }
         }
     }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     return true;
 }
 
@@ -195,17 +217,27 @@ __device__ __forceinline__ int le_swz(int i) {
 // ------------------------------------------------------------------------------------------------------------------
 // the loader wave
 // ------------------------------------------------------------------------------------------------------------------
+// TWO loader waves per CU (the workgroup's first and last wave): loader `which` issues the fills with global index g = which (mod 2) and publishes them in
+// its own word.  One wave issues a 1-KiB piece per ~75 cycles and every cycle it spends on anything else -- the slot poll, the counted wait, the publish --
+// came straight out of the stream (3.6-4.2 TB/s with one loader, profiles/r05_layer_engine_8b_q8_0.txt); two alternate, so one issues while the other waits.
+// Both walk the whole fill sequence (g, the slot index and the slots' owners are pure functions of it).
 __device__ __forceinline__ void le_loader(LCOp* ops, int nops, int ns, uint32_t ring_lds, le_ctl_t* ctl, int cu, int ncu, int lane,
-                                          unsigned* err, le_u64* dbg) {
-    unsigned g = 0;          // global fill index: fills 0 .. g-1 issued
+                                          unsigned* err, le_u64* dbg, int which) {
+    unsigned g = 0;          // global fill index
     int gslot = 0;           // g % ns
-    // DMA instructions of fills g-1 / g-2 / g-3 while those are not yet published as landed.  A fill is published when the fill THREE behind it
-    // has been issued: by then it has long landed and the counted wait does not stall (waiting for the fill before last cost 340 cycles
-    // of idle queue per fill); the 6-bit vmcnt holds 4 x 15 instructions.
-    int c1 = 0, c2 = 0, c3 = 0;
-    unsigned seen_done = 0;  // lower bound of min(done words) from the last poll: the six-word poll only when it does not suffice
-    auto publish = [&](unsigned n) { if (lane == 0) ctl[C_FILLED] = n; };
+    unsigned mine = 0;       // own fills issued
+    int c1 = 0;              // DMA instructions of the previous own fill while it is not yet published as landed
+    unsigned owners = 0;     // bit s: consumer group that owns the fill now in slot s (its three waves free the slot; the other group only passes it)
+    unsigned seen[2] = {0, 0};   // lower bounds of min(done words) per consumer group from the last poll
+    auto publish = [&](unsigned n) { if (lane == 0) ctl[C_FILLED + which] = n; };
+    auto group_min = [&](int grp) {
+        unsigned m = le_ld(ctl + C_DONE + LE_GW * grp);
+#pragma unroll
+        for (int i = 1; i < LE_GW; ++i) m = min(m, le_ld(ctl + C_DONE + LE_GW * grp + i));
+        return m;
+    };
     const unsigned lane16 = 16u * (unsigned)lane;
+    if (dbg && which) dbg = nullptr;   // (the stamps are loader 0's)
     for (int k = 0; k < nops; ++k) {
         LCOp& op = ops[k];
         if (op.kind != LE_GEMV) continue;
@@ -223,7 +255,7 @@ __device__ __forceinline__ void le_loader(LCOp* ops, int nops, int ns, uint32_t 
         const uint8_t* W1 = op.seg[1].W;
         const uint8_t* W2 = op.seg[2].W;
         const int n0 = op.seg[0].rows, n1 = op.seg[1].rows;
-        // row cursor of the plain form: (segment, row inside it) of the CU's first row, then advanced row by row
+        // row cursor of the plain form: (segment, row inside it) of the CU's first row, then advanced row by row (by BOTH loaders: each skips the other's fills)
         int seg = 0, rr = r0;
         if (!pair) {
             if (op.nseg > 1 && rr >= n0) { rr -= n0; seg = 1; if (op.nseg > 2 && rr >= n1) { rr -= n1; seg = 2; } }
@@ -233,55 +265,76 @@ __device__ __forceinline__ void le_loader(LCOp* ops, int nops, int ns, uint32_t 
         if (dbg && lane == 0) dbg[((size_t)cu * nops + k) * LE_DBG + 4] = le_now();
         le_u64 t_slot = 0, t_vm = 0, t_issue = 0;   // shader cycles (debug launches only: dbg != nullptr)
         for (int f = 0; f < nf; ++f) {
-            le_u64 ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
-            const int first = r0 + (pair ? (f >> 1) : f) * rpf;
+            const int unit = pair ? (f >> 1) : f;
+            const int first = r0 + unit * rpf;
             const int cnt = min(rpf, r1 - first);
-            if (g >= (unsigned)ns) {   // the slot's previous fill (g - ns) must have been passed by every consumer wave
-                const unsigned need = g - (unsigned)ns + 1u;
-                if ((int)(seen_done - need) < 0) {
-                    seen_done = le_minc(ctl, C_DONE);
-                    if ((int)(seen_done - need) < 0) {
-                        // nothing can be issued: publish everything in flight first (the consumers may be waiting for exactly that)
-                        if (c1 | c2 | c3) { le_wait_vm(0); publish(g); }
-                        c1 = c2 = c3 = 0;
-                        if (!le_wait_minc(ctl, C_DONE, need, err, k, LW_SLOT, cu, lane)) return;
-                        seen_done = need;
+            const bool my = (g & 1u) == (unsigned)which;
+            if (my) {
+                le_u64 ta = dbg ? __builtin_amdgcn_s_memtime() : 0;
+                if (g >= (unsigned)ns) {   // the slot's previous fill (g - ns) must have been consumed by the three waves of the group that owned it
+                    const unsigned need = g - (unsigned)ns + 1u;
+                    const int og = (int)((owners >> gslot) & 1u);
+                    if ((int)(seen[og] - need) < 0) {
+                        seen[og] = group_min(og);
+                        if ((int)(seen[og] - need) < 0) {
+                            // nothing can be issued: publish what is in flight first (the consumers may be waiting for exactly that)
+                            if (c1) { le_wait_vm(0); publish(mine); c1 = 0; }
+                            unsigned spins = 0;
+                            for (;;) {
+                                seen[og] = group_min(og);
+                                if ((int)(seen[og] - need) >= 0) break;
+                                __builtin_amdgcn_s_sleep(1);
+                                if ((++spins & 63u) == 0u) {
+                                    if (le_ld(ctl + C_ABORT)) return;
+                                    if (spins > LE_SPIN_LDS) { le_fail(ctl, err, k, LW_SLOT, cu, lane, need, (seen[og] << 4) | (unsigned)og | (g << 16)); return; }
+                                }
+                            }
+                        }
                     }
                 }
+                le_u64 tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
+                t_slot += tb - ta;
+                uint32_t dst = ring_lds + (uint32_t)gslot * (uint32_t)LE_SLOT;
+                const uint8_t* rowp = src;
+                int sl = seg_left, sg = seg;
+                for (int r = 0; r < cnt; ++r) {
+                    const uint8_t* row = pair ? ((f & 1) ? W1 : W0) + (size_t)(first + r) * row_bytes : rowp;
+                    unsigned voff = lane16;
+                    uint32_t d = dst;
+                    int i = 0;
+                    for (; i + 4 <= nfull; i += 4) { le_dma4((uint32_t)le_uni((int)d), row, voff); d += 4096u; }
+                    for (; i < nfull; ++i) { le_dma1((uint32_t)le_uni((int)d), row, voff); voff += 1024u; d += 1024u; }
+                    if (tail && (int)lane16 < tail) le_dma1((uint32_t)le_uni((int)d), row, voff);   // (lane 0 is always active: the piece is issued)
+                    dst += row_bytes;
+                    if (!pair) {
+                        rowp += row_bytes;
+                        if (--sl == 0) { ++sg; rowp = sg == 1 ? W1 : W2; sl = sg == 1 ? n1 : 0x7fffffff; }
+                    }
+                }
+                const int c0 = cnt * ipr;
+                le_u64 tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
+                t_issue += tc - tb;
+                if (c1) { le_wait_vm(c0); publish(mine); }   // the previous own fill has landed: own fills 0 .. mine-1 readable
+                if (dbg) t_vm += __builtin_amdgcn_s_memtime() - tc;
+                c1 = c0; ++mine;
             }
-            le_u64 tb = dbg ? __builtin_amdgcn_s_memtime() : 0;
-            t_slot += tb - ta;
-            uint32_t dst = ring_lds + (uint32_t)gslot * (uint32_t)LE_SLOT;
-            for (int r = 0; r < cnt; ++r) {
-                const uint8_t* row = pair ? ((f & 1) ? W1 : W0) + (size_t)(first + r) * row_bytes : src;
-                unsigned voff = lane16;
-                uint32_t d = dst;
-                int i = 0;
-                for (; i + 4 <= nfull; i += 4) { le_dma4((uint32_t)le_uni((int)d), row, voff); d += 4096u; }
-                for (; i < nfull; ++i) { le_dma1((uint32_t)le_uni((int)d), row, voff); voff += 1024u; d += 1024u; }
-                if (tail && (int)lane16 < tail) le_dma1((uint32_t)le_uni((int)d), row, voff);   // (lane 0 is always active: the piece is issued)
-                dst += row_bytes;
-                if (!pair) {   // next row of the operator
+            // both loaders: the sequence moves on
+            owners = (owners & ~(1u << gslot)) | ((unsigned)(unit & 1) << gslot);
+            if (!pair) {   // the plain form's row cursor
+                for (int r = 0; r < cnt; ++r) {
                     src += row_bytes;
                     if (--seg_left == 0) { ++seg; src = seg == 1 ? W1 : W2; seg_left = seg == 1 ? n1 : 0x7fffffff; }
                 }
             }
-            const int c0 = cnt * ipr;
-            le_u64 tc = dbg ? __builtin_amdgcn_s_memtime() : 0;
-            t_issue += tc - tb;
-            if (c3) { le_wait_vm(c2 + c1 + c0); publish(g - 2u); }   // fill g-3 has landed: fills 0 .. g-3 readable
-            if (dbg) t_vm += __builtin_amdgcn_s_memtime() - tc;
-            c3 = c2; c2 = c1; c1 = c0; ++g;
+            ++g;
             if (++gslot == ns) gslot = 0;
         }
         if (dbg && lane == 0) {
             le_u64* d = dbg + ((size_t)cu * nops + k) * LE_DBG;
-            d[5] = le_now(); d[8] = t_slot; d[9] = t_issue; d[10] = t_vm; d[11] = (le_u64)nf;
+            d[5] = le_now(); d[8] = t_slot; d[9] = t_issue; d[10] = t_vm; d[11] = (le_u64)((nf + 1 - which) / 2);
         }
     }
-    if (c3) { le_wait_vm(c2 + c1); publish(g - 2u); }
-    if (c2) { le_wait_vm(c1); publish(g - 1u); }
-    if (c1 | c2 | c3) { le_wait_vm(0); publish(g); }
+    if (c1) { le_wait_vm(0); publish(mine); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -307,15 +360,19 @@ __device__ __forceinline__ bool le_gather(LCOp& op, float* xs, le_ctl_t* ctl, in
             unsigned spins = 0;
             for (;;) {
 #pragma unroll
-                for (int j = 0; j < GPL; ++j) gr[j] = le_gran_ld(op.xg + min(base + 64 * j, n - 1));
+                for (int j = 0; j < GPL; ++j) gr[j] = le_gran_ld(op.xg + (size_t)LE_GS * min(base + 64 * j, n - 1));
                 bool ok = true;
 #pragma unroll
                 for (int j = 0; j < GPL; ++j) ok = ok && (unsigned)(gr[j] >> 32) == want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
                 if ((++spins & 15u) == 0u) {
+                    // (every 16 failed passes this CU's L1 is dropped: see le_attention -- a sweep that began before a wave of the SAME CU stored into
+                    //  the line can keep reading the line's previous contents; every all-gather includes the CU's own rows.  err[61] counts.)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (lane == 0) __hip_atomic_fetch_add((le_gu32*)err + 61, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (le_ld(ctl + C_ABORT)) return false;
-                    if (spins > LE_SPIN_GRAN) { le_fail(ctl, err, k, LW_GRAN, cu, lane); return false; }
+                    if (spins > LE_SPIN_GRAN) { le_fail(ctl, err, k, LW_GRAN, cu, lane, (unsigned)chunk, want); return false; }
                 }
             }
         }
@@ -388,9 +445,9 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
     // this lane's 8 dimensions of q, k, v and their RoPE partners, as granules of the Q|K|V operator
     le_u64 gq[8], gqp[8], gk[8], gkp[8], gv[8];
     {
-        const le_u64* qb = op.qg + (size_t)head * HD;
-        const le_u64* kb = op.kg + (size_t)kvh * HD;
-        const le_u64* vb = op.vg + (size_t)kvh * HD;
+        const le_u64* qb = op.qg + (size_t)head * HD * LE_GS;
+        const le_u64* kb = op.kg + (size_t)kvh * HD * LE_GS;
+        const le_u64* vb = op.vg + (size_t)kvh * HD * LE_GS;
         const unsigned want = op.xtag;
         unsigned spins = 0;
         for (;;) {
@@ -398,9 +455,9 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = 8 * pi + j, pd = d ^ HALF;
-                gq[j] = le_gran_ld(qb + d); gqp[j] = le_gran_ld(qb + pd);
-                gk[j] = le_gran_ld(kb + d); gkp[j] = le_gran_ld(kb + pd);
-                gv[j] = le_gran_ld(vb + d);
+                gq[j] = le_gran_ld(qb + LE_GS * d); gqp[j] = le_gran_ld(qb + LE_GS * pd);
+                gk[j] = le_gran_ld(kb + LE_GS * d); gkp[j] = le_gran_ld(kb + LE_GS * pd);
+                gv[j] = le_gran_ld(vb + LE_GS * d);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -409,8 +466,36 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 15u) == 0u) {
+                // Every 16 failed passes: drop this CU's L1 (buffer_inv sc1).  sc1 loads are documented to bypass it, yet the CU that runs head 0 -- the
+                // only one that sweeps lines it stores into itself -- has been seen to read the PREVIOUS contents of its own last q rows for 16 000
+                // passes when it started sweeping before they were stored (NEGATIVE_RESULTS 7).  err[60] counts how often this path runs.
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (lane == 0) __hip_atomic_fetch_add((le_gu32*)err + 60, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (le_ld(ctl + C_ABORT)) return false;
-                if (spins > LE_SPIN_GRAN) { le_fail(ctl, err, k, LW_ATTG, cu, lane); return false; }
+                if (spins > LE_SPIN_GRAN) {   // which granule: array (0 q, 1 q partner, 2 k, 3 k partner, 4 v), dimension, the tag it carries -- of the first lane that misses one
+                    unsigned bad = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int j = 7; j >= 0; --j) {
+                        const int d = 8 * pi + j, pd = d ^ HALF;
+                        if ((unsigned)(gv[j] >> 32) != want) bad = (4u << 28) | ((unsigned)d << 16) | ((unsigned)(gv[j] >> 32) & 0xFFFFu);
+                        if ((unsigned)(gkp[j] >> 32) != want) bad = (3u << 28) | ((unsigned)pd << 16) | ((unsigned)(gkp[j] >> 32) & 0xFFFFu);
+                        if ((unsigned)(gk[j] >> 32) != want) bad = (2u << 28) | ((unsigned)d << 16) | ((unsigned)(gk[j] >> 32) & 0xFFFFu);
+                        if ((unsigned)(gqp[j] >> 32) != want) bad = (1u << 28) | ((unsigned)pd << 16) | ((unsigned)(gqp[j] >> 32) & 0xFFFFu);
+                        if ((unsigned)(gq[j] >> 32) != want) bad = (0u << 28) | ((unsigned)d << 16) | ((unsigned)(gq[j] >> 32) & 0xFFFFu);
+                    }
+                    const unsigned long long m = __ballot(bad != 0xFFFFFFFFu);
+                    const unsigned first = m ? (unsigned)__builtin_amdgcn_readlane((int)bad, (int)__builtin_ctzll(m)) : 0xFFFFFFFFu;
+                    // (diagnostic) the same granule through a device-scope read-modify-write, which executes at the point of coherence: does MEMORY hold
+                    // the new tag while the sc1 loads keep returning the old one?
+                    unsigned rmw_tag = 0;
+                    if ((first >> 28) == 0u) {
+                        const unsigned dd = (first >> 16) & 0xFFFu;
+                        const le_u64 x = __hip_atomic_fetch_or((le_gu64*)(qb + LE_GS * dd), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rmw_tag = (unsigned)(x >> 32);
+                    }
+                    le_fail(ctl, err, k, LW_ATTG, cu, lane, (rmw_tag << 16) | (unsigned)head, first);
+                    return false;
+                }
             }
         }
     }
@@ -512,7 +597,7 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
             L = fmaf(w, ls[i], L);
             o = fmaf(w, accs[i * 128 + d], o);
         }
-        le_gran_st(op.og + (size_t)head * HD + d, op.tag, o / L);
+        le_gran_st(op.og + ((size_t)head * HD + d) * LE_GS, op.tag, o / L);
     }
     return true;
 }
@@ -526,7 +611,7 @@ __device__ __forceinline__ void le_locate(LCOp& op, int R, int& s, int& rr) {
     while (s + 1 < op.nseg && rr >= op.seg[s].rows) { rr -= op.seg[s].rows; ++s; }
 }
 __device__ __forceinline__ void le_store(LCOp& op, int s, int rr, float v) {
-    if (op.seg[s].yg) le_gran_st(op.seg[s].yg + rr, op.tag, v);
+    if (op.seg[s].yg) le_gran_st(op.seg[s].yg + (size_t)rr * LE_GS, op.tag, v);
     if (op.seg[s].yp) op.seg[s].yp[rr] = v;
 }
 
@@ -604,7 +689,7 @@ __device__ __forceinline__ bool le_gemv(LCOp* ops, int k, const uint8_t* ring, i
             const uint8_t* slot = ring + (size_t)gslot * LE_SLOT;
             if (!SPLIT) {
                 if (mem < cnt && alive) {
-                    alive = le_wait_ge(ctl, C_FILLED, g + 1u, err, k, LW_FILL, cu, lane);
+                    alive = le_wait_ge(ctl, C_FILLED + (int)(g & 1u), (g >> 1) + 1u, err, k, LW_FILL, cu, lane);
                     asm volatile("" ::: "memory");
                     if (dbg) tb = __builtin_amdgcn_s_memtime();
                     const float acc = Dot<NTK_DT_Q8_0, false>::run(slot + (size_t)mem * row_bytes, 0, lane, ncols[0], x2[0], zz4, zz2);
@@ -624,7 +709,7 @@ __device__ __forceinline__ bool le_gemv(LCOp* ops, int k, const uint8_t* ring, i
                     }
                 }
             } else {
-                if (alive) alive = le_wait_ge(ctl, C_FILLED, g + 1u, err, k, LW_FILL, cu, lane);
+                if (alive) alive = le_wait_ge(ctl, C_FILLED + (int)(g & 1u), (g >> 1) + 1u, err, k, LW_FILL, cu, lane);
                 asm volatile("" ::: "memory");
                 if (dbg) tb = __builtin_amdgcn_s_memtime();
                 float acc = 0.0f;
@@ -659,6 +744,12 @@ __device__ __forceinline__ bool le_gemv(LCOp* ops, int k, const uint8_t* ring, i
         if (lane == 0) ctl[C_DONE + c] = g + 1u;
         if (++gslot == ns) gslot = 0;
     }
+#ifndef NTK_LE_NO_STORE_DRAIN
+    // The wave's granule stores are acknowledged before it goes on: the next thing it may do is SWEEP granules -- on the CU that runs head 0 its own
+    // rows of q among them, stored microseconds earlier (see NEGATIVE_RESULTS 7: without this wait that CU's sweep kept reading the PREVIOUS contents
+    // of its own last rows for 16 000 passes, build-dependent; every other CU polls other CUs' stores only).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     stamp(3);
     if (dbg && c == 0 && lane == 0) { le_u64* d = dbg + ((size_t)cu * nops + k) * LE_DBG; d[12] = t_fill; d[13] = t_dot; }
     return alive;
@@ -683,11 +774,10 @@ __global__ __launch_bounds__(LE_T) void layer_engine_kernel(const LeOp* __restri
     le_ctl_t* ctl = (le_ctl_t*)(le_smem + (size_t)ns * LE_SLOT + xbytes);
     if (threadIdx.x < 160) ctl[threadIdx.x] = 0u;
     __syncthreads();   // the only barrier of the launch
-    if (wave == 0) {
-        le_loader(ops, nops, ns, (uint32_t)(uintptr_t)le_smem, ctl, cu, ncu, lane, err, dbg);
+    if (wave == 0 || wave == LE_NC + 1) {   // the two loader waves
+        le_loader(ops, nops, ns, (uint32_t)(uintptr_t)le_smem, ctl, cu, ncu, lane, err, dbg, wave == 0 ? 0 : 1);
         return;
     }
-    if (wave > LE_NC) return;   // (the eighth wave: spare)
     const int c = wave - 1;
     const int pos = *d_pos;
     unsigned g = 0, xseq = 0, attseq = 0;
@@ -790,7 +880,7 @@ int ntk_layer_engine_plan_create(const ntk_pop* ops, int nops, void** plan_out) 
     LayerEnginePlan* p = new LayerEnginePlan();
     p->nops = nops;
     p->grid = grid;
-    p->gran_bytes = total * sizeof(le_u64);
+    p->gran_bytes = total * sizeof(le_u64) * LE_GS;
     auto fail = [&](int code) {
         if (p->d_ops) (void)hipFree(p->d_ops);
         if (p->d_gran) (void)hipFree(p->d_gran);
@@ -802,7 +892,7 @@ int ntk_layer_engine_plan_create(const ntk_pop* ops, int nops, void** plan_out) 
     auto gran_of = [&](const void* ptr) -> le_u64* {
         const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
         for (const LeRegion& r : reg)
-            if (a >= r.lo && a < r.hi) return p->d_gran + r.base + (a - r.lo) / 4;
+            if (a >= r.lo && a < r.hi) return p->d_gran + (r.base + (a - r.lo) / 4) * LE_GS;
         return nullptr;
     };
     // ---- LDS: ring | activation image | control words ----
@@ -923,11 +1013,18 @@ int ntk_layer_engine_launch(void* plan, const int* d_pos, void* stream) {
 int ntk_layer_engine_error(void* plan, unsigned* code_out) {
     LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
     if (!p) return NTK_E_NULL;
-    unsigned e = 0;
-    if (hipMemcpy(&e, p->d_err, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
-    if (code_out) *code_out = e;
-    if (e) {
-        (void)hipMemset(p->d_err, 0, sizeof(unsigned));
+    unsigned e[64] = {0};
+    if (hipMemcpy(e, p->d_err, sizeof e, hipMemcpyDeviceToHost) != hipSuccess) return NTK_E_LAUNCH;
+    if (code_out) *code_out = e[0];
+    if (e[0]) {
+#ifdef NTK_TUNE
+        for (unsigned i = 0; i < e[1] && i < 13u; ++i) {   // (tuning / experiments builds: the log of the waits that gave up)
+            const unsigned c = e[4 + 4 * i] - 1u;
+            fprintf(stderr, "layer engine: wait gave up: operator %u kind %u CU %u wave %u a %u b %u (0x%x)\n", c & 4095u, (c >> 12) & 15u, c >> 16, e[5 + 4 * i],
+                    e[6 + 4 * i], e[7 + 4 * i], e[7 + 4 * i]);
+        }
+#endif
+        (void)hipMemset(p->d_err, 0, 60 * sizeof(unsigned));
         return NTK_E_LAUNCH;
     }
     return NTK_OK;
@@ -940,6 +1037,14 @@ int ntk_layer_engine_info(void* plan, int* geometry4) {
     if (!p || !geometry4) return NTK_E_NULL;
     geometry4[0] = p->grid; geometry4[1] = p->ns; geometry4[2] = p->lds; geometry4[3] = p->nops;
     return NTK_OK;
+}
+// (experiments) how many times an attention sweep ran 16 failed passes and dropped its CU's L1; reads and clears the counter
+unsigned ntk_layer_engine_slow_sweeps(void* plan) {
+    LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);
+    unsigned n[2] = {0, 0}, z[2] = {0, 0};   // [0] attention sweeps, [1] all-gather sweeps
+    if (!p || hipMemcpy(n, p->d_err + 60, 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    (void)hipMemcpy(p->d_err + 60, z, 8, hipMemcpyHostToDevice);
+    return n[0] + 65536u * n[1];
 }
 int ntk_layer_engine_debug(void* plan, int enable, unsigned long long* out) {
     LayerEnginePlan* p = static_cast<LayerEnginePlan*>(plan);

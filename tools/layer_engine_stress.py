@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Stress of the persistent layer engine (EXPERIMENTS=1 library, "persistent" = 2): N x 500 greedy tokens of the 8B Q8_0 model (the engine covers positions
+< 544), every token stream compared with the launch path's; any bounded wait that gives up prints its log (tuning builds) and fails the run.
+usage (GPU box): NTK_LIB_PATH=.../libntransformer_hip_exp.so python tools/layer_engine_stress.py [--rounds 6]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntransformer_amd import engine as E   # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rounds", type=int, default=6)
+ap.add_argument("--model", default="8b")
+a = ap.parse_args()
+spec = E.synth_spec(a.model, "Q8_0")
+eng = E.Engine()
+eng.load_synthetic(spec, 1024)
+prompt = [spec.bos] + list(range(100, 115))
+eng.set_option("persistent", 0)
+first = eng.generate_tokens(prompt, 1, temperature=0.0, repeat_penalty=1.0, stop_at_eos=False)[0]
+ref = eng.decode_greedy_steps(first, len(prompt), 500)
+eng.set_option("persistent", 2)
+assert "layer engine" in eng.decode_path(), eng.decode_path()
+bad = 0
+for r in range(a.rounds):
+    t0 = time.perf_counter()
+    try:
+        got = eng.decode_greedy_steps(first, len(prompt), 500)
+    except Exception as e:
+        print("round %d FAILED: %r" % (r, e), flush=True)
+        bad += 1
+        eng.set_option("persistent", 2)
+        continue
+    dt = time.perf_counter() - t0
+    same = got == ref
+    n_same = next((i for i, (x, y) in enumerate(zip(got, ref)) if x != y), len(ref))
+    print("round %d: %.1f tok/s, stream equal to the launch path's: %s (first %d tokens equal), path now: %s" % (r, 500 / dt, same, n_same, eng.decode_path()[:30]), flush=True)
+    bad += 0 if same else 1
+try:
+    import ctypes as C
+    from ntransformer_amd import _lib
+    L = _lib.lib()
+    L.nt_engine_persistent_plan.restype = C.c_void_p; L.nt_engine_persistent_plan.argtypes = [C.c_void_p]
+    L.ntk_layer_engine_slow_sweeps.argtypes = [C.c_void_p]; L.ntk_layer_engine_slow_sweeps.restype = C.c_uint
+    plan = L.nt_engine_persistent_plan(eng.h)
+    if plan:
+        n = L.ntk_layer_engine_slow_sweeps(plan)
+        print("sweeps that ran 16 failed passes and dropped their CU's L1: attention %d, all-gather %d" % (n & 0xFFFF, n >> 16), flush=True)
+except Exception as e:
+    print("counter unavailable:", repr(e))
+eng.close()
+print("stress", "ok" if bad == 0 else "FAILED (%d)" % bad)
+sys.exit(1 if bad else 0)
