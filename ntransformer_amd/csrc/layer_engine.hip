@@ -366,8 +366,8 @@ __device__ __forceinline__ bool le_gather(LCOp& op, float* xs, le_ctl_t* ctl, in
                 for (int j = 0; j < GPL; ++j) ok = ok && (unsigned)(gr[j] >> 32) == want;
                 if (__all(ok)) break;
                 __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 15u) == 0u) {
-                    // (every 16 failed passes this CU's L1 is dropped: see le_attention -- a sweep that began before a wave of the SAME CU stored into
+                if ((++spins & 31u) == 0u) {
+                    // (every 32 failed passes this CU's L1 is dropped: see le_attention -- a sweep that began before a wave of the SAME CU stored into
                     //  the line can keep reading the line's previous contents; every all-gather includes the CU's own rows.  err[61] counts.)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     if (lane == 0) __hip_atomic_fetch_add((le_gu32*)err + 61, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -441,6 +441,16 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
         const float angle = pos * freq * op.fscale;
         rope[i] = cosf(angle);
         rope[64 + i] = sinf(angle);
+    }
+    // the first cache rows of this lane's position group do not depend on the token: requested before the wait for q, k, v
+    const size_t stride = (size_t)n_kv * HD;
+    const uint16_t* kbase = op.kc + (size_t)kvh * HD + 8 * pi;
+    const uint16_t* vbase = op.vc + (size_t)kvh * HD + 8 * pi;
+    int p = g;
+    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
+    if (p < pos) {
+        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
+        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
     }
     // this lane's 8 dimensions of q, k, v and their RoPE partners, as granules of the Q|K|V operator
     le_u64 gq[8], gqp[8], gk[8], gkp[8], gv[8];
@@ -517,7 +527,6 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
         kx[j] = h2f(hk[j]);
         vx[j] = h2f(hv[j]);
     }
-    const size_t stride = (size_t)n_kv * HD;
     if (head % group == 0 && c == 0 && sub == 0 && pos < op.max_seq) {   // the token's cache row (read by later launches only)
         const size_t at = (size_t)pos * stride + (size_t)kvh * HD + 8 * pi;
         u32x4 pk, pv;
@@ -525,14 +534,6 @@ __device__ __forceinline__ bool le_attention(LCOp& op, le_ctl_t* ctl, int c, int
         pv.x = hv[0] | ((uint32_t)hv[1] << 16); pv.y = hv[2] | ((uint32_t)hv[3] << 16); pv.z = hv[4] | ((uint32_t)hv[5] << 16); pv.w = hv[6] | ((uint32_t)hv[7] << 16);
         *reinterpret_cast<u32x4*>(op.kc + at) = pk;
         *reinterpret_cast<u32x4*>(op.vc + at) = pv;
-    }
-    const uint16_t* kbase = op.kc + (size_t)kvh * HD + 8 * pi;
-    const uint16_t* vbase = op.vc + (size_t)kvh * HD + 8 * pi;
-    int p = g;
-    u32x4 kraw = {0, 0, 0, 0}, vraw = {0, 0, 0, 0};
-    if (p < pos) {
-        kraw = *reinterpret_cast<const u32x4*>(kbase + (size_t)p * stride);
-        vraw = *reinterpret_cast<const u32x4*>(vbase + (size_t)p * stride);
     }
     float m = -INFINITY, l = 0.0f, acc[8];
 #pragma unroll
@@ -674,6 +675,10 @@ __device__ __forceinline__ bool le_gemv(LCOp* ops, int k, const uint8_t* ring, i
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) ctl[C_XLOADED + c] = xseq;
+    // Every vector-memory LOAD of this wave has landed (norm weights, granules): said with the builtin, which the compiler's wait-count pass
+    // reads -- otherwise it puts an s_waitcnt vmcnt(0) in front of the first use of x inside the fill loop, and from the second row on
+    // that wait is for the acknowledgement of the previous row's granule STORE (in-order counter): a microsecond per row
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     stamp(2);
     const float zz4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, zz2[2] = {0.0f, 0.0f};
     float gate_carry = 0.0f;

@@ -47,7 +47,7 @@ try:
     plan = L.nt_engine_persistent_plan(eng.h)
     if plan:
         n = L.ntk_layer_engine_slow_sweeps(plan)
-        print("sweeps that ran 16 failed passes and dropped their CU's L1: attention %d, all-gather %d" % (n & 0xFFFF, n >> 16), flush=True)
+        print("sweeps that dropped their CU's L1 (every 16 failed passes of an attention entry, every 32 of an all-gather): attention %d, all-gather %d" % (n & 0xFFFF, n >> 16), flush=True)
 except Exception as e:
     print("counter unavailable:", repr(e))
 eng.close()
