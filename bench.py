@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--persistent", type=int, nargs="?", const=1, default=0,
                     help="EXPERIMENTS=1 library only: 1 = the round-2 persistent token kernel, 2 = the round-5 loader / consumer layer engine, instead of fused launches")
     ap.add_argument("--no-repack", action="store_true", help="K-quant decode GEMVs from the raw GGUF blocks (csrc/gemv.hip) instead of the engine's load-time repack (csrc/gemv_rp.hip)")
+    ap.add_argument("--attention-merge", action="store_true", help="split-KV decode attention as ONE launch (csrc/attention_merge.hip.h; A/B: identical results, measured slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=128, help="-n of the reference CLI run that is the CPU baseline (BASELINE config 1: 128)")
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (8B Q4_K_M, 70B Q4_K_M, 70B Q6_K, 8B Q8_0 behind 3900- and 32768-token prompts)")
@@ -187,6 +188,8 @@ def run_workload(args, model, mix, steps, warmup, timed, sync, prompt_len=None, 
     eng = E.Engine()
     eng.set_option("fused", not args.no_fuse)
     eng.set_option("graph", not args.no_graph)
+    if args.attention_merge:
+        eng.set_option("attention_merge", 1)
     if args.persistent:
         eng.set_option("persistent", args.persistent)
     if args.no_repack:

@@ -210,6 +210,15 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
                                void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,
                                int head_dim, int max_seq, float scale, float theta_base, float freq_scale, int nsplit,
                                float* scratch, void* stream);
+/* The same as ONE launch: the workgroup that finishes last among the nsplit (<= 64) of a head merges their states itself -- the same
+ * operations in the same order as the merge launch, identical bits.  The first ntk_attention_split_scratch_bytes' n_heads u32 of
+ * `scratch` are arrival counters: zero them ONCE after allocating (ntk_attention_split_scratch_init, stream ordered); every launch
+ * leaves them zero.  One scratch serves one stream at a time. */
+int ntk_attention_split_scratch_init(float* scratch, int n_heads, void* stream);
+int ntk_attention_decode_split_merged(float* output, const float* q, const float* k, const float* v, void* k_cache,
+                                      void* v_cache, const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads,
+                                      int head_dim, int max_seq, float scale, float theta_base, float freq_scale, int nsplit,
+                                      float* scratch, void* stream);
 
 /* Parity instrumentation: ntk_gemv_fused with the activation form of its Q4_K / Q6_K launches chosen by the CALL.  Those launches take,
  * from 48 MiB of weights on (a constant of the library: below it the conversion costs what the decode saves), the integer-activation

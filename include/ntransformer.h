@@ -68,7 +68,8 @@ int  nt_engine_load_synthetic(nt_engine_t e, const nt_synth_spec* spec, int max_
  * everywhere and take effect only in EXPERIMENTS=1 builds (include/ntk_experiments.h); "repack" = "0" raw-GGUF decode GEMVs | "1" load-time repack with the GGUF
  * bytes kept resident (K-quant weights twice in HBM) | "2" one resident copy: the GGUF bytes of a repacked matrix are freed and unpacked into a scratch
  * for the launches that read raw blocks (prompt GEMM, 1:1 sequence; a fixed cost per prompt pass) | "3" (default) "2" when both copies would leave less than
- * a fifth of the device's memory free, else "1" */
+ * a fifth of the device's memory free, else "1"; "attention_merge" = "1" split-KV decode attention as one launch | "0" (default) with the separate merge
+ * launch (identical results; the one-launch form measured slower) */
 int  nt_engine_set_option(nt_engine_t e, const char* key, const char* value);
 const char* nt_engine_last_error(nt_engine_t e);
 void nt_gen_params_default(nt_gen_params* p);

@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         "ntk_gemm_quant": (i, [vp, vp, vp, i, i, i, i, vp, vp]),
         "ntk_attention_decode_split": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, f, i, vp, vp]),
         "ntk_attention_split_scratch_bytes": (C.c_size_t, [i, i, i]),
+        "ntk_attention_split_scratch_init": (i, [vp, i, vp]),
+        "ntk_attention_decode_split_merged": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, f, i, vp, vp]),
         "ntk_attention_decode_fused": (i, [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, f, vp]),
         "ntk_embed_rows": (i, [vp, vp, vp, i, i, i, vp]),
         "ntk_argmax": (i, [vp, i, vp, vp, vp, vp]),

@@ -12,6 +12,7 @@
 // engine's decode path additionally fuses RoPE + KV store into the attention launch and takes the position
 // from device memory so the launch can be replayed from a hipGraph.
 #include "common.hip.h"
+#include "attention_merge.hip.h"
 #include <cfloat>
 #include <cstdlib>
 
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void attention_decode_fused_kernel(
 // state (acc[hd], m, l) in `output` = part[head][sp] for attention_split_combine_kernel; otherwise nsplit = 1 and `output` is the
 // head's normalised result.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int D, bool SPLIT>
+template <int LPR, int D, bool SPLIT, bool MERGE = false>   // MERGE: the partial state is written through (attention_merge.hip.h)
 __device__ __forceinline__ void attention_decode_walk(
     float* __restrict__ output, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
@@ -443,8 +444,8 @@ __device__ __forceinline__ void attention_decode_walk(
             o = fmaf(w, accs[i * hd + d], o);
         }
         if constexpr (SPLIT) {
-            output[d] = o;
-            if (d == 0) { output[hd] = M; output[hd + 1] = L; }
+            att_part_store<MERGE>(output + d, o);
+            if (d == 0) { att_part_store<MERGE>(output + hd, M); att_part_store<MERGE>(output + hd + 1, L); }
         } else {
             output[(size_t)head * hd + d] = o / L;
         }
@@ -484,16 +485,25 @@ __global__ __launch_bounds__(256) void attention_decode_fused_v3_kernel(
 // at position 4095 with the plain order).
 // part layout: [n_heads][nsplit][hd + 2] = acc[hd], m, l
 // ---------------------------------------------------------------------------------------------
-template <int LPR, int D>
+// MERGE: the head's last workgroup to finish merges the nsplit states into output[head] itself (attention_merge.hip.h) -- no combine launch
+template <int LPR, int D, bool MERGE>
 __global__ __launch_bounds__(256) void attention_decode_split_kernel(
     float* __restrict__ part, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
-    int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale) {
+    int n_heads, int n_kv_heads, int hd, int max_seq, float scale, float theta, float fscale, float* __restrict__ output,
+    unsigned* __restrict__ counters) {
     const int group = n_heads / n_kv_heads;
     const int kv_head = blockIdx.x % n_kv_heads, head = kv_head * group + blockIdx.x / n_kv_heads;
     const int sp = blockIdx.y, nsplit = gridDim.y;
-    attention_decode_walk<LPR, D, true>(part + ((size_t)head * nsplit + sp) * (hd + 2), q, k, v, kc, vc, d_pos, inv_freq, n_heads,
-                                        n_kv_heads, hd, max_seq, scale, theta, fscale, head, sp, nsplit);
+    attention_decode_walk<LPR, D, true, MERGE>(part + ((size_t)head * nsplit + sp) * (hd + 2), q, k, v, kc, vc, d_pos, inv_freq, n_heads,
+                                               n_kv_heads, hd, max_seq, scale, theta, fscale, head, sp, nsplit);
+    if constexpr (MERGE) {
+        extern __shared__ __attribute__((aligned(16))) float lds[];   // (the walk's LDS: nothing reads it any more)
+        if (!att_merge_arrive(counters + head, nsplit, (int)threadIdx.x, reinterpret_cast<volatile int*>(lds))) return;
+        const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+        if (64 * wave < hd)   // (uniform per wave) hd 64: wave 0; 128: waves 0, 1; 256: all four
+            att_merge_head_wave<1>(output + (size_t)head * hd, part + (size_t)head * nsplit * (hd + 2), hd, nsplit, lane, 64 * wave + lane);
+    }
 }
 
 __global__ __launch_bounds__(128) void attention_split_combine_kernel(float* __restrict__ output, const float* __restrict__ part,
@@ -727,7 +737,7 @@ static size_t attn_lds(int hd, int n_keys, int nvec) {
 
 int launch_attention_decode_kvhead_mfma(float* part, const float* q, const float* k, const float* v, uint16_t* kc, uint16_t* vc,
                                         const int* d_pos, const float* inv_freq, int nh, int nkv, int max_seq, float scale, float theta,
-                                        float fscale, int nsplit, hipStream_t st);   // attention_mfma.hip
+                                        float fscale, int nsplit, float* merged_output, unsigned* counters, hipStream_t st);   // attention_mfma.hip
 int launch_attention_prefill_mfma(float* out, const float* Q, const uint16_t* kc, const uint16_t* vc, int T, int start_pos, int nh, int nkv,
                                   int hd, float scale, hipStream_t st);   // attention_mfma.hip
 
@@ -856,15 +866,24 @@ int ntk_attention_decode_fused(float* output, const float* q, const float* k, co
 }
 
 size_t ntk_attention_split_scratch_bytes(int n_heads, int head_dim, int nsplit) {
-    return (size_t)n_heads * (size_t)nsplit * (size_t)(head_dim + 2) * sizeof(float);
+    return ntk::att_merge_header_bytes(n_heads) + (size_t)n_heads * (size_t)nsplit * (size_t)(head_dim + 2) * sizeof(float);
 }
 
-int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
-                               const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
-                               float scale, float theta_base, float freq_scale, int nsplit, float* scratch, void* stream) {
-    if (!output || !q || !k || !v || !k_cache || !v_cache || !d_pos || !scratch) return NTK_E_NULL;
+int ntk_attention_split_scratch_init(float* scratch, int n_heads, void* stream) {
+    if (!scratch) return NTK_E_NULL;
+    if (n_heads <= 0) return NTK_E_SHAPE;
+    return hipMemsetAsync(scratch, 0, ntk::att_merge_header_bytes(n_heads), ntk::resolve_stream(stream)) == hipSuccess ? NTK_OK : NTK_E_LAUNCH;
+}
+
+static int attention_decode_split_impl(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
+                                       const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                                       float scale, float theta_base, float freq_scale, int nsplit, float* scratch_all, void* stream, bool merged) {
+    if (!output || !q || !k || !v || !k_cache || !v_cache || !d_pos || !scratch_all) return NTK_E_NULL;
     if (n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads != 0 || max_seq <= 0 || nsplit < 1 || nsplit > 1024)
         return NTK_E_SHAPE;
+    if (merged && nsplit > ntk::ATT_MERGE_MAX_SPLITS) return NTK_E_SHAPE;
+    unsigned* counters = reinterpret_cast<unsigned*>(scratch_all);   // (zero outside the merged launches)
+    float* scratch = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(scratch_all) + ntk::att_merge_header_bytes(n_heads));
     if (head_dim != 128 && head_dim != 64 && head_dim != 256) return NTK_E_SHAPE;   // 16-byte row pieces: the engine falls back to the single pass otherwise
     if ((size_t)max_seq * n_kv_heads * head_dim * 2 >= 0xF0000000ull) return NTK_E_SHAPE;   // (32-bit row offsets inside one layer's cache)
     if ((reinterpret_cast<uintptr_t>(k_cache) & 15) || (reinterpret_cast<uintptr_t>(v_cache) & 15)) return NTK_E_ALIGN;
@@ -879,24 +898,44 @@ int ntk_attention_decode_split(float* output, const float* q, const float* k, co
     static const int kvhead_form = NTK_TUNE_ENV_INT("NTK_ATTN_KVHEAD", 1);   // (tuning builds: 0 = the per-query-head walk, 2 = the matrix-core form at any split count)
     if (head_dim == 128 && n_heads / n_kv_heads <= 16 && ((kvhead_form == 1 && nsplit >= 16) || kvhead_form == 2)) {
         const int rc = ntk::launch_attention_decode_kvhead_mfma(scratch, q, k, v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, max_seq,
-                                                                scale, theta_base, freq_scale, nsplit, st);
-        if (rc != NTK_OK) return rc;
+                                                                scale, theta_base, freq_scale, nsplit, merged ? output : nullptr, counters, st);
+        if (rc != NTK_OK || merged) return rc;
         hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit, n_kv_heads);
         return ntk::last_launch_status();
     }
     const int G = 4 * (64 / (head_dim / 8));
     const size_t lds = sizeof(float) * ((size_t)3 * head_dim + 2 * G + (size_t)G * head_dim);
 #define NTK_ATTSP(...) hipLaunchKernelGGL((ntk::attention_decode_split_kernel<__VA_ARGS__>), dim3(n_heads, nsplit), dim3(256), lds, st, scratch, q, k, \
-                                           v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale)
+                                           v, k16, v16, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base, freq_scale, output, counters)
     static const int split_d = NTK_TUNE_ENV_INT("NTK_ATTN_SPLIT_D", 4);   // (tuning builds: rows in flight per position group)
-    if (head_dim == 128 && split_d == 8) NTK_ATTSP(16, 8);
-    else if (head_dim == 128) NTK_ATTSP(16, 4);
-    else if (head_dim == 64) NTK_ATTSP(8, 4);
-    else NTK_ATTSP(32, 4);
+    if (merged) {
+        if (head_dim == 128) NTK_ATTSP(16, 4, true);
+        else if (head_dim == 64) NTK_ATTSP(8, 4, true);
+        else NTK_ATTSP(32, 4, true);
+        return ntk::last_launch_status();
+    }
+    if (head_dim == 128 && split_d == 8) NTK_ATTSP(16, 8, false);
+    else if (head_dim == 128) NTK_ATTSP(16, 4, false);
+    else if (head_dim == 64) NTK_ATTSP(8, 4, false);
+    else NTK_ATTSP(32, 4, false);
 #undef NTK_ATTSP
     if (ntk::last_launch_status() != NTK_OK) return NTK_E_LAUNCH;
     hipLaunchKernelGGL(ntk::attention_split_combine_kernel, dim3(n_heads), dim3(128), 0, st, output, scratch, head_dim, nsplit, n_kv_heads);
     return ntk::last_launch_status();
+}
+
+int ntk_attention_decode_split(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
+                               const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                               float scale, float theta_base, float freq_scale, int nsplit, float* scratch, void* stream) {
+    return attention_decode_split_impl(output, q, k, v, k_cache, v_cache, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base,
+                                       freq_scale, nsplit, scratch, stream, false);
+}
+
+int ntk_attention_decode_split_merged(float* output, const float* q, const float* k, const float* v, void* k_cache, void* v_cache,
+                                      const int* d_pos, const float* inv_freq, int n_heads, int n_kv_heads, int head_dim, int max_seq,
+                                      float scale, float theta_base, float freq_scale, int nsplit, float* scratch, void* stream) {
+    return attention_decode_split_impl(output, q, k, v, k_cache, v_cache, d_pos, inv_freq, n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base,
+                                       freq_scale, nsplit, scratch, stream, true);
 }
 
 }  // extern "C"

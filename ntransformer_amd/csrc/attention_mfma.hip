@@ -25,6 +25,7 @@
 //     diagonal tile is masked per element; workgroups with the longest prefixes are dispatched first.
 // Bound: MFMA (64 MFMAs = 1024 cycles per 16 queries x 64 keys and SIMD; the softmax adds ~200 VALU instructions per tile).
 #include "common.hip.h"
+#include "attention_merge.hip.h"
 
 namespace ntk {
 
@@ -258,10 +259,13 @@ constexpr int AD_CK = 32;                       // cache rows per chunk
 constexpr int AD_VP = 40;                       // halves per V^T row in LDS (80 B: the 8-byte operand reads of 32 lanes cover 64 banks)
 constexpr int AD_WAVE_LDS = AM_HD * AD_VP * 2;  // 10240 B per wave: V^T of its chunk; afterwards its partial output [head][128] floats
 
+// MERGE: the KV head's last workgroup to finish merges the nsplit states of its query heads into `output` itself (attention_merge.hip.h)
+template <bool MERGE>
 __global__ __launch_bounds__(256) void attention_decode_kvhead_mfma_kernel(
     float* __restrict__ part, const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const int* __restrict__ d_pos, const float* __restrict__ inv_freq,
-    const int n_heads, const int n_kv_heads, const int max_seq, const float scale, const float theta, const float fscale) {
+    const int n_heads, const int n_kv_heads, const int max_seq, const float scale, const float theta, const float fscale,
+    float* __restrict__ output, unsigned* __restrict__ counters) {
     // one LDS object: [queries 16 x 128 f32][new k row, new v row as halves][4 wave regions][m, l of 4 waves x 16 heads]
     __shared__ __attribute__((aligned(16))) uint8_t smem[16 * AM_HD * 4 + 2 * AM_HD * 2 + 4 * AD_WAVE_LDS + 2 * 64 * 4];
     float* qs = reinterpret_cast<float*>(smem);
@@ -510,23 +514,34 @@ __global__ __launch_bounds__(256) void attention_decode_kvhead_mfma_kernel(
             }
         }
         float* out = part + (((size_t)kv_head * group + n) * nsplit + sp) * (AM_HD + 2);
-        out[d] = acc;
-        if (d == 0) { out[AM_HD] = M; out[AM_HD + 1] = L; }
+        att_part_store<MERGE>(out + d, acc);
+        if (d == 0) { att_part_store<MERGE>(out + AM_HD, M); att_part_store<MERGE>(out + AM_HD + 1, L); }
     }
     if (writer) {   // the new cache row, at the very end (attention.hip: a store in front of the walk delays the first row)
         const size_t cache_row = (size_t)pos * n_kv_heads * AM_HD + (size_t)kv_head * AM_HD;
         if (tid < 64) { kc[cache_row + tid] = st_h[0]; kc[cache_row + tid + 64] = st_h[1]; }
         else if (tid >= 128) vc[cache_row + tid - 128] = st_h[0];
     }
+    if constexpr (MERGE) {
+        if (!att_merge_arrive(counters + kv_head, nsplit, tid, reinterpret_cast<volatile int*>(qs))) return;   // (qs: the queries, read long ago)
+        for (int n = wave; n < group; n += 4) {   // a wave per query head of the group, both halves of its 128 elements
+            const int head = kv_head * group + n;
+            att_merge_head_wave<2>(output + (size_t)head * AM_HD, part + (size_t)head * nsplit * (AM_HD + 2), AM_HD, nsplit, lane, lane);
+        }
+    }
 }
 
 // head_dim 128, <= 16 query heads per KV head, 16-byte aligned caches (caller-checked): partial states for attention_split_combine_kernel
 int launch_attention_decode_kvhead_mfma(float* part, const float* q, const float* k, const float* v, uint16_t* kc, uint16_t* vc,
                                         const int* d_pos, const float* inv_freq, int nh, int nkv, int max_seq, float scale, float theta,
-                                        float fscale, int nsplit, hipStream_t st) {
+                                        float fscale, int nsplit, float* merged_output, unsigned* counters, hipStream_t st) {
     if (nh % nkv != 0 || nh / nkv > 16 || nsplit < 1) return NTK_E_SHAPE;
-    hipLaunchKernelGGL(attention_decode_kvhead_mfma_kernel, dim3(nkv, nsplit), dim3(256), 0, st, part, q, k, v, kc, vc, d_pos, inv_freq,
-                       nh, nkv, max_seq, scale, theta, fscale);
+    if (merged_output)
+        hipLaunchKernelGGL(attention_decode_kvhead_mfma_kernel<true>, dim3(nkv, nsplit), dim3(256), 0, st, part, q, k, v, kc, vc, d_pos, inv_freq,
+                           nh, nkv, max_seq, scale, theta, fscale, merged_output, counters);
+    else
+        hipLaunchKernelGGL(attention_decode_kvhead_mfma_kernel<false>, dim3(nkv, nsplit), dim3(256), 0, st, part, q, k, v, kc, vc, d_pos, inv_freq,
+                           nh, nkv, max_seq, scale, theta, fscale, nullptr, nullptr);
     return last_launch_status();
 }
 

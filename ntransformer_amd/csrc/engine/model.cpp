@@ -432,6 +432,16 @@ bool Model::keep_both_copies() const {
     return fr >= tot / 5;
 }
 
+int Model::set_attention_merge(bool on) {
+    if (on == attn_merge_) return NTK_OK;
+    if (!layers_.empty()) {
+        NT_TRY(sync());
+        for (auto& row : graphs_) for (auto& gx : row) { if (gx) (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(gx)); gx = nullptr; }
+    }
+    attn_merge_ = on;
+    return NTK_OK;
+}
+
 int Model::set_repack(int level) {
     level = level < 0 ? 0 : level > 3 ? 3 : level;
     if (layers_.empty()) { repack_ = level; return NTK_OK; }   // before the load: finish_load() decides
@@ -478,7 +488,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_token_ = (int*)dev(64, true);
     argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
-    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, kMaxAttnSplits), false);
+    attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, kMaxAttnSplits), true);   // (zeroed: the arrival counters in front)
     h_token_ = (int*)nt_hip_malloc_host(64);
     h_ring_ = (unsigned long long*)nt_hip_malloc_host(64);
     if (h_ring_) memset(h_ring_, 0, 64);
@@ -948,9 +958,9 @@ int Model::enqueue_layers(int first, int last_layer) {
             NT_TRY(ntk_attention_decode_fused(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
                                               cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale, s));
         else
-            NT_TRY(ntk_attention_decode_split(attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd,
-                                              cfg_.max_seq_len, scale, cfg_.rope_theta, cfg_.rope_freq_scale,
-                                              attention_splits(attn_regime_, hd), attn_scratch_, s));
+            NT_TRY((attn_merge_ ? ntk_attention_decode_split_merged : ntk_attention_decode_split)(
+                attn_out, q_buf, k_buf, v_buf, kc, vc, d_pos_, rope_inv_freq_, nh, nkv, hd, cfg_.max_seq_len, scale, cfg_.rope_theta,
+                cfg_.rope_freq_scale, attention_splits(attn_regime_, hd), attn_scratch_, s));
         mark(1, false);
         if (tp_world_ > 1) {   // partial sum over this rank's heads -> exchange slot -> hidden += sum over ranks
             NT_TRY(project1(L.wo, tp_slot(), attn_out, nullptr, nullptr, 2));

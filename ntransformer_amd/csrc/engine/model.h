@@ -101,6 +101,10 @@ public:
     void set_persistent(int level);   // 0 off, 1 decode_persistent.hip, 2 layer_engine.hip (round 5); EXPERIMENTS=1 builds only, otherwise stays off
     int persistent_kind() const { return persistent_plan_ ? persistent_kind_ : 0; }
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
+    // Split-KV decode attention as ONE launch (the last workgroup of a head merges the partial states: attention_merge.hip.h) or -- the default --
+    // with the separate combine launch of rounds 3-5; same bits either way, the one-launch form measured 0.1-0.6 us (walk) / 1.5-4 us (matrix-core
+    // form) per layer slower (profiles/NEGATIVE_RESULTS.md 8).  Captured graphs are dropped when the setting changes.
+    int set_attention_merge(bool on);
     // Decode GEMVs of the K-quant matrices from the load-time repack (ntk_gemv_rp_fused) instead of the raw GGUF blocks (ntk_gemv_fused).
     // level 0: no repack (raw path).  1: repack AND the uploaded GGUF bytes stay resident (K-quant weights x 2 in HBM; round 4's form).
     // 2: ONE resident copy (round 5) -- the GGUF bytes of every repacked matrix are freed after the repack; the launches that read raw blocks
@@ -226,6 +230,7 @@ private:
     void* raw_scratch_ = nullptr;    // where raw_of() unpacks to
     size_t raw_scratch_bytes_ = 0, raw_cursor_ = 0;
     int raw_err_ = 0;                // first failure inside raw_of() (it returns a pointer): surfaced by the caller's next status check
+    bool attn_merge_ = false;        // split-KV attention without the combine launch (round 5; identical bits, measured 0-2 us per layer SLOWER: opt-in)
     bool fuse_attention_ = false;    // attention + Wo projection as one launch: measured SLOWER than two launches (profiles/r02_*): opt-in
     int tp_rank_ = 0, tp_world_ = 1;
     void* tp_comm_ = nullptr;        // this rank's communication buffer (flags + two slots of max_seq x H floats)

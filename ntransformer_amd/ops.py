@@ -268,6 +268,20 @@ def attention_decode_split(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_
     return None
 
 
+def attention_decode_split_merged(output, q, k, v, k_cache, v_cache, d_pos, n_heads, n_kv_heads, head_dim, max_seq, scale,
+                                  theta_base, nsplit, freq_scale=1.0, inv_freq=None, stream=None, launches=1):
+    """The same as ONE launch (ntk_attention_decode_split_merged): the last workgroup of a head merges; `launches` > 1 repeats the launch on
+    the same scratch (the arrival counters must come back to zero each time)."""
+    scratch = DeviceBuffer(int(_lib.lib().ntk_attention_split_scratch_bytes(n_heads, head_dim, nsplit)))
+    check(_lib.lib().ntk_attention_split_scratch_init(_p(scratch), n_heads, stream), "attention_split_scratch_init")
+    for _ in range(launches):
+        check(_lib.lib().ntk_attention_decode_split_merged(_p(output), _p(q), _p(k), _p(v), _p(k_cache), _p(v_cache), _p(d_pos),
+                                                           _p(inv_freq), n_heads, n_kv_heads, head_dim, max_seq, scale, theta_base,
+                                                           freq_scale, nsplit, _p(scratch), stream), "attention_decode_split_merged")
+    synchronize()
+    return None
+
+
 def embed_rows(out, table, tokens, n_tokens, hidden, dtype, stream=None, allow_unsupported=False):
     st = _lib.lib().ntk_embed_rows(_p(out), _p(table), _p(tokens), n_tokens, hidden, int(dtype), stream)
     if not (allow_unsupported and st == -1):

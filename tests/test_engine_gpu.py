@@ -290,6 +290,44 @@ def test_decode_at_8k_and_33k_positions_matches_the_oracle(tmp_path):
                    "max_abs_err_vs_oracle": observed})
 
 
+def test_split_attention_without_the_combine_launch_gives_the_same_bits(tmp_path):
+    """The engine's split-KV decode attention as one launch ("attention_merge" = 1: the last workgroup of a head merges the partial states; opt-in,
+    it measured slower) against the two-launch form of rounds 3-5 ("attention_merge" = 0, the default) on the same seeded cache rows: both attention regimes (walk with 8
+    splits at position 700, matrix cores with 32 splits at 3500), eager and hipGraph replay (the arrival counters return to zero inside every
+    replay), 24 teacher-forced tokens each -- the logits must be equal BIT FOR BIT.  The two-launch form is the one pinned to the oracle above."""
+    import dataclasses
+    ctx = 4096
+    shape = dataclasses.replace(G.SMALL, name="small4k", layers=2, ctx=ctx)
+    path = str(tmp_path / "small4k_q8_0.gguf")
+    G.make_synthetic_llama(path, shape, "Q8_0", seed=20260928)
+    per = shape.kv_heads * (shape.hidden // shape.heads)
+    for start in (700, 3500):
+        r = np.random.Generator(np.random.Philox(key=[20260928, start]))
+        rows_k = [(0.5 * r.standard_normal((start, per))).astype(np.float16).view(np.uint16) for _ in range(shape.layers)]
+        rows_v = [(0.5 * r.standard_normal((start, per))).astype(np.float16).view(np.uint16) for _ in range(shape.layers)]
+        cont = [int(t) for t in r.integers(0, 256, 24)]
+        outs = {}
+        for merge in (0, 1):
+            for graph in (False, True):
+                eng = E.Engine()
+                eng.load(path, ctx)
+                eng.set_option("attention_merge", merge)
+                for i in range(shape.layers):
+                    eng.kv_write(i, 0, rows_k[i], rows_v[i])
+                lg, pos = [], start
+                for t in cont:
+                    lg.append(eng.decode_fused(t, pos, graph))
+                    pos += 1
+                toks = eng.decode_greedy_steps(cont[-1], pos, 16)
+                eng.close()
+                outs[(merge, graph)] = (np.stack(lg), toks)
+        base = outs[(0, False)]
+        assert np.isfinite(base[0]).all()
+        for key, (lg, toks) in outs.items():
+            assert np.array_equal(lg, base[0]), (start, key, float(np.abs(lg - base[0]).max()))
+            assert toks == base[1], (start, key)
+
+
 # ---------------------------------------------------------------------------------------------------
 # Parity at the BASELINE configs' real width, shallow depth (SURVEY 8(d) "Parity procedure"; reference
 # src/model/transformer.cpp:604-669).  Teacher-forced: the oracle runs free greedy decode, the HIP engine is fed the

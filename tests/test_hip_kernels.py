@@ -760,6 +760,45 @@ def test_attention_decode_split_beyond_4096_positions(pos, nsplit, nh, nkv):
     assert np.array_equal(got_k[: pos * nkv * hd], kc[: pos * nkv * hd]) and np.array_equal(got_v[: pos * nkv * hd], vc[: pos * nkv * hd])   # earlier rows untouched
 
 
+@pytest.mark.parametrize("pos,nh,nkv,hd,nsplit", [
+    (0, 32, 8, 128, 8), (3, 32, 8, 128, 8), (607, 32, 8, 128, 8), (1500, 32, 8, 128, 8), (1500, 32, 8, 128, 13), (2047, 32, 8, 64, 8), (900, 8, 8, 256, 8),
+    (700, 12, 4, 64, 5), (3071, 32, 8, 128, 16), (4095, 32, 8, 128, 32), (4095, 64, 8, 128, 32), (2500, 40, 8, 128, 64), (1023, 16, 16, 128, 33),
+    (5, 32, 8, 128, 32), (8191, 8, 2, 128, 32), (33000, 8, 2, 128, 32)])
+def test_attention_decode_split_merged_equals_the_two_launch_form(pos, nh, nkv, hd, nsplit):
+    """ntk_attention_decode_split_merged (one launch: the last workgroup of a head -- walk form -- or of a KV head -- matrix-core form -- merges the
+    partial states, csrc/attention_merge.hip.h) against ntk_attention_decode_split (a second launch merges): the same operations in the same order, so
+    the outputs are equal BIT FOR BIT, and so are the cache rows; three launches on one scratch (the arrival counters must return to zero).  The
+    two-launch form is the one the tests above pin to the oracle at the same shapes."""
+    r = rng(pos * 5 + nh + nsplit)
+    max_seq = max(2048, pos + 1)
+    kc, vc = make_cache(r, pos, max_seq, nkv, hd)
+    q = r.standard_normal(nh * hd).astype(np.float32)
+    k = r.standard_normal(nkv * hd).astype(np.float32)
+    v = r.standard_normal(nkv * hd).astype(np.float32)
+    scale, theta = float(1 / np.sqrt(hd)), 500000.0
+    outs = []
+    for merged in (False, True):
+        kcd, vcd = DB.from_numpy(kc), DB.from_numpy(vc)
+        od = DB.from_numpy(np.full(nh * hd, np.nan, np.float32))
+        args = (od, DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v), kcd, vcd, DB.from_numpy(np.array([pos], np.int32)),
+                nh, nkv, hd, max_seq, scale, theta, nsplit)
+        if merged: ops.attention_decode_split_merged(*args, launches=3)
+        else: ops.attention_decode_split(*args)
+        outs.append((od.numpy(), kcd.numpy(np.uint16), vcd.numpy(np.uint16)))
+    assert np.isfinite(outs[0][0]).all()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_attention_decode_split_merged_refuses_more_than_64_splits():
+    """One lane per split in the merging wave: 65 splits and more stay with the two-launch form (NTK_E_SHAPE, nothing launched)."""
+    nh, nkv, hd, max_seq = 8, 2, 128, 2048
+    z = lambda n: DB.zeros(n)
+    with pytest.raises(Exception):
+        ops.attention_decode_split_merged(z(nh * hd * 4), z(nh * hd * 4), z(nkv * hd * 4), z(nkv * hd * 4), z(max_seq * nkv * hd * 2), z(max_seq * nkv * hd * 2),
+                                          DB.from_numpy(np.array([100], np.int32)), nh, nkv, hd, max_seq, 0.1, 500000.0, 65)
+
+
 @pytest.mark.parametrize("pos", [5, 40, 607, 1500])
 @pytest.mark.parametrize("nh,nkv,nsplit", [(32, 8, 8), (32, 8, 16), (64, 8, 32)])
 def test_attention_decode_split_ignores_rows_past_the_position(pos, nh, nkv, nsplit):

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--long", action="store_true")
     ap.add_argument("--cases", default=None, help="pos:nsplit,... instead of the built-in table")
     ap.add_argument("--models", default="8b,70b")
+    ap.add_argument("--merged", action="store_true", help="time every split case in both forms: with the combine launch and as one launch (ntk_attention_decode_split_merged)")
     ap.add_argument("--max-seq", type=int, default=4096, help="context the caches are allocated for (round 5: 8192 ... 131072; use fewer --layers)")
     a = ap.parse_args()
     ops.init(0)
@@ -56,14 +57,19 @@ def main():
             cases = tuple((p_, n_) for p_ in (600, 1023, 2047, 4095) for n_ in (1, 4, 8, 16, 32) if not (n_ == 1 and p_ > 1023))
         if a.cases:
             cases = tuple(tuple(int(t) for t in c.split(":")) for c in a.cases.split(","))
-        for pos, nsplit in cases:
+        if a.merged:
+            cases = tuple((p_, n_, m_) for p_, n_ in cases for m_ in ((0, 1) if 1 < n_ <= 64 else (0,)))
+        else:
+            cases = tuple((p_, n_, 0) for p_, n_ in cases)
+        for pos, nsplit, merged in cases:
+            split_fn = L.ntk_attention_decode_split_merged if merged else L.ntk_attention_decode_split
             dpos = DB.from_numpy(np.array([pos], np.int32))
             n = 64 if max_seq <= 4096 else 16
             def launch(i):
                 if nsplit == 1:
                     ops.attention_decode_fused(out, q, k, v, kc[i % nl], vc[i % nl], dpos, nh, nkv, hd, max_seq, 1.0 / np.sqrt(hd), 500000.0)
                 else:
-                    _lib.check(L.ntk_attention_decode_split(out.ptr, q.ptr, k.ptr, v.ptr, kc[i % nl].ptr, vc[i % nl].ptr, dpos.ptr, None, nh, nkv, hd,
+                    _lib.check(split_fn(out.ptr, q.ptr, k.ptr, v.ptr, kc[i % nl].ptr, vc[i % nl].ptr, dpos.ptr, None, nh, nkv, hd,
                                                             max_seq, 1.0 / np.sqrt(hd), 500000.0, 1.0, nsplit, scratch.ptr, None), "split")
             launch(0); ops.synchronize()
             graph, gexec = C.c_void_p(), C.c_void_p()
@@ -78,9 +84,9 @@ def main():
             HIP.hipGraphExecDestroy(gexec); HIP.hipGraphDestroy(graph)
             us = ms.value * 1e3 / n
             kvb = 2 * (pos + 1) * per * 2
-            res.append({"model": name, "pos": pos, "nsplit": nsplit, "us": round(us, 2), "kv_MB": round(kvb / 1e6, 3), "GBs": round(kvb / us / 1e3, 1)})
+            res.append({"model": name, "pos": pos, "nsplit": nsplit, "merged": merged, "us": round(us, 2), "kv_MB": round(kvb / 1e6, 3), "GBs": round(kvb / us / 1e3, 1)})
             print("%-4s pos %5d nsplit %2d: %8.2f us per layer (%s), KV %7.3f MB -> %7.1f GB/s"
-                  % (name, pos, nsplit, us, "single pass" if nsplit == 1 else "split", kvb / 1e6, kvb / us / 1e3), flush=True)
+                  % (name, pos, nsplit, us, "single pass" if nsplit == 1 else ("split, one launch" if merged else "split + combine launch"), kvb / 1e6, kvb / us / 1e3), flush=True)
     if a.json: json.dump(res, open(a.json, "w"), indent=1)
 
 
