@@ -271,6 +271,19 @@ size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features);
  * rows_i, dtype}; <= 3 segments, no residual.  workspace sized for (in_features, sum of rows_i). */
 int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
                             size_t workspace_bytes, int reuse_x, void* stream);
+/* The same two with the tokens' largest |X[t, :]| supplied (row_max[n_tokens], device; NULL = computed by a pass over X as above): the
+ * operand pre-pass is then ONE launch.  Identical results.  The kernels that usually PRODUCE X in the reference's prompt path leave
+ * row_max beside it: RMSNorm (reference src/model/norm.cpp -> launch_rmsnorm, rmsnorm.cu:60-68; same expressions and sums as
+ * ntk_rmsnorm, identical output) -- zero_tokens (optional): n_tokens floats set to 0 for a later ntk_silu_mul_rowmax -- and
+ * SiLU(gate) * up (reference ffn.cpp:127 -> launch_silu_mul, gemm.cu:719-724; identical output; width % 4 == 0, 16-byte aligned
+ * pointers, output may alias gate), whose row_max must hold zeros (or earlier maxima of the same tokens) on entry. */
+int ntk_gemm_quant_ws_rm(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
+                         const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream);
+int ntk_gemm_quant_ws_multi_rm(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                               size_t workspace_bytes, int reuse_x, const float* row_max, void* stream);
+int ntk_rmsnorm_rowmax(float* output, const float* input, const float* weight, int n_tokens, int hidden_size, float eps, float* row_max,
+                       float* zero_tokens, void* stream);
+int ntk_silu_mul_rowmax(float* output, const float* gate, const float* up, int n_tokens, int width, float* row_max, void* stream);
 int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features,
                       int weight_dtype, const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream);
 

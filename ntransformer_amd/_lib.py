@@ -76,6 +76,8 @@ def lib() -> C.CDLL:
         "ntk_gemv_add": (i, [vp, vp, vp, i, i, i, vp]),
         "ntk_gemm_f32": (i, [vp, vp, vp, i, i, i, vp]),
         "ntk_silu_mul": (i, [vp, vp, vp, i, vp]),
+        "ntk_rmsnorm_rowmax": (i, [vp, vp, vp, i, i, f, vp, vp, vp]),
+        "ntk_silu_mul_rowmax": (i, [vp, vp, vp, i, i, vp, vp]),
         "ntk_add_bias": (i, [vp, vp, i, vp]),
         "ntk_attention_decode": (i, [vp, vp, vp, vp, i, i, i, i, i, f, vp]),
         "ntk_attention_prefill": (i, [vp, vp, vp, vp, i, i, i, i, i, i, f, vp]),

@@ -74,7 +74,7 @@ void Model::free_all() {
     host_pos_ = 0;
     attn_regime_ = 0;
     k_cache_ = v_cache_ = nullptr;
-    hidden_ = residual_ = workspace_ = logits_ = argmax_scratch_ = rope_inv_freq_ = attn_scratch_ = nullptr;
+    hidden_ = residual_ = workspace_ = logits_ = argmax_scratch_ = rope_inv_freq_ = attn_scratch_ = row_max_ = nullptr;
     positions_ = tokens_dev_ = d_pos_ = d_token_ = nullptr;
 }
 
@@ -488,6 +488,7 @@ int Model::alloc_buffers() {   // transformer.cpp:330-391
     d_token_ = (int*)dev(64, true);
     argmax_scratch_ = (float*)dev(2 * 1024 * 4, false);
     rope_inv_freq_ = (float*)dev((size_t)cfg_.head_dim / 2 * 4 + 64, false);
+    row_max_ = (float*)dev((size_t)S * 2 * 4, true);
     attn_scratch_ = (float*)dev(ntk_attention_split_scratch_bytes(cfg_.n_heads, cfg_.head_dim, kMaxAttnSplits), true);   // (zeroed: the arrival counters in front)
     h_token_ = (int*)nt_hip_malloc_host(64);
     h_ring_ = (unsigned long long*)nt_hip_malloc_host(64);
@@ -601,14 +602,16 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
     // (a prompt of <= 16 tokens is one pass of the F32-MFMA GEMM, with no operand pre-pass: measured 2 217 vs 1 727 tok/s at 16)
     const bool bf16_now = bf16_prefill_ && gemm_ws_ && T > 16;
     const float* planes_of = nullptr;   // the x whose FP16 planes sit in gemm_ws_ (Q, K, V and gate, up share one x)
-    auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride) {
+    // rm: the tokens' largest |X| when the kernel that produced X left them (ntk_rmsnorm_rowmax / ntk_silu_mul_rowmax): the FP16 GEMM's operand
+    // pre-pass then needs no pass of its own over X for the token scales
+    auto project = [&](float* Y, const DevTensor& w, const float* X, size_t ystride, size_t xstride, const float* rm) {
         raw_begin();
         const void* wp = raw_of(w);
         if (batched && is_quant(w.dtype) && ystride == (size_t)w.out_f && xstride == (size_t)w.in_f) {
             int st = NTK_E_DTYPE;
             if (bf16_now)   // FP16 matrix cores, up to 1024 tokens per pass (Q8_0 / Q4_K / Q5_K / Q6_K)
-                st = ntk_gemm_quant_ws(Y, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
-                                       X == planes_of ? 1 : 0, s);
+                st = ntk_gemm_quant_ws_rm(Y, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, gemm_ws_, gemm_ws_bytes_,
+                                          X == planes_of ? 1 : 0, rm, s);
             if (st == NTK_OK) planes_of = X;
             if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)
                 st = ntk_gemm_quant(Y, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, nullptr, s);
@@ -617,7 +620,7 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
         for (int t = 0; t < T; ++t) gemv(Y + (size_t)t * ystride, w, wp, X + (size_t)t * xstride);
     };
     // matrices that share X (Q | K | V, gate | up): those of one format go out as ONE launch of the FP16 GEMM, the rest one by one
-    auto project_many = [&](float* const* Ys, const DevTensor* const* Ws, int n, const float* X) {
+    auto project_many = [&](float* const* Ys, const DevTensor* const* Ws, int n, const float* X, const float* rm) {
         bool done[3] = {false, false, false};
         if (batched && bf16_now) {
             for (int a = 0; a < n; ++a) {
@@ -629,19 +632,19 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
                 if (m < 2) continue;
                 raw_begin();   // (the group's tensors side by side in the unpack scratch when their GGUF bytes are not resident)
                 for (int k = 0; k < m; ++k) segs[k] = {raw_of(*Ws[idx[k]]), Ys[idx[k]], (int)Ws[idx[k]]->out_f, Ws[idx[k]]->dtype};
-                const int st = ntk_gemm_quant_ws_multi(segs, m, X, T, (int)Ws[a]->in_f, gemm_ws_, gemm_ws_bytes_, X == planes_of ? 1 : 0, s);
+                const int st = ntk_gemm_quant_ws_multi_rm(segs, m, X, T, (int)Ws[a]->in_f, gemm_ws_, gemm_ws_bytes_, X == planes_of ? 1 : 0, rm, s);
                 if (st == NTK_OK) { planes_of = X; for (int k = 0; k < m; ++k) done[idx[k]] = true; }
                 else if (st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) { ok(st); return; }
             }
         }
         for (int a = 0; a < n; ++a)
-            if (!done[a]) project(Ys[a], *Ws[a], X, (size_t)Ws[a]->out_f, (size_t)Ws[a]->in_f);
+            if (!done[a]) project(Ys[a], *Ws[a], X, (size_t)Ws[a]->out_f, (size_t)Ws[a]->in_f, rm);
     };
     // hidden += W . X (attention.cpp:207 + transformer.cpp:645, ffn.cpp:130 + transformer.cpp:652): the batched
     // projection adds the residual in its epilogue, the reference sequence goes through residual_ and launch_add_inplace
-    auto project_add = [&](const DevTensor& w, const float* X, size_t xstride) {
+    auto project_add = [&](const DevTensor& w, const float* X, size_t xstride, const float* rm) {
         if (tp_world_ > 1) {   // this rank's columns give a PARTIAL sum: into the exchange slot, then hidden += sum over ranks
-            project(tp_slot(), w, X, H, xstride);
+            project(tp_slot(), w, X, H, xstride, rm);
             planes_of = nullptr;
             ok(tp_allreduce(hidden_, T * H));
             return;
@@ -651,40 +654,52 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
             raw_begin();
             const void* wp = raw_of(w);
             if (bf16_now)
-                st = ntk_gemm_quant_ws(hidden_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, s);
+                st = ntk_gemm_quant_ws_rm(hidden_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, rm, s);
             planes_of = nullptr;   // (this projection rewrites hidden_, and the next group has a new x)
             if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN)
                 st = ntk_gemm_quant(hidden_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, s);
             if (st != NTK_E_ALIGN && st != NTK_E_SHAPE) { ok(st); return; }
         }
-        project(residual_, w, X, H, xstride);
+        project(residual_, w, X, H, xstride, rm);
         ok(ntk_add_inplace(hidden_, residual_, T * H, s));
+    };
+    // RMSNorm / SiLU x up in front of an FP16-GEMM projection also leave the tokens' largest |x| (row_max_: [2][max_seq]; the second array is
+    // zeroed by the layer's first RMSNorm launch for the SiLU launch's atomic maxima)
+    const bool with_max = batched && bf16_now && row_max_ != nullptr && prefill_row_max_;
+    float* rm_a = with_max ? row_max_ : nullptr;
+    float* rm_b = with_max ? row_max_ + cfg_.max_seq_len : nullptr;
+    auto norm = [&](const DevTensor& nw, bool zero_b) {
+        if (with_max) ok(ntk_rmsnorm_rowmax(residual_, hidden_, (const float*)nw.ptr, T, H, cfg_.norm_eps, rm_a, zero_b ? rm_b : nullptr, s));
+        else ok(ntk_rmsnorm(residual_, hidden_, (const float*)nw.ptr, T, H, cfg_.norm_eps, s));
     };
     for (int i = first; i < last_layer; ++i) {
         const LayerWeights& L = layers_[i];
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
-        ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.attn_norm.ptr, T, H, cfg_.norm_eps, s));
+        norm(L.attn_norm, true);
         planes_of = nullptr;   // residual_ has new contents
         {
             float* const ys[3] = {q_buf, k_buf, v_buf};
             const DevTensor* const ws[3] = {&L.wq, &L.wk, &L.wv};
-            project_many(ys, ws, 3, residual_);
+            project_many(ys, ws, 3, residual_, rm_a);
         }
         ok(ntk_rope(q_buf, k_buf, positions_, 1, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, s));
         ok(ntk_copy_to_kv_cache(kc, vc, k_buf, v_buf, T, nkv, hd, start_pos, cfg_.max_seq_len, s));
         if (T == 1) ok(ntk_attention_decode(attn_out, q_buf, kc, vc, start_pos + T, nh, nkv, hd, cfg_.max_seq_len, scale, s));
         else ok(ntk_attention_prefill(attn_out, q_buf, kc, vc, T, start_pos, nh, nkv, hd, cfg_.max_seq_len, scale, s));
-        project_add(L.wo, attn_out, qd);
-        ok(ntk_rmsnorm(residual_, hidden_, (const float*)L.ffn_norm.ptr, T, H, cfg_.norm_eps, s));
+        project_add(L.wo, attn_out, qd, nullptr);
+        norm(L.ffn_norm, false);
         planes_of = nullptr;
         {
             float* const ys[2] = {gate_buf, up_buf};
             const DevTensor* const ws[2] = {&L.w_gate, &L.w_up};
-            project_many(ys, ws, 2, residual_);
+            project_many(ys, ws, 2, residual_, rm_a);
         }
-        ok(ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s));   // per token in the reference (ffn.cpp:127): same elementwise op
-        project_add(L.w_down, gate_buf, I);
+        // per token in the reference (ffn.cpp:127): same elementwise op
+        int st_silu = with_max ? ntk_silu_mul_rowmax(gate_buf, gate_buf, up_buf, T, I, rm_b, s) : NTK_E_SHAPE;
+        if (st_silu == NTK_E_SHAPE || st_silu == NTK_E_ALIGN) { st_silu = ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s); rm_b = nullptr; }   // (then for the rest of the pass)
+        ok(st_silu);
+        project_add(L.w_down, gate_buf, I, rm_b);
         if (rc != NTK_OK) break;
     }
     return rc;

@@ -101,6 +101,7 @@ public:
     void set_persistent(int level);   // 0 off, 1 decode_persistent.hip, 2 layer_engine.hip (round 5); EXPERIMENTS=1 builds only, otherwise stays off
     int persistent_kind() const { return persistent_plan_ ? persistent_kind_ : 0; }
     void set_fuse_attention(bool on) { fuse_attention_ = on; }
+    void set_prefill_row_max(bool on) { prefill_row_max_ = on; }
     // Split-KV decode attention as ONE launch (the last workgroup of a head merges the partial states: attention_merge.hip.h) or -- the default --
     // with the separate combine launch of rounds 3-5; same bits either way, the one-launch form measured 0.1-0.6 us (walk) / 1.5-4 us (matrix-core
     // form) per layer slower (profiles/NEGATIVE_RESULTS.md 8).  Captured graphs are dropped when the setting changes.
@@ -219,6 +220,8 @@ private:
     int host_pos_ = 0;               // host mirror of *d_pos_ (set_device_pos + one per fused step): picks the regime
     int attn_regime_ = 0;            // regime enqueue_token() emits
     float* attn_scratch_ = nullptr;  // partial softmax states of the split-KV attention
+    bool prefill_row_max_ = true;    // RMSNorm / SiLU launches of the prompt pass leave the tokens' largest |x| for the FP16 GEMM's pre-pass (A/B switch)
+    float* row_max_ = nullptr;       // [2][max_seq]: the prompt tokens' largest |x| beside the RMSNorm / SiLU outputs (FP16 GEMM pre-pass)
     void* gemm_ws_ = nullptr;        // workspace of ntk_gemm_quant_ws (FP16 prompt projections), sized for max(H, I) columns
     size_t gemm_ws_bytes_ = 0;
     bool bf16_prefill_ = true;

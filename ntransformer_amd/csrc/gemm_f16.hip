@@ -93,6 +93,11 @@ typedef uint16_t __attribute__((aligned(2))) u16_a2;
 // s = 2^(14 - floor(log2 m)), m = the token's largest |x|: m s in [2^14, 2^15) -- FP16's largest binade but one.  Exponent fields are
 // kept inside [1, 253] so that both s and 1 / s are normal numbers (an all-zero or subnormal token multiplies to zero either way; a
 // token holding Inf / NaN propagates it through the first piece).  grid = ceil(T / 4), block = 256: one wave per token.
+// exponent field of s from the token's largest |x| (bit pattern; a NaN pattern counts as the largest binade: any scale will do then)
+__device__ __forceinline__ int scale_exp_of_max(uint32_t max_bits) {
+    const int em = (int)((max_bits >> 23) & 0xFFu);
+    return min(253, max(1, 268 - em));
+}
 __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ X, int T, int in, float* __restrict__ scale, float* __restrict__ inv) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
@@ -106,8 +111,7 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     uint32_t mb = __float_as_uint(m);
     if (m != m) mb = 0x7F800000u;   // (fmaxf drops NaNs: a NaN anywhere in the row is found by the planes, any scale will do)
-    const int em = (int)((mb >> 23) & 0xFFu);
-    const int es = min(253, max(1, 268 - em));
+    const int es = scale_exp_of_max(mb);
     if (lane == 0) {
         scale[t] = __uint_as_float((uint32_t)es << 23);
         inv[t] = __uint_as_float((uint32_t)(254 - es) << 23);
@@ -116,13 +120,17 @@ __global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict_
 
 // ---- pre-pass 2: X -> FP16 planes in operand order + per-step sums ---------------------------------------------------------------
 // grid = (in / 32 steps + 8 (a record of zeros and a whole unit of zero sums), 64-token chunks), block = 256 = 4 token blocks x 64 lanes
+// FROM_MAX: `scale` holds the tokens' largest |x| (written by the kernel that PRODUCED X: rmsnorm_rowmax_kernel, silu_mul_rowmax_kernel below) instead
+// of their scales -- no row_scale_kernel pass over X; the blocks of step 0 leave 1 / s in `inv` for the main kernel
+template <bool FROM_MAX>
 __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ X, int T, int in, u32x4* __restrict__ xb, float* __restrict__ aux,
-                                                      size_t chunk_bytes, const float* __restrict__ scale) {
+                                                      size_t chunk_bytes, const float* __restrict__ scale, float* __restrict__ inv) {
     const int step = blockIdx.x, tb = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 15, g = lane >> 4, t = tb * 16 + j;
     // blockIdx.y = 64-token chunk: its tokens, its planes
     X += (size_t)blockIdx.y * GB_TOK * in;
     scale += (size_t)blockIdx.y * GB_TOK;
+    if constexpr (FROM_MAX) inv += (size_t)blockIdx.y * GB_TOK;
     T = min(GB_TOK, T - (int)blockIdx.y * GB_TOK);
     xb = reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(xb) + blockIdx.y * chunk_bytes);
     aux = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(aux) + blockIdx.y * chunk_bytes);
@@ -134,7 +142,13 @@ __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ 
         const float* row = X + (size_t)t * in + step * 32 + 4 * g;
         const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 16);
         x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
-        sc = scale[t];
+        if constexpr (FROM_MAX) {
+            const int es = scale_exp_of_max(__float_as_uint(scale[t]));
+            sc = __uint_as_float((uint32_t)es << 23);
+            if (step == 0 && g == 0) inv[t] = __uint_as_float((uint32_t)(254 - es) << 23);
+        } else {
+            sc = scale[t];
+        }
     }
     float p1[8], p2[8];
 #pragma unroll
@@ -167,6 +181,51 @@ __global__ __launch_bounds__(256) void split_x_kernel(const float* __restrict__ 
         rec[pos] = h1;
         rec[4 * 128 + pos] = h2;
     }
+}
+
+// ---- producers that leave the tokens' largest |x| beside X (so that the pre-pass above needs no pass of its own over X) ----------
+// RMSNorm (elementwise.hip's rmsnorm_kernel, reference rmsnorm.cu:60-68, same expressions) + max |y| per token; zero (optional): T floats set to
+// 0 for a LATER launch that accumulates maxima with atomics (silu_mul_rowmax_kernel).  One workgroup per token.
+__global__ __launch_bounds__(1024) void rmsnorm_rowmax_kernel(float* __restrict__ output, const float* __restrict__ input, const float* __restrict__ weight,
+                                                              int hidden, float eps, float* __restrict__ row_max, float* __restrict__ zero) {
+    __shared__ float red[16];
+    const float* x = input + (size_t)blockIdx.x * hidden;
+    float ssq = 0.0f;
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) ssq = fmaf(x[i], x[i], ssq);
+    const float tot = block_sum(ssq, red);
+    const float rms_inv = 1.0f / sqrtf(tot / (float)hidden + eps);
+    uint32_t mb = 0;   // (bit patterns of |y|: ordered like the values, and a NaN is not dropped)
+    for (int i = threadIdx.x; i < hidden; i += blockDim.x) {
+        const float v = x[i] * rms_inv * weight[i];
+        output[(size_t)blockIdx.x * hidden + i] = v;
+        mb = max(mb, __float_as_uint(v) & 0x7FFFFFFFu);
+    }
+    __syncthreads();   // (red is reused)
+    const float m = block_max(__uint_as_float(mb <= 0x7F800000u ? mb : 0x7F800000u), red);   // (NaN -> the largest binade, like row_scale_kernel's rule)
+    if (threadIdx.x == 0) {
+        row_max[blockIdx.x] = m;
+        if (zero) zero[blockIdx.x] = 0.0f;
+    }
+}
+// out = silu(gate) * up (elementwise.hip's silu_mul_kernel, reference gemm.cu:719-724) + max |out| per token, accumulated with one atomic per
+// workgroup on the bit pattern (non-negative floats order like their bits).  grid (ceil(I / 1024), T), 256 threads x 4 elements; I % 4 == 0.
+__global__ __launch_bounds__(256) void silu_mul_rowmax_kernel(float* __restrict__ out, const float* __restrict__ gate, const float* __restrict__ up, int I,
+                                                              float* __restrict__ row_max) {
+    __shared__ float red[16];
+    const int t = blockIdx.y, i = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    uint32_t mb = 0;
+    if (i < I) {
+        const size_t at = (size_t)t * I + i;
+        const float4 g = *reinterpret_cast<const float4*>(gate + at), u = *reinterpret_cast<const float4*>(up + at);
+        float4 o;
+        o.x = g.x / (1.0f + expf(-g.x)) * u.x; o.y = g.y / (1.0f + expf(-g.y)) * u.y;
+        o.z = g.z / (1.0f + expf(-g.z)) * u.z; o.w = g.w / (1.0f + expf(-g.w)) * u.w;
+        *reinterpret_cast<float4*>(out + at) = o;
+        mb = max(max(__float_as_uint(o.x) & 0x7FFFFFFFu, __float_as_uint(o.y) & 0x7FFFFFFFu),
+                 max(__float_as_uint(o.z) & 0x7FFFFFFFu, __float_as_uint(o.w) & 0x7FFFFFFFu));
+    }
+    const float m = block_max(__uint_as_float(mb <= 0x7F800000u ? mb : 0x7F800000u), red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(row_max) + t, __float_as_uint(m));
 }
 
 // ---- per-format weight operand ---------------------------------------------------------------------------------------------
@@ -930,7 +989,7 @@ struct HostSeg { float* Y; const void* W; int out; };
 // T <= GB_MAX_CHUNKS * 64 = 1024 tokens in one launch; nseg matrices [out_s][in] of one format sharing X
 template <int DT>
 static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T, int in, const float* resid, void* ws, int reuse_x,
-                            hipStream_t st) {
+                            const float* row_max, hipStream_t st) {
     using D = DeqI<DT>;
     constexpr int TRIP = GB_UPT * D::SPU;   // steps per loop trip: K ranges are whole trips
     // whole units only (Q8_0: in a multiple of 128, Q4_0 and the K-quants: of 256): a partial last unit would decode the next row's bytes as
@@ -956,10 +1015,13 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
     float* scales = reinterpret_cast<float*>(wsb + (size_t)GB_MAX_CHUNKS * p.chunk_bytes);   // [inv: 1024][scale: 1024]
     p.inv = scales;
     p.resid = resid;
-    if (!reuse_x) {
+    if (!reuse_x && row_max) {   // the tokens' largest |x| came with X: one pre-pass launch
+        hipLaunchKernelGGL(split_x_kernel<true>, dim3(p.steps + 8, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb),
+                           const_cast<float*>(p.aux), p.chunk_bytes, row_max, scales);
+    } else if (!reuse_x) {
         hipLaunchKernelGGL(row_scale_kernel, dim3((T + 3) / 4), dim3(256), 0, st, X, T, in, scales + GB_MAX_CHUNKS * GB_TOK, scales);
-        hipLaunchKernelGGL(split_x_kernel, dim3(p.steps + 8, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb), const_cast<float*>(p.aux),
-                           p.chunk_bytes, scales + GB_MAX_CHUNKS * GB_TOK);
+        hipLaunchKernelGGL(split_x_kernel<false>, dim3(p.steps + 8, p.chunks), dim3(256), 0, st, X, T, in, reinterpret_cast<u32x4*>(wsb),
+                           const_cast<float*>(p.aux), p.chunk_bytes, scales + GB_MAX_CHUNKS * GB_TOK, static_cast<float*>(nullptr));
     }
     // Rows per wave (RT x 16): a workgroup streams ALL B operands of its K range from L2 whatever its height, so taller tiles
     // cut that traffic and the LDS reads per MFMA; K is then split (in whole trips) while fewer than one workgroup per CU exists.
@@ -1075,7 +1137,7 @@ size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features) {
 }
 
 static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, int n_tokens, int in_features, int weight_dtype, const float* resid,
-                            void* workspace, int reuse_x, hipStream_t st) {
+                            void* workspace, int reuse_x, const float* row_max, hipStream_t st) {
     constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
     if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (1024 tokens) at a time
     for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 16 x 64 tokens per launch: the chunks share the weights in L2
@@ -1084,34 +1146,43 @@ static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, 
         for (int i = 0; i < nseg; ++i) sg[i] = ntk::HostSeg{segs[i].Y + (size_t)t0 * segs[i].out, segs[i].W, segs[i].out};
         const float* x = X + (size_t)t0 * in_features;
         const float* rs = resid ? resid + (size_t)t0 * segs[0].out : nullptr;
+        const float* rm = row_max ? row_max + t0 : nullptr;
         int rc;
         switch (weight_dtype) {
-            case NTK_DT_Q8_0: rc = ntk::launch_gemm_f16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
-            case NTK_DT_Q4_0: rc = ntk::launch_gemm_f16<NTK_DT_Q4_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
-            case NTK_DT_Q4_K: rc = ntk::launch_gemm_f16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
-            case NTK_DT_Q5_K: rc = ntk::launch_gemm_f16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
-            default: rc = ntk::launch_gemm_f16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, st); break;
+            case NTK_DT_Q8_0: rc = ntk::launch_gemm_f16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
+            case NTK_DT_Q4_0: rc = ntk::launch_gemm_f16<NTK_DT_Q4_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
+            case NTK_DT_Q4_K: rc = ntk::launch_gemm_f16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
+            case NTK_DT_Q5_K: rc = ntk::launch_gemm_f16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
+            default: rc = ntk::launch_gemm_f16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
         }
         if (rc != NTK_OK) return rc;
     }
     return NTK_OK;
 }
 
-int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
-                      const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream) {
+static int gemm_quant_ws_impl(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
+                              const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
     if (!Y || !W || !X || !workspace) return NTK_E_NULL;
     if (n_tokens < 0 || out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
     if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
     const ntk::HostSeg sg{Y, W, out_features};
-    return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, ntk::resolve_stream(stream));
+    return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, row_max, ntk::resolve_stream(stream));
+}
+int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
+                      const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream) {
+    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, nullptr, stream);
+}
+int ntk_gemm_quant_ws_rm(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
+                         const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
+    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, row_max, stream);
 }
 
 // several matrices of one format sharing X (Q | K | V, gate | up) in ONE launch: segs[i] = {Y_i [n_tokens][rows_i], W_i, rows_i}
 // (ntk_gemv_seg: y, W, rows, dtype -- the dtypes must agree).  workspace: ntk_gemm_quant_workspace_bytes(in, sum of rows).
-int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
-                            size_t workspace_bytes, int reuse_x, void* stream) {
+static int gemm_quant_ws_multi_impl(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                                    size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
     if (!segs || !X || !workspace) return NTK_E_NULL;
     if (nseg < 1 || nseg > ntk::GB_MAX_SEG || n_tokens < 0 || in_features <= 0) return NTK_E_SHAPE;
     ntk::HostSeg sg[ntk::GB_MAX_SEG];
@@ -1126,7 +1197,35 @@ int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, 
     if (dt != NTK_DT_Q8_0 && dt != NTK_DT_Q4_0 && dt != NTK_DT_Q4_K && dt != NTK_DT_Q5_K && dt != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, (int)total) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
     if (n_tokens == 0) return NTK_OK;
-    return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, ntk::resolve_stream(stream));
+    return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, row_max, ntk::resolve_stream(stream));
+}
+int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                            size_t workspace_bytes, int reuse_x, void* stream) {
+    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, nullptr, stream);
+}
+int ntk_gemm_quant_ws_multi_rm(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                               size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
+    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, row_max, stream);
+}
+
+int ntk_rmsnorm_rowmax(float* output, const float* input, const float* weight, int n_tokens, int hidden_size, float eps, float* row_max,
+                       float* zero_tokens, void* stream) {
+    if (!output || !input || !weight || !row_max) return NTK_E_NULL;
+    if (n_tokens < 0 || hidden_size <= 0) return NTK_E_SHAPE;
+    if (n_tokens == 0) return NTK_OK;
+    hipLaunchKernelGGL(ntk::rmsnorm_rowmax_kernel, dim3(n_tokens), dim3(hidden_size <= 1024 ? 256 : (hidden_size <= 4096 ? 512 : 1024)) /* = ntk_rmsnorm's blocks: the same sums */, 0,
+                       ntk::resolve_stream(stream), output, input,
+                       weight, hidden_size, eps, row_max, zero_tokens);
+    return ntk::last_launch_status();
+}
+int ntk_silu_mul_rowmax(float* output, const float* gate, const float* up, int n_tokens, int width, float* row_max, void* stream) {
+    if (!output || !gate || !up || !row_max) return NTK_E_NULL;
+    if (n_tokens < 0 || width <= 0 || width % 4 != 0) return NTK_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(output) | reinterpret_cast<uintptr_t>(gate) | reinterpret_cast<uintptr_t>(up)) & 15) return NTK_E_ALIGN;
+    if (n_tokens == 0) return NTK_OK;
+    hipLaunchKernelGGL(ntk::silu_mul_rowmax_kernel, dim3((width + 1023) / 1024, n_tokens), dim3(256), 0, ntk::resolve_stream(stream), output, gate, up, width,
+                       row_max);
+    return ntk::last_launch_status();
 }
 
 }  // extern "C"

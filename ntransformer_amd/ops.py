@@ -231,6 +231,27 @@ def gemm_quant_ws(Y, W, X, n_tokens, out_features, in_features, dtype, resid=Non
     return st
 
 
+def gemm_quant_ws_rm(Y, W, X, n_tokens, out_features, in_features, dtype, row_max, resid=None, stream=None):
+    """ntk_gemm_quant_ws_rm: ntk_gemm_quant_ws with the tokens' largest |x| supplied (row_max: device floats [n_tokens]; None = ntk_gemm_quant_ws)."""
+    L = _lib.lib()
+    L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+    n = int(L.ntk_gemm_quant_workspace_bytes(C.c_int(in_features), C.c_int(out_features)))
+    ws = DeviceBuffer(n)
+    L.ntk_gemm_quant_ws_rm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    st = L.ntk_gemm_quant_ws_rm(_p(Y), _p(W), _p(X), n_tokens, out_features, in_features, int(dtype), _p(resid), _p(ws), n, 0, _p(row_max), stream)
+    synchronize()
+    return st
+
+
+def launch_rmsnorm_rowmax(output, input, weight, n_tokens, hidden_size, eps, row_max, zero_tokens=None, stream=None):
+    check(_lib.lib().ntk_rmsnorm_rowmax(_p(output), _p(input), _p(weight), n_tokens, hidden_size, eps, _p(row_max), _p(zero_tokens), stream), "rmsnorm_rowmax")
+
+
+def launch_silu_mul_rowmax(output, gate, up, n_tokens, width, row_max, stream=None):
+    check(_lib.lib().ntk_silu_mul_rowmax(_p(output), _p(gate), _p(up), n_tokens, width, _p(row_max), stream), "silu_mul_rowmax")
+
+
 def sample_top_k(logits, n, recent, n_recent, repeat_penalty, temperature, top_k, top_p, r, d_out, stream=None):
     """ntk_sample_top_k: the reference sampler on the device; logits are penalised in place; token id to d_out (device int)."""
     L = _lib.lib()

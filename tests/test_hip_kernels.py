@@ -141,6 +141,54 @@ def gemm_ws_gpu(Wraw, X, out_f, in_f, dt, resid=None):
     return Yd.numpy(np.float32).reshape(T, out_f)
 
 
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K", "Q6_K"])
+@pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (200, 48, 1024), (1100, 32, 256), (70, 32, 14336)])
+def test_gemm_quant_f16_with_row_maxima_from_the_producers(qname, T, out_f, in_f):
+    """The prompt GEMM's operand pre-pass without its own pass over X for the token scales: ntk_rmsnorm_rowmax and ntk_silu_mul_rowmax leave every
+    token's largest |x| beside their output and ntk_gemm_quant_ws_rm takes it.  Against the separate launches (ntk_rmsnorm / ntk_silu_mul +
+    ntk_gemm_quant_ws, which the tests around this one pin to the oracle): the producers' outputs, the maxima and the GEMM results are equal BIT FOR
+    BIT -- rows of zeros, rows 1e15 / 1e20 times larger and 1100 tokens (two passes of 1024: the second takes row_max + 1024) included."""
+    gt = QUANT[qname]
+    dt = G.GGML_TO_DT[gt]
+    r = rng(T * 31 + out_f + in_f + gt)
+    W = np.frombuffer(G.synth_tensor(r, gt, out_f, in_f), np.uint8)
+    Wd = DB.from_numpy(W)
+    h = r.standard_normal((T, in_f)).astype(np.float32)
+    h[T // 2] = 0.0
+    h[0] *= np.float32(1e15) if T > 1 else np.float32(1.0)
+    nw = (1.0 + 0.1 * r.standard_normal(in_f)).astype(np.float32)
+    eps = 1e-5
+    # RMSNorm -> GEMM
+    x1, x2 = DB.zeros(T * in_f * 4), DB.zeros(T * in_f * 4)
+    rm, zz = DB.from_numpy(np.full(T, np.nan, np.float32)), DB.from_numpy(np.full(T, 7.0, np.float32))
+    ops.launch_rmsnorm(x1, DB.from_numpy(h), DB.from_numpy(nw), T, in_f, eps)
+    ops.launch_rmsnorm_rowmax(x2, DB.from_numpy(h), DB.from_numpy(nw), T, in_f, eps, rm, zz)
+    X1 = x1.numpy(np.float32).reshape(T, in_f)
+    assert np.array_equal(X1, x2.numpy(np.float32).reshape(T, in_f))
+    assert np.array_equal(rm.numpy(np.float32), np.abs(X1).max(axis=1)) and not zz.numpy(np.float32).any()
+    y1, y2 = DB.zeros(T * out_f * 4), DB.zeros(T * out_f * 4)
+    assert ops.gemm_quant_ws(y1, Wd, x1, T, out_f, in_f, dt) == 0
+    assert ops.gemm_quant_ws_rm(y2, Wd, x2, T, out_f, in_f, dt, rm) == 0
+    Y1 = y1.numpy(np.float32)
+    assert np.isfinite(Y1).all() and np.array_equal(Y1, y2.numpy(np.float32))
+    # SiLU(gate) * up -> GEMM (+ residual epilogue)
+    g = (2.0 * r.standard_normal((T, in_f))).astype(np.float32)
+    u = r.standard_normal((T, in_f)).astype(np.float32)
+    g[T // 2] = 0.0
+    u[0] *= np.float32(1e20) if T > 1 else np.float32(1.0)
+    a1, a2 = DB.zeros(T * in_f * 4), DB.from_numpy(g)
+    ops.launch_silu_mul(a1, DB.from_numpy(g), DB.from_numpy(u), T * in_f)
+    ops.launch_silu_mul_rowmax(a2, a2, DB.from_numpy(u), T, in_f, zz)            # in place over gate, maxima into the array the RMSNorm launch zeroed
+    A1 = a1.numpy(np.float32).reshape(T, in_f)
+    assert np.array_equal(A1, a2.numpy(np.float32).reshape(T, in_f))
+    assert np.array_equal(zz.numpy(np.float32), np.abs(A1).max(axis=1))
+    res = r.standard_normal((T, out_f)).astype(np.float32)
+    y1, y2 = DB.from_numpy(res), DB.from_numpy(res)
+    assert ops.gemm_quant_ws(y1, Wd, a1, T, out_f, in_f, dt, resid=y1) == 0
+    assert ops.gemm_quant_ws_rm(y2, Wd, a2, T, out_f, in_f, dt, zz, resid=y2) == 0
+    assert np.array_equal(y1.numpy(np.float32), y2.numpy(np.float32))
+
+
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048), (9, 32, 768),
                                           (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672), (300, 64, 512), (520, 48, 1024), (1100, 32, 256)])

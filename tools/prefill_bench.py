@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--mixes", default="Q8_0,Q4_K,Q6_K", help="per-matrix table: weight formats")
     ap.add_argument("--tokens", default="16,64,256,1024", help="engine part: prompt lengths")
     ap.add_argument("--modes", default="2,1,0", help="engine part: 2 = FP16 GEMM, 1 = F32-MFMA GEMM, 0 = per-token loop (<= 64 tokens only)")
+    ap.add_argument("--ab-row-max", action="store_true", help="engine part, mode 2: alternate prefill_row_max = 1 / 0 three times (the RMSNorm / SiLU launches leave the token maxima for the GEMM pre-pass, or the pre-pass makes its own pass over X)")
     ap.add_argument("--bf16-only", action="store_true", help="per-matrix table: only the FP16 GEMM launches (profiling; the flag keeps its round-2 name)")
     a = ap.parse_args()
     ops.init(0)
@@ -85,6 +86,16 @@ def main():
         for T in [int(t) for t in a.tokens.split(',')]:
             modes = [m for m in want_modes if m > 0 or T <= 64]
             prompt = [128000] + [int(t) for t in r.integers(0, 128000, T - 1)]
+            if a.ab_row_max:
+                eng.set_option("batched_prefill", 1); eng.set_option("bf16_prefill", 1)
+                for rep in range(3):
+                    for rm in (1, 0):
+                        eng.set_option("prefill_row_max", rm)
+                        eng.forward(prompt, 0)
+                        t0 = time.perf_counter(); eng.forward(prompt, 0); eng.forward(prompt, 0); dt_ = (time.perf_counter() - t0) / 2
+                        print("8B %s prompt of %4d tokens, FP16 GEMM, prefill_row_max=%d (rep %d): %9.2f ms = %9.1f tokens/s" % (a.mix, T, rm, rep, dt_ * 1e3, T / dt_), flush=True)
+                eng.set_option("prefill_row_max", 1)
+                continue
             for batched in modes:   # 2: FP16 MFMA, 64-token chunks; 1: F32 MFMA, 16 per pass; 0: the reference's per-token loop
                 eng.set_option("batched_prefill", batched > 0)
                 eng.set_option("bf16_prefill", batched == 2)
