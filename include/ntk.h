@@ -79,7 +79,7 @@ void   nt_hip_free(void* p);
 void   nt_hip_memcpy_h2d(void* dst, const void* src, size_t size);   /* blocking, like the reference */
 void   nt_hip_memcpy_d2h(void* dst, const void* src, size_t size);
 void   nt_hip_memcpy_d2d(void* dst, const void* src, size_t size);
-void   nt_hip_memset(void* p, int value, size_t size);
+void   nt_hip_memset(void* p, int value, size_t size);                /* complete on return (and so is the d2d copy) */
 void*  nt_hip_malloc_host(size_t size);              /* pinned */
 void   nt_hip_free_host(void* p);
 int    ntk_memcpy_h2d_async(void* dst, const void* src, size_t size, void* stream);   /* device.cu:136-144 */
@@ -139,6 +139,10 @@ int ntk_attention_prefill(float* output, const float* Q, const void* k_cache, co
 /* launch_copy_to_kv_cache, kernels.h:61-64 / attention.cu:405-425.  F32 -> F16 (RNE) scatter at start_pos. */
 int ntk_copy_to_kv_cache(void* k_cache, void* v_cache, const float* k, const float* v, int seq_len,
                          int n_kv_heads, int head_dim, int start_pos, int max_seq, void* stream);
+/* launch_rope + launch_copy_to_kv_cache of a prompt as ONE launch (the two calls back to back in reference attention.cpp:164-184): q rotated in
+ * place, the rotated k and v converted to F16 (RNE) into the caches at start_pos; k and v are only read.  Identical q and cache rows.  head_dim <= 256. */
+int ntk_rope_kv_store(float* q, const float* k, const float* v, const int* positions, int seq_len, int n_heads, int n_kv_heads, int head_dim,
+                      float theta_base, float freq_scale, int interleaved, void* k_cache, void* v_cache, int start_pos, int max_seq, void* stream);
 /* element-wise, kernels.h:67-72 / elementwise.cu:90-115 */
 int ntk_add(float* out, const float* a, const float* b, int size, void* stream);
 int ntk_add_inplace(float* a, const float* b, int size, void* stream);
@@ -281,6 +285,27 @@ int ntk_gemm_quant_ws_rm(float* Y, const void* W, const float* X, int n_tokens, 
                          const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream);
 int ntk_gemm_quant_ws_multi_rm(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
                                size_t workspace_bytes, int reuse_x, const float* row_max, void* stream);
+/* ... and the projection's split-K sums folded into the launch that consumes it.  The *_deferred forms run the same launch but, when it splits K,
+ * leave the partial sums in the workspace instead of launching the reduce: *partials then describes them (nsplit > 1; valid until the next call with
+ * this workspace) -- or says nsplit == 1, in which case Y was written as usual.  No residual input: the consumer adds it.
+ *   ntk_reduce_rmsnorm_rowmax : hidden[t] = (sum of the splits, in order) + hidden[t]  (= the residual epilogue's association), x_out = rmsnorm(hidden)
+ *                               with row_max / zero_tokens as ntk_rmsnorm_rowmax: Wo / down projection + residual + the next RMSNorm, one launch;
+ *   ntk_reduce_silu_mul_rowmax: output[t] = silu(gate[t]) * up[t] of a deferred two-matrix gate | up launch, with row_max as ntk_silu_mul_rowmax.
+ * Identical bits to the separate launches (same sums in the same order). */
+typedef struct ntk_gemm_partials {
+    const float* part[3];   /* per matrix: [nsplit][n_tokens][rows] partial sums (NULL when nsplit == 1) */
+    float*       y[3];      /* per matrix: the Y passed to the launch (written when nsplit == 1)            */
+    int          rows[3];
+    int          nseg, n_tokens, nsplit;
+} ntk_gemm_partials;
+int ntk_gemm_quant_ws_deferred(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
+                               void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials,
+                               void* stream);
+int ntk_gemm_quant_ws_multi_deferred(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                                     size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials, void* stream);
+int ntk_reduce_rmsnorm_rowmax(float* hidden, const ntk_gemm_partials* partials, const float* weight, float eps, float* x_out, float* row_max,
+                              float* zero_tokens, void* stream);
+int ntk_reduce_silu_mul_rowmax(float* output, const ntk_gemm_partials* partials, float* row_max, void* stream);
 int ntk_rmsnorm_rowmax(float* output, const float* input, const float* weight, int n_tokens, int hidden_size, float eps, float* row_max,
                        float* zero_tokens, void* stream);
 int ntk_silu_mul_rowmax(float* output, const float* gate, const float* up, int n_tokens, int width, float* row_max, void* stream);

@@ -30,6 +30,10 @@ class GemvSeg(C.Structure):
     _fields_ = [("W", C.c_void_p), ("y", C.c_void_p), ("rows", C.c_int), ("dtype", C.c_int)]
 
 
+class GemmPartials(C.Structure):   # ntk_gemm_partials (include/ntk.h)
+    _fields_ = [("part", C.c_void_p * 3), ("y", C.c_void_p * 3), ("rows", C.c_int * 3), ("nseg", C.c_int), ("n_tokens", C.c_int), ("nsplit", C.c_int)]
+
+
 _lib = None
 
 
@@ -77,6 +81,7 @@ def lib() -> C.CDLL:
         "ntk_gemm_f32": (i, [vp, vp, vp, i, i, i, vp]),
         "ntk_silu_mul": (i, [vp, vp, vp, i, vp]),
         "ntk_rmsnorm_rowmax": (i, [vp, vp, vp, i, i, f, vp, vp, vp]),
+        "ntk_rope_kv_store": (i, [vp, vp, vp, vp, i, i, i, i, f, f, i, vp, vp, i, i, vp]),
         "ntk_silu_mul_rowmax": (i, [vp, vp, vp, i, i, vp, vp]),
         "ntk_add_bias": (i, [vp, vp, i, vp]),
         "ntk_attention_decode": (i, [vp, vp, vp, vp, i, i, i, i, i, f, vp]),

@@ -720,6 +720,49 @@ __global__ __launch_bounds__(256) void rope_rows_kernel(float* __restrict__ q, f
     }
 }
 
+// ... and the same launch also stores the token's K (rotated) and V rows into the half-precision caches (kv_store_kernel's conversions of the same
+// values: identical cache rows); q is rotated in place, k and v are only read.  One launch instead of two per prompt layer.
+__global__ __launch_bounds__(256) void rope_kv_store_rows_kernel(float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                                 const int* __restrict__ positions, int n_heads, int n_kv_heads, int head_dim, float theta,
+                                                                 float fscale, int interleaved, uint16_t* __restrict__ kc, uint16_t* __restrict__ vc,
+                                                                 int start_pos, int max_seq) {
+    __shared__ float cs[2][128];
+    const int sp = blockIdx.x, half_dim = head_dim / 2;
+    const int pos = positions[sp];
+    for (int i = threadIdx.x; i < half_dim; i += blockDim.x) {
+        const float freq = 1.0f / (float)pow((double)theta, (double)((2.0f * i) / head_dim));
+        const float angle = pos * freq * fscale;
+        cs[0][i] = cosf(angle);
+        cs[1][i] = sinf(angle);
+    }
+    __syncthreads();
+    const int cp = start_pos + sp, per_pos = n_kv_heads * head_dim;
+    const bool store = cp < max_seq;   // reference attention.cu:336
+    const int total = (n_heads + n_kv_heads) * half_dim;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const int pair = idx % half_dim, head = idx / half_dim;
+        const int i0 = interleaved ? 2 * pair : pair, i1 = interleaved ? 2 * pair + 1 : pair + half_dim;
+        const float c = cs[0][pair], sn = cs[1][pair];
+        if (head < n_heads) {
+            float* data = q + ((size_t)sp * n_heads + head) * head_dim;
+            const float a = data[i0], b = data[i1];
+            rope_rotate(a, b, c, sn, data[i0], data[i1]);
+        } else {
+            const int kh = head - n_heads;
+            const float* data = k + ((size_t)sp * n_kv_heads + kh) * head_dim;
+            float ra, rb;
+            rope_rotate(data[i0], data[i1], c, sn, ra, rb);
+            if (store) {
+                uint16_t* row = kc + (size_t)cp * per_pos + (size_t)kh * head_dim;
+                row[i0] = f2h(ra);
+                row[i1] = f2h(rb);
+            }
+        }
+    }
+    if (store)
+        for (int e = threadIdx.x; e < per_pos; e += blockDim.x) vc[(size_t)cp * per_pos + e] = f2h(v[(size_t)sp * per_pos + e]);
+}
+
 __global__ void kv_store_kernel(uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, const float* __restrict__ k,
                                 const float* __restrict__ v, int total, int per_pos, int start_pos, int max_seq) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -803,6 +846,16 @@ int ntk_rope(float* q, float* k, const int* positions, int /*batch_size*/, int s
     else
         hipLaunchKernelGGL(ntk::rope_kernel, dim3((total + 255) / 256), dim3(256), 0, ntk::resolve_stream(stream), q, k,
                            positions, seq_len, n_heads, n_kv_heads, head_dim, theta_base, freq_scale, interleaved);
+    return ntk::last_launch_status();
+}
+
+int ntk_rope_kv_store(float* q, const float* k, const float* v, const int* positions, int seq_len, int n_heads, int n_kv_heads, int head_dim,
+                      float theta_base, float freq_scale, int interleaved, void* k_cache, void* v_cache, int start_pos, int max_seq, void* stream) {
+    if (!q || !k || !v || !positions || !k_cache || !v_cache) return NTK_E_NULL;
+    if (seq_len < 0 || n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0 || (head_dim & 1) || head_dim > 256 || start_pos < 0 || max_seq <= 0) return NTK_E_SHAPE;
+    if (seq_len == 0) return NTK_OK;
+    hipLaunchKernelGGL(ntk::rope_kv_store_rows_kernel, dim3(seq_len), dim3(256), 0, ntk::resolve_stream(stream), q, k, v, positions, n_heads, n_kv_heads,
+                       head_dim, theta_base, freq_scale, interleaved, static_cast<uint16_t*>(k_cache), static_cast<uint16_t*>(v_cache), start_pos, max_seq);
     return ntk::last_launch_status();
 }
 

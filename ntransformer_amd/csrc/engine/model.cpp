@@ -672,34 +672,75 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
         if (with_max) ok(ntk_rmsnorm_rowmax(residual_, hidden_, (const float*)nw.ptr, T, H, cfg_.norm_eps, rm_a, zero_b ? rm_b : nullptr, s));
         else ok(ntk_rmsnorm(residual_, hidden_, (const float*)nw.ptr, T, H, cfg_.norm_eps, s));
     };
+    // hidden += W . X followed by the NEXT RMSNorm (nw; into residual_, with the token maxima) as one consumer launch of the projection's K splits
+    // (ntk_gemm_quant_ws_deferred + ntk_reduce_rmsnorm_rowmax); false = not this shape / format: the caller runs project_add + norm
+    auto project_add_norm = [&](const DevTensor& w, const float* X, const float* rm, const DevTensor& nw, bool zero_b) -> bool {
+        if (!with_max || tp_world_ > 1 || !is_quant(w.dtype) || (size_t)w.out_f != (size_t)H) return false;
+        raw_begin();
+        const void* wp = raw_of(w);
+        ntk_gemm_partials pt;
+        // (Y, used when the launch does not split K: residual_ -- the previous RMSNorm's output, consumed by the projections before this one)
+        int st = ntk_gemm_quant_ws_deferred(residual_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, gemm_ws_, gemm_ws_bytes_, 0, rm, &pt, s);
+        if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN) return false;   // (nothing was launched)
+        planes_of = nullptr;
+        if (st == NTK_OK) st = ntk_reduce_rmsnorm_rowmax(hidden_, &pt, (const float*)nw.ptr, cfg_.norm_eps, residual_, rm_a, zero_b ? rm_b : nullptr, s);
+        ok(st);
+        return true;
+    };
+    bool normed_ahead = false;   // residual_ / rm_a already hold this layer's normalised input (written with the previous layer's down projection)
     for (int i = first; i < last_layer; ++i) {
         const LayerWeights& L = layers_[i];
         uint16_t* kc = k_cache_ + (size_t)i * kv_layer;
         uint16_t* vc = v_cache_ + (size_t)i * kv_layer;
-        norm(L.attn_norm, true);
+        if (!normed_ahead) norm(L.attn_norm, true);
+        normed_ahead = false;
         planes_of = nullptr;   // residual_ has new contents
         {
             float* const ys[3] = {q_buf, k_buf, v_buf};
             const DevTensor* const ws[3] = {&L.wq, &L.wk, &L.wv};
             project_many(ys, ws, 3, residual_, rm_a);
         }
-        ok(ntk_rope(q_buf, k_buf, positions_, 1, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, s));
-        ok(ntk_copy_to_kv_cache(kc, vc, k_buf, v_buf, T, nkv, hd, start_pos, cfg_.max_seq_len, s));
+        if (with_max && T >= 4 && hd <= 256) {   // (the prompt form of the rotation: ntk_rope takes it from 4 tokens on, too)
+            ok(ntk_rope_kv_store(q_buf, k_buf, v_buf, positions_, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, kc, vc,
+                                 start_pos, cfg_.max_seq_len, s));
+        } else {
+            ok(ntk_rope(q_buf, k_buf, positions_, 1, T, nh, nkv, hd, cfg_.rope_theta, cfg_.rope_freq_scale, cfg_.rope_interleaved, s));
+            ok(ntk_copy_to_kv_cache(kc, vc, k_buf, v_buf, T, nkv, hd, start_pos, cfg_.max_seq_len, s));
+        }
         if (T == 1) ok(ntk_attention_decode(attn_out, q_buf, kc, vc, start_pos + T, nh, nkv, hd, cfg_.max_seq_len, scale, s));
         else ok(ntk_attention_prefill(attn_out, q_buf, kc, vc, T, start_pos, nh, nkv, hd, cfg_.max_seq_len, scale, s));
-        project_add(L.wo, attn_out, qd, nullptr);
-        norm(L.ffn_norm, false);
+        if (!project_add_norm(L.wo, attn_out, nullptr, L.ffn_norm, false)) {
+            project_add(L.wo, attn_out, qd, nullptr);
+            norm(L.ffn_norm, false);
+        }
         planes_of = nullptr;
-        {
+        // gate | up and SiLU x up (per token in the reference, ffn.cpp:127: the same elementwise op): with the token maxima, the gate | up launch's K
+        // splits are summed by the SiLU launch itself (ntk_gemm_quant_ws_multi_deferred + ntk_reduce_silu_mul_rowmax)
+        bool ffn_done = false;
+        if (with_max && rm_b && tp_world_ == 1 && L.w_gate.dtype == L.w_up.dtype && is_quant(L.w_gate.dtype) && L.w_gate.in_f == L.w_up.in_f &&
+            (size_t)L.w_gate.out_f == (size_t)I && (size_t)L.w_up.out_f == (size_t)I && I % 4 == 0) {
+            raw_begin();
+            ntk_gemv_seg segs[2] = {{raw_of(L.w_gate), gate_buf, (int)I, L.w_gate.dtype}, {raw_of(L.w_up), up_buf, (int)I, L.w_up.dtype}};
+            ntk_gemm_partials pt;
+            int st = ntk_gemm_quant_ws_multi_deferred(segs, 2, residual_, T, (int)L.w_gate.in_f, gemm_ws_, gemm_ws_bytes_, 0, rm_a, &pt, s);
+            if (st != NTK_E_DTYPE && st != NTK_E_SHAPE && st != NTK_E_ALIGN) {   // (those three: nothing was launched)
+                if (st == NTK_OK) st = ntk_reduce_silu_mul_rowmax(gate_buf, &pt, rm_b, s);
+                ok(st);
+                ffn_done = true;
+            }
+        }
+        if (!ffn_done) {
             float* const ys[2] = {gate_buf, up_buf};
             const DevTensor* const ws[2] = {&L.w_gate, &L.w_up};
             project_many(ys, ws, 2, residual_, rm_a);
+            int st_silu = with_max && rm_b ? ntk_silu_mul_rowmax(gate_buf, gate_buf, up_buf, T, I, rm_b, s) : NTK_E_SHAPE;
+            if (st_silu == NTK_E_SHAPE || st_silu == NTK_E_ALIGN) { st_silu = ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s); rm_b = nullptr; }   // (then for the rest of the pass)
+            ok(st_silu);
         }
-        // per token in the reference (ffn.cpp:127): same elementwise op
-        int st_silu = with_max ? ntk_silu_mul_rowmax(gate_buf, gate_buf, up_buf, T, I, rm_b, s) : NTK_E_SHAPE;
-        if (st_silu == NTK_E_SHAPE || st_silu == NTK_E_ALIGN) { st_silu = ntk_silu_mul(gate_buf, gate_buf, up_buf, T * I, s); rm_b = nullptr; }   // (then for the rest of the pass)
-        ok(st_silu);
-        project_add(L.w_down, gate_buf, I, rm_b);
+        planes_of = nullptr;
+        // down projection + residual, and the NEXT layer's first RMSNorm in the same consumer launch when there is a next layer in this pass
+        if (i + 1 < last_layer && project_add_norm(L.w_down, gate_buf, rm_b, layers_[i + 1].attn_norm, true)) normed_ahead = true;
+        else project_add(L.w_down, gate_buf, I, rm_b);
         if (rc != NTK_OK) break;
     }
     return rc;

@@ -978,6 +978,89 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const ReduceArgs a) 
     *reinterpret_cast<float4*>(Y + idx) = v;
 }
 
+// ---- the K splits' sums folded into the launch that consumes the projection (the reduce launch deferred: ntk_gemm_partials) ---------
+// hidden[t] = (part[0][t] + part[1][t] + ...) + hidden[t]   (reduce_splits_kernel's order, the residual last), then RMSNorm of the new row into
+// x_out + the row's largest |x| (rmsnorm_rowmax_kernel's expressions, sums and block size: identical bits).  One workgroup per token.
+__global__ __launch_bounds__(1024) void reduce_rmsnorm_rowmax_kernel(float* __restrict__ hidden, const float* __restrict__ part, int nsplit, int T, int H,
+                                                                     const float* __restrict__ weight, float eps, float* __restrict__ x_out,
+                                                                     float* __restrict__ row_max, float* __restrict__ zero) {
+    __shared__ float red[16];
+    const size_t row = (size_t)blockIdx.x * H, plane = (size_t)T * H;
+    float* h = hidden + row;
+    const int bd = (int)blockDim.x, tid = (int)threadIdx.x;
+    float ssq = 0.0f;
+    // the thread's elements tid, tid + bd, ... (rmsnorm_kernel's assignment and accumulation order), eight at a time, the splits four at a time:
+    // 32 independent loads in flight, the additions in split order (a rolled loop over the splits is one dependent load per addition:
+    // 20 us per launch at 64 tokens x 8 splits, profiles/r05_prefill_row_max_ab.txt)
+    for (int i0 = tid; i0 < H; i0 += 8 * bd) {
+        int idx[8];
+        float v[8], r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx[k] = min(i0 + k * bd, H - 1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = part[row + idx[k]]; r[k] = h[idx[k]]; }
+        for (int sp = 1; sp < nsplit; sp += 4) {
+            float q[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const size_t at = (size_t)min(sp + j, nsplit - 1) * plane + row;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) q[j][k] = part[at + idx[k]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sp + j < nsplit) {   // (uniform)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += q[j][k];
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k * bd < H) {
+                const float y = v[k] + r[k];
+                h[i0 + k * bd] = y;
+                ssq = fmaf(y, y, ssq);
+            }
+    }
+    const float tot = block_sum(ssq, red);
+    const float rms_inv = 1.0f / sqrtf(tot / (float)H + eps);
+    uint32_t mb = 0;
+    for (int i = tid; i < H; i += bd) {   // (h[i]: this thread's own stores)
+        const float v = h[i] * rms_inv * weight[i];
+        x_out[row + i] = v;
+        mb = max(mb, __float_as_uint(v) & 0x7FFFFFFFu);
+    }
+    const float m = block_max(__uint_as_float(mb <= 0x7F800000u ? mb : 0x7F800000u), red);
+    if (tid == 0) {
+        row_max[blockIdx.x] = m;
+        if (zero) zero[blockIdx.x] = 0.0f;
+    }
+}
+// out = silu(sum of gate's splits) * (sum of up's splits) + max |out| per token (silu_mul_rowmax_kernel's expressions).  grid (ceil(I / 1024), T)
+__global__ __launch_bounds__(256) void reduce_silu_mul_rowmax_kernel(float* __restrict__ out, const float* __restrict__ pg, const float* __restrict__ pu,
+                                                                     int nsplit, int T, int I, float* __restrict__ row_max) {
+    __shared__ float red[16];
+    const int t = blockIdx.y, i = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    uint32_t mb = 0;
+    if (i < I) {
+        const size_t at = (size_t)t * I + i, plane = (size_t)T * I;
+        float4 g = *reinterpret_cast<const float4*>(pg + at), u = *reinterpret_cast<const float4*>(pu + at);
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const float4 a = *reinterpret_cast<const float4*>(pg + (size_t)sp * plane + at), b = *reinterpret_cast<const float4*>(pu + (size_t)sp * plane + at);
+            g.x += a.x; g.y += a.y; g.z += a.z; g.w += a.w;
+            u.x += b.x; u.y += b.y; u.z += b.z; u.w += b.w;
+        }
+        float4 o;
+        o.x = g.x / (1.0f + expf(-g.x)) * u.x; o.y = g.y / (1.0f + expf(-g.y)) * u.y;
+        o.z = g.z / (1.0f + expf(-g.z)) * u.z; o.w = g.w / (1.0f + expf(-g.w)) * u.w;
+        *reinterpret_cast<float4*>(out + at) = o;
+        mb = max(max(__float_as_uint(o.x) & 0x7FFFFFFFu, __float_as_uint(o.y) & 0x7FFFFFFFu),
+                 max(__float_as_uint(o.z) & 0x7FFFFFFFu, __float_as_uint(o.w) & 0x7FFFFFFFu));
+    }
+    const float m = block_max(__uint_as_float(mb <= 0x7F800000u ? mb : 0x7F800000u), red);
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(row_max) + t, __float_as_uint(m));
+}
+
 // one chunk's planes + sums (+ the record of zeros), rounded to 256 B
 // (the sums: whole units of 8 steps covering steps 0 .. in/32 + 7 -- the pre-pass writes a full unit of zeros behind the last step)
 static size_t ws_chunk_bytes(int in) { return ((size_t)(in / 32 + 1) * GB_STEP_BYTES + (size_t)((in / 32 + 15) / 8) * GB_MIN_UNIT_BYTES + 255) / 256 * 256; }
@@ -989,7 +1072,7 @@ struct HostSeg { float* Y; const void* W; int out; };
 // T <= GB_MAX_CHUNKS * 64 = 1024 tokens in one launch; nseg matrices [out_s][in] of one format sharing X
 template <int DT>
 static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T, int in, const float* resid, void* ws, int reuse_x,
-                            const float* row_max, hipStream_t st) {
+                            const float* row_max, ntk_gemm_partials* defer, hipStream_t st) {
     using D = DeqI<DT>;
     constexpr int TRIP = GB_UPT * D::SPU;   // steps per loop trip: K ranges are whole trips
     // whole units only (Q8_0: in a multiple of 128, Q4_0 and the K-quants: of 256): a partial last unit would decode the next row's bytes as
@@ -1104,6 +1187,11 @@ static int launch_gemm_f16(const HostSeg* segs, int nseg, const float* X, int T,
         if (rt == 2) hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 2, false, PFD, 1>), grid, dim3(256), lds2, st, p);
         else hipLaunchKernelGGL((gemm_quant_f16_kernel<DT, 1, false, PFD, 1>), grid, dim3(256), lds1, st, p);
     }
+    if (defer) {   // the caller's next launch sums the splits (and adds the residual) itself
+        defer->nseg = nseg; defer->n_tokens = T; defer->nsplit = nsplit;
+        for (int i = 0; i < nseg; ++i) { defer->part[i] = nsplit > 1 ? p.seg[i].part : nullptr; defer->y[i] = segs[i].Y; defer->rows[i] = segs[i].out; }
+        if (nsplit > 1) return last_launch_status();
+    }
     if (nsplit > 1) {
         ReduceArgs ra{};
         ra.nseg = nseg; ra.T = T; ra.nsplit = nsplit; ra.resid = resid;
@@ -1137,9 +1225,14 @@ size_t ntk_gemm_quant_workspace_bytes(int in_features, int out_features) {
 }
 
 static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, int n_tokens, int in_features, int weight_dtype, const float* resid,
-                            void* workspace, int reuse_x, const float* row_max, hipStream_t st) {
+                            void* workspace, int reuse_x, const float* row_max, ntk_gemm_partials* defer, hipStream_t st) {
     constexpr int PASS = ntk::GB_MAX_CHUNKS * ntk::GB_TOK;
     if (n_tokens > PASS) reuse_x = 0;   // the planes hold one pass (1024 tokens) at a time
+    if (defer) {
+        defer->nseg = nseg; defer->n_tokens = n_tokens; defer->nsplit = 1;   // (more than one pass: each pass reduces itself, nothing is deferred)
+        for (int i = 0; i < nseg; ++i) { defer->part[i] = nullptr; defer->y[i] = segs[i].Y; defer->rows[i] = segs[i].out; }
+        if (n_tokens > PASS) defer = nullptr;
+    }
     for (int t0 = 0; t0 < n_tokens; t0 += PASS) {   // up to 16 x 64 tokens per launch: the chunks share the weights in L2
         const int T = std::min(PASS, n_tokens - t0);
         ntk::HostSeg sg[ntk::GB_MAX_SEG];
@@ -1149,11 +1242,11 @@ static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, 
         const float* rm = row_max ? row_max + t0 : nullptr;
         int rc;
         switch (weight_dtype) {
-            case NTK_DT_Q8_0: rc = ntk::launch_gemm_f16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
-            case NTK_DT_Q4_0: rc = ntk::launch_gemm_f16<NTK_DT_Q4_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
-            case NTK_DT_Q4_K: rc = ntk::launch_gemm_f16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
-            case NTK_DT_Q5_K: rc = ntk::launch_gemm_f16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
-            default: rc = ntk::launch_gemm_f16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, st); break;
+            case NTK_DT_Q8_0: rc = ntk::launch_gemm_f16<NTK_DT_Q8_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, defer, st); break;
+            case NTK_DT_Q4_0: rc = ntk::launch_gemm_f16<NTK_DT_Q4_0>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, defer, st); break;
+            case NTK_DT_Q4_K: rc = ntk::launch_gemm_f16<NTK_DT_Q4_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, defer, st); break;
+            case NTK_DT_Q5_K: rc = ntk::launch_gemm_f16<NTK_DT_Q5_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, defer, st); break;
+            default: rc = ntk::launch_gemm_f16<NTK_DT_Q6_K>(sg, nseg, x, T, in_features, rs, workspace, reuse_x, rm, defer, st); break;
         }
         if (rc != NTK_OK) return rc;
     }
@@ -1161,28 +1254,35 @@ static int gemm_ws_dispatch(const ntk::HostSeg* segs, int nseg, const float* X, 
 }
 
 static int gemm_quant_ws_impl(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
-                              const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
+                              const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* defer,
+                              void* stream) {
     if (!Y || !W || !X || !workspace) return NTK_E_NULL;
     if (n_tokens < 0 || out_features < 0 || in_features <= 0) return NTK_E_SHAPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, out_features) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
     if (weight_dtype != NTK_DT_Q8_0 && weight_dtype != NTK_DT_Q4_0 && weight_dtype != NTK_DT_Q4_K && weight_dtype != NTK_DT_Q5_K && weight_dtype != NTK_DT_Q6_K) return NTK_E_DTYPE;
+    if (defer) { defer->nseg = 1; defer->n_tokens = n_tokens; defer->nsplit = 1; defer->part[0] = nullptr; defer->y[0] = Y; defer->rows[0] = out_features; }
     if (n_tokens == 0 || out_features == 0) return NTK_OK;
     const ntk::HostSeg sg{Y, W, out_features};
-    return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, row_max, ntk::resolve_stream(stream));
+    return gemm_ws_dispatch(&sg, 1, X, n_tokens, in_features, weight_dtype, resid, workspace, reuse_x, row_max, defer, ntk::resolve_stream(stream));
 }
 int ntk_gemm_quant_ws(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
                       const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, void* stream) {
-    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, nullptr, stream);
+    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, nullptr, nullptr, stream);
 }
 int ntk_gemm_quant_ws_rm(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
                          const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
-    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, row_max, stream);
+    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, row_max, nullptr, stream);
+}
+int ntk_gemm_quant_ws_deferred(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype, void* workspace,
+                               size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials, void* stream) {
+    if (!partials) return NTK_E_NULL;
+    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, nullptr, workspace, workspace_bytes, reuse_x, row_max, partials, stream);
 }
 
 // several matrices of one format sharing X (Q | K | V, gate | up) in ONE launch: segs[i] = {Y_i [n_tokens][rows_i], W_i, rows_i}
 // (ntk_gemv_seg: y, W, rows, dtype -- the dtypes must agree).  workspace: ntk_gemm_quant_workspace_bytes(in, sum of rows).
 static int gemm_quant_ws_multi_impl(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
-                                    size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
+                                    size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* defer, void* stream) {
     if (!segs || !X || !workspace) return NTK_E_NULL;
     if (nseg < 1 || nseg > ntk::GB_MAX_SEG || n_tokens < 0 || in_features <= 0) return NTK_E_SHAPE;
     ntk::HostSeg sg[ntk::GB_MAX_SEG];
@@ -1196,16 +1296,58 @@ static int gemm_quant_ws_multi_impl(const ntk_gemv_seg* segs, int nseg, const fl
     const int dt = segs[0].dtype;
     if (dt != NTK_DT_Q8_0 && dt != NTK_DT_Q4_0 && dt != NTK_DT_Q4_K && dt != NTK_DT_Q5_K && dt != NTK_DT_Q6_K) return NTK_E_DTYPE;
     if (workspace_bytes < ntk_gemm_quant_workspace_bytes(in_features, (int)total) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return NTK_E_SHAPE;
+    if (defer) { defer->nseg = nseg; defer->n_tokens = n_tokens; defer->nsplit = 1; for (int i = 0; i < nseg; ++i) { defer->part[i] = nullptr; defer->y[i] = sg[i].Y; defer->rows[i] = sg[i].out; } }
     if (n_tokens == 0) return NTK_OK;
-    return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, row_max, ntk::resolve_stream(stream));
+    return gemm_ws_dispatch(sg, nseg, X, n_tokens, in_features, dt, nullptr, workspace, reuse_x, row_max, defer, ntk::resolve_stream(stream));
 }
 int ntk_gemm_quant_ws_multi(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
                             size_t workspace_bytes, int reuse_x, void* stream) {
-    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, nullptr, stream);
+    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, nullptr, nullptr, stream);
 }
 int ntk_gemm_quant_ws_multi_rm(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
                                size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
-    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, row_max, stream);
+    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, row_max, nullptr, stream);
+}
+int ntk_gemm_quant_ws_multi_deferred(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
+                                     size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials, void* stream) {
+    if (!partials) return NTK_E_NULL;
+    return gemm_quant_ws_multi_impl(segs, nseg, X, n_tokens, in_features, workspace, workspace_bytes, reuse_x, row_max, partials, stream);
+}
+
+// hidden[t] += W . X[t] (the projection's splits summed here, residual last) and x_out[t] = rmsnorm(hidden[t]) with its largest |x|
+int ntk_reduce_rmsnorm_rowmax(float* hidden, const ntk_gemm_partials* p, const float* weight, float eps, float* x_out, float* row_max,
+                              float* zero_tokens, void* stream) {
+    if (!hidden || !p || !weight || !x_out || !row_max) return NTK_E_NULL;
+    if (p->nseg != 1 || p->n_tokens < 0 || p->rows[0] <= 0 || p->nsplit < 1) return NTK_E_SHAPE;
+    if (p->n_tokens == 0) return NTK_OK;
+    const int T = p->n_tokens, H = p->rows[0];
+    hipStream_t st = ntk::resolve_stream(stream);
+    const dim3 block(H <= 1024 ? 256 : (H <= 4096 ? 512 : 1024));
+    if (p->nsplit == 1 || !p->part[0]) {   // the projection wrote Y = W . X itself (p->y[0]; no residual in a deferred launch): hidden += Y first
+        if (p->y[0] != hidden) {
+            const size_t n4 = ((size_t)T * H + 3) / 4;
+            if (((size_t)T * H) % 4 != 0 || (reinterpret_cast<uintptr_t>(hidden) & 15) || (reinterpret_cast<uintptr_t>(p->y[0]) & 15)) return NTK_E_ALIGN;
+            ntk::ReduceArgs ra{};
+            ra.nseg = 1; ra.T = T; ra.nsplit = 1; ra.resid = hidden; ra.Y[0] = hidden; ra.part[0] = p->y[0]; ra.out[0] = H;
+            hipLaunchKernelGGL(ntk::reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, st, ra);
+        }
+        hipLaunchKernelGGL(ntk::rmsnorm_rowmax_kernel, dim3(T), block, 0, st, x_out, hidden, weight, H, eps, row_max, zero_tokens);
+        return ntk::last_launch_status();
+    }
+    hipLaunchKernelGGL(ntk::reduce_rmsnorm_rowmax_kernel, dim3(T), block, 0, st, hidden, p->part[0], p->nsplit, T, H, weight, eps, x_out, row_max, zero_tokens);
+    return ntk::last_launch_status();
+}
+// out[t] = silu(gate[t]) * up[t] of a deferred gate | up launch (p: two matrices of equal height) with the tokens' largest |out|
+int ntk_reduce_silu_mul_rowmax(float* output, const ntk_gemm_partials* p, float* row_max, void* stream) {
+    if (!output || !p || !row_max) return NTK_E_NULL;
+    if (p->nseg != 2 || p->rows[0] != p->rows[1] || p->rows[0] <= 0 || p->rows[0] % 4 != 0 || p->n_tokens < 0 || p->nsplit < 1) return NTK_E_SHAPE;
+    if (p->n_tokens == 0) return NTK_OK;
+    const int T = p->n_tokens, I = p->rows[0];
+    if (p->nsplit == 1 || !p->part[0] || !p->part[1]) return ntk_silu_mul_rowmax(output, p->y[0], p->y[1], T, I, row_max, stream);
+    if (reinterpret_cast<uintptr_t>(output) & 15) return NTK_E_ALIGN;
+    hipLaunchKernelGGL(ntk::reduce_silu_mul_rowmax_kernel, dim3((I + 1023) / 1024, T), dim3(256), 0, ntk::resolve_stream(stream), output, p->part[0], p->part[1],
+                       p->nsplit, T, I, row_max);
+    return ntk::last_launch_status();
 }
 
 int ntk_rmsnorm_rowmax(float* output, const float* input, const float* weight, int n_tokens, int hidden_size, float eps, float* row_max,

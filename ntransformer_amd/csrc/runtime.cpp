@@ -168,8 +168,11 @@ void* nt_hip_malloc(size_t size) {
 void nt_hip_free(void* p) { if (p) (void)hipFree(p); }
 void nt_hip_memcpy_h2d(void* d, const void* s, size_t n) { if (n) (void)hipMemcpy(d, s, n, hipMemcpyHostToDevice); }
 void nt_hip_memcpy_d2h(void* d, const void* s, size_t n) { if (n) (void)hipMemcpy(d, s, n, hipMemcpyDeviceToHost); }
-void nt_hip_memcpy_d2d(void* d, const void* s, size_t n) { if (n) (void)hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
-void nt_hip_memset(void* p, int v, size_t n) { if (n) (void)hipMemset(p, v, n); }
+// Device-to-device copies and fills run on the legacy stream and may return before they have executed; the library's own streams are NON-blocking
+// (not ordered against the legacy stream), so a kernel launched right afterwards could otherwise run BEFORE the fill (seen: a test buffer zeroed over
+// the results a launch had just written).  Both therefore wait for the legacy stream: "blocking, like the reference".
+void nt_hip_memcpy_d2d(void* d, const void* s, size_t n) { if (n) { (void)hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); (void)hipStreamSynchronize(nullptr); } }
+void nt_hip_memset(void* p, int v, size_t n) { if (n) { (void)hipMemset(p, v, n); (void)hipStreamSynchronize(nullptr); } }
 void* nt_hip_malloc_host(size_t size) {
     if (ensure_ready() != NTK_OK) return nullptr;
     void* p = nullptr;

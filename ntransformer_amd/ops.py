@@ -215,7 +215,9 @@ def gemm_quant_ws_multi(segs, X, n_tokens, in_features, stream=None):
     for i, (W, y, rows, dt) in enumerate(segs):
         arr[i].W, arr[i].y, arr[i].rows, arr[i].dtype = _p(W), _p(y), rows, int(dt)
     L.ntk_gemm_quant_ws_multi.argtypes = [C.POINTER(GemvSeg), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    return L.ntk_gemm_quant_ws_multi(arr, len(segs), _p(X), n_tokens, in_features, ws.ptr, n, 0, stream)
+    st = L.ntk_gemm_quant_ws_multi(arr, len(segs), _p(X), n_tokens, in_features, ws.ptr, n, 0, stream)
+    synchronize()   # `ws` is released when this returns
+    return st
 
 
 def gemm_quant_ws(Y, W, X, n_tokens, out_features, in_features, dtype, resid=None, stream=None):
@@ -242,6 +244,42 @@ def gemm_quant_ws_rm(Y, W, X, n_tokens, out_features, in_features, dtype, row_ma
     st = L.ntk_gemm_quant_ws_rm(_p(Y), _p(W), _p(X), n_tokens, out_features, in_features, int(dtype), _p(resid), _p(ws), n, 0, _p(row_max), stream)
     synchronize()
     return st
+
+
+def gemm_deferred_then_consumer(kind, W, X, n_tokens, rows, in_features, dtype, row_max=None, **kw):
+    """The prompt projections with their split-K sums folded into the consuming launch (include/ntk.h: ntk_gemm_partials).
+    kind "norm": ntk_gemm_quant_ws_deferred (W: one matrix [rows][in]) + ntk_reduce_rmsnorm_rowmax(kw: hidden, weight, eps, x_out, row_max_out, zero);
+    kind "silu": ntk_gemm_quant_ws_multi_deferred (W: (gate, up)) + ntk_reduce_silu_mul_rowmax(kw: output, row_max_out).  Returns the launch's nsplit."""
+    L = _lib.lib()
+    L.ntk_gemm_quant_workspace_bytes.restype = C.c_size_t
+    pt = _lib.GemmPartials()
+    if kind == "norm":
+        n = int(L.ntk_gemm_quant_workspace_bytes(C.c_int(in_features), C.c_int(rows)))
+        ws, y = DeviceBuffer(n), DeviceBuffer(n_tokens * rows * 4)
+        L.ntk_gemm_quant_ws_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
+                                                 C.c_void_p, C.POINTER(_lib.GemmPartials), C.c_void_p]
+        check(L.ntk_gemm_quant_ws_deferred(y.ptr, _p(W), _p(X), n_tokens, rows, in_features, int(dtype), ws.ptr, n, 0, _p(row_max), C.byref(pt), None), "gemm deferred")
+        L.ntk_reduce_rmsnorm_rowmax.argtypes = [C.c_void_p, C.POINTER(_lib.GemmPartials), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        check(L.ntk_reduce_rmsnorm_rowmax(_p(kw["hidden"]), C.byref(pt), _p(kw["weight"]), kw["eps"], _p(kw["x_out"]), _p(kw["row_max_out"]), _p(kw.get("zero")), None),
+              "reduce_rmsnorm_rowmax")
+    else:
+        n = int(L.ntk_gemm_quant_workspace_bytes(C.c_int(in_features), C.c_int(2 * rows)))
+        ws, yg, yu = DeviceBuffer(n), DeviceBuffer(n_tokens * rows * 4), DeviceBuffer(n_tokens * rows * 4)
+        arr = (GemvSeg * 2)()
+        for i, (w, y) in enumerate(((W[0], yg), (W[1], yu))):
+            arr[i].W, arr[i].y, arr[i].rows, arr[i].dtype = _p(w), y.ptr, rows, int(dtype)
+        L.ntk_gemm_quant_ws_multi_deferred.argtypes = [C.POINTER(GemvSeg), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                                       C.POINTER(_lib.GemmPartials), C.c_void_p]
+        check(L.ntk_gemm_quant_ws_multi_deferred(arr, 2, _p(X), n_tokens, in_features, ws.ptr, n, 0, _p(row_max), C.byref(pt), None), "gemm multi deferred")
+        L.ntk_reduce_silu_mul_rowmax.argtypes = [C.c_void_p, C.POINTER(_lib.GemmPartials), C.c_void_p, C.c_void_p]
+        check(L.ntk_reduce_silu_mul_rowmax(_p(kw["output"]), C.byref(pt), _p(kw["row_max_out"]), None), "reduce_silu_mul_rowmax")
+    synchronize()
+    return int(pt.nsplit)
+
+
+def rope_kv_store(q, k, v, positions, seq_len, n_heads, n_kv_heads, head_dim, theta_base, freq_scale, interleaved, k_cache, v_cache, start_pos, max_seq):
+    check(_lib.lib().ntk_rope_kv_store(_p(q), _p(k), _p(v), _p(positions), seq_len, n_heads, n_kv_heads, head_dim, theta_base, freq_scale,
+                                       int(bool(interleaved)), _p(k_cache), _p(v_cache), start_pos, max_seq, None), "rope_kv_store")
 
 
 def launch_rmsnorm_rowmax(output, input, weight, n_tokens, hidden_size, eps, row_max, zero_tokens=None, stream=None):

@@ -168,6 +168,35 @@ def test_batched_prefill_fills_the_same_kv_cache(mix, tmp_path):
     assert np.abs(outs[1] - outs[0]).max() <= TOL, np.abs(outs[1] - outs[0]).max()
 
 
+@pytest.mark.parametrize("name,shape,mix", [("tiny_q8_0", "TINY", "Q8_0"), ("small_q8_0", "SMALL", "Q8_0"), ("small_q4_k_m", "SMALL", "Q4_K_M")])
+def test_prompt_pass_with_folded_launches_gives_the_same_bits(name, shape, mix, tmp_path):
+    """The prompt pass with its small launches folded ("prefill_row_max" = 1, the default: RMSNorm / SiLU leave the token maxima for the FP16 GEMM's
+    pre-pass, the Wo / down / gate | up launches' K splits are summed by the RMSNorm / SiLU launch that consumes them, RoPE and the cache store are
+    one launch) against the separate launches ("prefill_row_max" = 0, the path the golden-logit tests pin to the reference's host code): prompts of 40,
+    200 and 700 tokens, the logits after the prompt and after six more decoded tokens (which read every cache row the prompt wrote) equal BIT FOR BIT."""
+    path, z = golden_model(name, getattr(G, shape), mix, tmp_path)
+    ctx = int(z["ctx"])
+    r = np.random.Generator(np.random.Philox(key=[20260929, len(name)]))
+    for n in (40, 200, 700):
+        if n + 8 > ctx: continue
+        prompt = [int(z["prompt"][0])] + [int(t) for t in r.integers(0, 256, n - 1)]
+        cont = [int(t) for t in r.integers(0, 256, 6)]
+        outs = []
+        for folded in (0, 1):
+            eng = E.Engine()
+            eng.load(path, ctx)
+            eng.set_option("prefill_row_max", folded)
+            lg = [eng.forward(prompt, 0)]
+            pos = len(prompt)
+            for t in cont:
+                lg.append(eng.decode_fused(t, pos, False))
+                pos += 1
+            eng.close()
+            outs.append(np.stack(lg))
+        assert np.isfinite(outs[0]).all()
+        assert np.array_equal(outs[0], outs[1]), (name, n, float(np.abs(outs[0] - outs[1]).max()))
+
+
 def test_long_context_decode_uses_split_attention_and_matches_the_oracle(tmp_path):
     """Decode at positions 540..550 crosses the engine's attention regimes (single pass -> 8 KV splits at 544,
     Model::attention_regime), 668..678 and 1020..1030 run inside the split regime.  Every mode -- the reference's 1:1 launcher

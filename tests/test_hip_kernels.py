@@ -189,6 +189,77 @@ def test_gemm_quant_f16_with_row_maxima_from_the_producers(qname, T, out_f, in_f
     assert np.array_equal(y1.numpy(np.float32), y2.numpy(np.float32))
 
 
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_K"])
+@pytest.mark.parametrize("T,rows,in_f", [(64, 1024, 2048), (40, 512, 4096), (5, 64, 512), (200, 256, 1024), (1100, 64, 256)])
+def test_gemm_quant_f16_split_sums_folded_into_the_consuming_launch(qname, T, rows, in_f):
+    """A prompt projection's K splits summed by the launch that consumes it instead of a reduce launch (ntk_gemm_partials): Wo / down + residual +
+    the next RMSNorm (ntk_gemm_quant_ws_deferred + ntk_reduce_rmsnorm_rowmax) and gate | up + SiLU x up (ntk_gemm_quant_ws_multi_deferred +
+    ntk_reduce_silu_mul_rowmax), against the separate launches the tests around pin to the oracle: hidden, the normalised / activated rows and the
+    token maxima equal BIT FOR BIT, whether the launch split K (nsplit > 1: the small-token shapes here) or not (nsplit = 1, and more than 1024
+    tokens: each pass reduces itself)."""
+    gt = QUANT[qname]
+    dt = G.GGML_TO_DT[gt]
+    r = rng(T * 13 + rows + in_f + gt)
+    eps = 1e-5
+    X = r.standard_normal((T, in_f)).astype(np.float32)
+    Xd = DB.from_numpy(X)
+    # (a) hidden += W . X, then RMSNorm of the new hidden
+    W = DB.from_numpy(np.frombuffer(G.synth_tensor(r, gt, rows, in_f), np.uint8))
+    h0 = r.standard_normal((T, rows)).astype(np.float32)
+    nw = (1.0 + 0.1 * r.standard_normal(rows)).astype(np.float32)
+    h1 = DB.from_numpy(h0)
+    assert ops.gemm_quant_ws(h1, W, Xd, T, rows, in_f, dt, resid=h1) == 0
+    x1 = DB.zeros(T * rows * 4)
+    ops.launch_rmsnorm(x1, h1, DB.from_numpy(nw), T, rows, eps)
+    h2, x2 = DB.from_numpy(h0), DB.zeros(T * rows * 4)
+    rm, zz = DB.from_numpy(np.full(T, np.nan, np.float32)), DB.from_numpy(np.full(T, 3.0, np.float32))
+    ns = ops.gemm_deferred_then_consumer("norm", W, Xd, T, rows, in_f, dt, hidden=h2, weight=DB.from_numpy(nw), eps=eps, x_out=x2, row_max_out=rm, zero=zz)
+    H1, X1 = h1.numpy(np.float32), x1.numpy(np.float32).reshape(T, rows)
+    assert np.isfinite(H1).all() and np.array_equal(H1, h2.numpy(np.float32))
+    assert np.array_equal(X1, x2.numpy(np.float32).reshape(T, rows))
+    assert np.array_equal(rm.numpy(np.float32), np.abs(X1).max(axis=1)) and not zz.numpy(np.float32).any()
+    # (b) silu(gate) * up of a two-matrix launch
+    Wg = DB.from_numpy(np.frombuffer(G.synth_tensor(r, gt, rows, in_f), np.uint8))
+    Wu = DB.from_numpy(np.frombuffer(G.synth_tensor(r, gt, rows, in_f), np.uint8))
+    g1, u1 = DB.zeros(T * rows * 4), DB.zeros(T * rows * 4)
+    assert ops.gemm_quant_ws_multi([(Wg, g1, rows, dt), (Wu, u1, rows, dt)], Xd, T, in_f) == 0
+    a1 = DB.zeros(T * rows * 4)
+    ops.launch_silu_mul(a1, g1, u1, T * rows)
+    a2 = DB.zeros(T * rows * 4)
+    ns2 = ops.gemm_deferred_then_consumer("silu", (Wg, Wu), Xd, T, rows, in_f, dt, output=a2, row_max_out=zz)
+    A1 = a1.numpy(np.float32).reshape(T, rows)
+    A2 = a2.numpy(np.float32).reshape(T, rows)
+    assert np.isfinite(A1).all() and np.array_equal(A1, A2), (ns2, int((A1 != A2).sum()), float(np.abs(A1 - A2).max()), np.argwhere(A1 != A2)[:6].tolist())
+    assert np.array_equal(zz.numpy(np.float32), np.abs(A1).max(axis=1))
+    if (T, rows, in_f) == (64, 1024, 2048): assert ns > 1 and ns2 > 1   # (a narrow matrix at one chunk of tokens does split K)
+    if T > 1024: assert ns == 1 and ns2 == 1
+
+
+@pytest.mark.parametrize("T,nh,nkv,hd,interleaved,start_pos,max_seq", [(5, 4, 2, 64, 0, 0, 64), (70, 32, 8, 128, 0, 10, 128), (9, 6, 3, 80, 1, 3, 10), (64, 8, 8, 256, 0, 0, 64)])
+def test_rope_kv_store_equals_rope_then_copy_to_kv_cache(T, nh, nkv, hd, interleaved, start_pos, max_seq):
+    """ntk_rope_kv_store (a prompt's rotation and cache store as one launch) against ntk_rope + ntk_copy_to_kv_cache (reference attention.cpp:164-184,
+    pinned to the oracle by test_rope / test_copy_to_kv_cache_is_bit_exact): the rotated q and both caches equal bit for bit, rows before start_pos and
+    past the prompt untouched, rows that would fall past max_seq dropped (attention.cu:336)."""
+    r = rng(T + nh + hd)
+    q = r.standard_normal(T * nh * hd).astype(np.float32)
+    k = r.standard_normal(T * nkv * hd).astype(np.float32)
+    v = r.standard_normal(T * nkv * hd).astype(np.float32)
+    pos = DB.from_numpy(np.arange(start_pos, start_pos + T, dtype=np.int32))
+    junk = r.integers(0, 65536, max_seq * nkv * hd).astype(np.uint16)
+    theta = 500000.0
+    q1, k1 = DB.from_numpy(q), DB.from_numpy(k)
+    kc1, vc1 = DB.from_numpy(junk), DB.from_numpy(junk[::-1].copy())
+    ops.launch_rope(q1, k1, pos, 1, T, nh, nkv, hd, theta, 1.0, interleaved)
+    ops.launch_copy_to_kv_cache(kc1, vc1, k1, DB.from_numpy(v), T, nkv, hd, start_pos, max_seq)
+    q2, k2, v2 = DB.from_numpy(q), DB.from_numpy(k), DB.from_numpy(v)
+    kc2, vc2 = DB.from_numpy(junk), DB.from_numpy(junk[::-1].copy())
+    ops.rope_kv_store(q2, k2, v2, pos, T, nh, nkv, hd, theta, 1.0, interleaved, kc2, vc2, start_pos, max_seq)
+    assert np.array_equal(q1.numpy(np.float32), q2.numpy(np.float32))
+    assert np.array_equal(k2.numpy(np.float32), k) and np.array_equal(v2.numpy(np.float32), v)          # k, v only read
+    assert np.array_equal(kc1.numpy(np.uint16), kc2.numpy(np.uint16)) and np.array_equal(vc1.numpy(np.uint16), vc2.numpy(np.uint16))
+    assert not np.array_equal(kc2.numpy(np.uint16), junk)
+
+
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_0", "Q4_K", "Q5_K", "Q6_K"])
 @pytest.mark.parametrize("T,out_f,in_f", [(1, 16, 256), (5, 64, 512), (64, 128, 4096), (37, 272, 1024), (100, 144, 2048), (9, 32, 768),
                                           (64, 1024, 4096), (130, 48, 8192), (20, 64, 14336), (64, 32, 28672), (300, 64, 512), (520, 48, 1024), (1100, 32, 256)])
