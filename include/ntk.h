@@ -287,8 +287,10 @@ int ntk_gemm_quant_ws_multi_rm(const ntk_gemv_seg* segs, int nseg, const float* 
                                size_t workspace_bytes, int reuse_x, const float* row_max, void* stream);
 /* ... and the projection's split-K sums folded into the launch that consumes it.  The *_deferred forms run the same launch but, when it splits K,
  * leave the partial sums in the workspace instead of launching the reduce: *partials then describes them (nsplit > 1; valid until the next call with
- * this workspace) -- or says nsplit == 1, in which case Y was written as usual.  No residual input: the consumer adds it.
- *   ntk_reduce_rmsnorm_rowmax : hidden[t] = (sum of the splits, in order) + hidden[t]  (= the residual epilogue's association), x_out = rmsnorm(hidden)
+ * this workspace) -- or says nsplit == 1, in which case Y was written as usual (with `resid` added by the launch's epilogue, single-matrix form; a
+ * launch that does split K ignores `resid`: its consumer adds the residual).
+ *   ntk_reduce_rmsnorm_rowmax : hidden[t] = (sum of the splits, in order) + hidden[t]  (= the residual epilogue's association; nsplit == 1: nothing to add when
+ *                               the launch ran with Y = resid = hidden, else hidden += Y), x_out = rmsnorm(hidden)
  *                               with row_max / zero_tokens as ntk_rmsnorm_rowmax: Wo / down projection + residual + the next RMSNorm, one launch;
  *   ntk_reduce_silu_mul_rowmax: output[t] = silu(gate[t]) * up[t] of a deferred two-matrix gate | up launch, with row_max as ntk_silu_mul_rowmax.
  * Identical bits to the separate launches (same sums in the same order). */
@@ -299,8 +301,8 @@ typedef struct ntk_gemm_partials {
     int          nseg, n_tokens, nsplit;
 } ntk_gemm_partials;
 int ntk_gemm_quant_ws_deferred(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype,
-                               void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials,
-                               void* stream);
+                               const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max,
+                               ntk_gemm_partials* partials, void* stream);
 int ntk_gemm_quant_ws_multi_deferred(const ntk_gemv_seg* segs, int nseg, const float* X, int n_tokens, int in_features, void* workspace,
                                      size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials, void* stream);
 int ntk_reduce_rmsnorm_rowmax(float* hidden, const ntk_gemm_partials* partials, const float* weight, float eps, float* x_out, float* row_max,

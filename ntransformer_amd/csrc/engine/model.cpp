@@ -679,8 +679,8 @@ int Model::layers_1to1(int T, int start_pos, int first, int last_layer) {
         raw_begin();
         const void* wp = raw_of(w);
         ntk_gemm_partials pt;
-        // (Y, used when the launch does not split K: residual_ -- the previous RMSNorm's output, consumed by the projections before this one)
-        int st = ntk_gemm_quant_ws_deferred(residual_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, gemm_ws_, gemm_ws_bytes_, 0, rm, &pt, s);
+        // (a launch that does not split K adds the residual in its own epilogue, in place, as project_add does: nothing is deferred then)
+        int st = ntk_gemm_quant_ws_deferred(hidden_, wp, X, T, (int)w.out_f, (int)w.in_f, w.dtype, hidden_, gemm_ws_, gemm_ws_bytes_, 0, rm, &pt, s);
         if (st == NTK_E_DTYPE || st == NTK_E_SHAPE || st == NTK_E_ALIGN) return false;   // (nothing was launched)
         planes_of = nullptr;
         if (st == NTK_OK) st = ntk_reduce_rmsnorm_rowmax(hidden_, &pt, (const float*)nw.ptr, cfg_.norm_eps, residual_, rm_a, zero_b ? rm_b : nullptr, s);

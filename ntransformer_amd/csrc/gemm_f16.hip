@@ -1273,10 +1273,11 @@ int ntk_gemm_quant_ws_rm(float* Y, const void* W, const float* X, int n_tokens, 
                          const float* resid, void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, void* stream) {
     return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, row_max, nullptr, stream);
 }
-int ntk_gemm_quant_ws_deferred(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype, void* workspace,
-                               size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials, void* stream) {
+int ntk_gemm_quant_ws_deferred(float* Y, const void* W, const float* X, int n_tokens, int out_features, int in_features, int weight_dtype, const float* resid,
+                               void* workspace, size_t workspace_bytes, int reuse_x, const float* row_max, ntk_gemm_partials* partials, void* stream) {
     if (!partials) return NTK_E_NULL;
-    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, nullptr, workspace, workspace_bytes, reuse_x, row_max, partials, stream);
+    // (resid: added by the launch's own epilogue when it does not split K -- nothing is deferred then; ignored, i.e. left to the consumer, when it does)
+    return gemm_quant_ws_impl(Y, W, X, n_tokens, out_features, in_features, weight_dtype, resid, workspace, workspace_bytes, reuse_x, row_max, partials, stream);
 }
 
 // several matrices of one format sharing X (Q | K | V, gate | up) in ONE launch: segs[i] = {Y_i [n_tokens][rows_i], W_i, rows_i}
@@ -1323,8 +1324,8 @@ int ntk_reduce_rmsnorm_rowmax(float* hidden, const ntk_gemm_partials* p, const f
     const int T = p->n_tokens, H = p->rows[0];
     hipStream_t st = ntk::resolve_stream(stream);
     const dim3 block(H <= 1024 ? 256 : (H <= 4096 ? 512 : 1024));
-    if (p->nsplit == 1 || !p->part[0]) {   // the projection wrote Y = W . X itself (p->y[0]; no residual in a deferred launch): hidden += Y first
-        if (p->y[0] != hidden) {
+    if (p->nsplit == 1 || !p->part[0]) {   // the projection wrote Y itself: in place over hidden with the residual added by its epilogue (Y = resid = hidden), or
+        if (p->y[0] != hidden) {              // Y = W . X elsewhere: hidden += Y first
             const size_t n4 = ((size_t)T * H + 3) / 4;
             if (((size_t)T * H) % 4 != 0 || (reinterpret_cast<uintptr_t>(hidden) & 15) || (reinterpret_cast<uintptr_t>(p->y[0]) & 15)) return NTK_E_ALIGN;
             ntk::ReduceArgs ra{};

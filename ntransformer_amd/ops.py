@@ -256,9 +256,11 @@ def gemm_deferred_then_consumer(kind, W, X, n_tokens, rows, in_features, dtype, 
     if kind == "norm":
         n = int(L.ntk_gemm_quant_workspace_bytes(C.c_int(in_features), C.c_int(rows)))
         ws, y = DeviceBuffer(n), DeviceBuffer(n_tokens * rows * 4)
-        L.ntk_gemm_quant_ws_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
-                                                 C.c_void_p, C.POINTER(_lib.GemmPartials), C.c_void_p]
-        check(L.ntk_gemm_quant_ws_deferred(y.ptr, _p(W), _p(X), n_tokens, rows, in_features, int(dtype), ws.ptr, n, 0, _p(row_max), C.byref(pt), None), "gemm deferred")
+        in_place = kw.get("in_place", True)   # Y = resid = hidden (the engine's form) or Y elsewhere and no residual input (the consumer adds Y)
+        L.ntk_gemm_quant_ws_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                 C.c_int, C.c_void_p, C.POINTER(_lib.GemmPartials), C.c_void_p]
+        check(L.ntk_gemm_quant_ws_deferred(_p(kw["hidden"]) if in_place else y.ptr, _p(W), _p(X), n_tokens, rows, in_features, int(dtype),
+                                           _p(kw["hidden"]) if in_place else None, ws.ptr, n, 0, _p(row_max), C.byref(pt), None), "gemm deferred")
         L.ntk_reduce_rmsnorm_rowmax.argtypes = [C.c_void_p, C.POINTER(_lib.GemmPartials), C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         check(L.ntk_reduce_rmsnorm_rowmax(_p(kw["hidden"]), C.byref(pt), _p(kw["weight"]), kw["eps"], _p(kw["x_out"]), _p(kw["row_max_out"]), _p(kw.get("zero")), None),
               "reduce_rmsnorm_rowmax")

@@ -213,7 +213,8 @@ def test_gemm_quant_f16_split_sums_folded_into_the_consuming_launch(qname, T, ro
     ops.launch_rmsnorm(x1, h1, DB.from_numpy(nw), T, rows, eps)
     h2, x2 = DB.from_numpy(h0), DB.zeros(T * rows * 4)
     rm, zz = DB.from_numpy(np.full(T, np.nan, np.float32)), DB.from_numpy(np.full(T, 3.0, np.float32))
-    ns = ops.gemm_deferred_then_consumer("norm", W, Xd, T, rows, in_f, dt, hidden=h2, weight=DB.from_numpy(nw), eps=eps, x_out=x2, row_max_out=rm, zero=zz)
+    ns = ops.gemm_deferred_then_consumer("norm", W, Xd, T, rows, in_f, dt, hidden=h2, weight=DB.from_numpy(nw), eps=eps, x_out=x2, row_max_out=rm, zero=zz,
+                                         in_place=(gt != G.GGML_Q4_K))   # (Q8_0: Y = resid = hidden, the engine's form; Q4_K: Y elsewhere, the consumer adds it)
     H1, X1 = h1.numpy(np.float32), x1.numpy(np.float32).reshape(T, rows)
     assert np.isfinite(H1).all() and np.array_equal(H1, h2.numpy(np.float32))
     assert np.array_equal(X1, x2.numpy(np.float32).reshape(T, rows))
