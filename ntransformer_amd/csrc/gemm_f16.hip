@@ -8,7 +8,7 @@
 //   * a GGUF weight is (integer) x (scale): the INTEGER part (Q8_0: -128..127, Q4_K: 0..15, Q6_K: -32..31) is exact in FP16;
 //   * an F32 activation x is scaled by a power of two s -- one per token, chosen so that the token's largest |x| s lies in
 //     [2^14, 2^15) -- and split into TWO FP16 pieces: h1 = rn16(x s), h2 = rn16(x s - h1).  The difference is exact in F32 (13
-//     significant bits), so |x s - h1 - h2| <= 2^-23 |x s| -- one F32 ulp of the activation -- for every x within 2^-17 of the
+//     significant bits), so |x s - h1 - h2| <= 2^-23 |x s| -- one F32 ulp of the activation -- for every x within 2^-16 of the
 //     token's largest, and <= 2^-25 / s (2^-39 of the largest) below that, where h2 is an FP16 subnormal (2^-28 of the largest if
 //     the matrix cores flush it) -- against the 2^-24 every F32 addition of the reference's own accumulation (gemm.cu:129-141)
 //     rounds by.  Round 2 used three BF16 pieces (8 + 8 + 8 bits, nothing rounded at all): one third more matrix instructions
